@@ -1,0 +1,202 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz by running the REFERENCE's
+own classes (imported from /root/reference through oracle/ref_stubs.py) on seeded
+synthetic inputs.  Run in the build container only:
+
+    python -B oracle/gen_golden.py
+
+The reference tree never travels; only the resulting input/output vectors do.
+Weights are not stored: both sides regenerate them with
+oracle.pose_oracle.make_state(kind, cfg, seed) (a per-key seeded fill, independent
+of module construction order).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import ref_stubs  # noqa: E402
+from oracle import pose_oracle as po  # noqa: E402
+
+ref_stubs.install()
+sys.path.insert(0, "/root/reference")
+from models.losses import PoseDistanceLoss  # noqa: E402
+from models.naive import NaiveEndEffectorStateEstimator, NaiveObjectStateEstimator  # noqa: E402
+from models.time_sensitive import (  # noqa: E402
+    TemporallyDependentObjectStateEstimator,
+    TemporallyDependentObjectStateEstimatorV2,
+    TemporallyDependentStateEstimator,
+)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+CASES = {
+    # kind: (cfg, lead, weight seed, data seed)
+    "no": (dict(latent_dim=64, hidden=[32, 16], use_depth=False, no_proprioception=False), (2,), 11, 101),
+    "n": (dict(latent_dim=64, hidden=[32]), (2,), 12, 102),
+    "td": (dict(latent_dim=64, hidden=32, use_depth=False), (2, 2), 13, 103),
+    "tdo": (dict(latent_dim=64, hidden=32, use_depth=True, no_proprioception=False), (2, 2), 14, 104),
+    "tdo_v2": (dict(latent_dim=64, hidden=32, proprio_hidden=8, use_depth=False), (2, 2), 15, 105),
+}
+LOSS_CFG = dict(distance_metric="combined", scale_factor=1.0, alpha=0.5, mode="pose")
+
+
+def build(kind, cfg):
+    L = cfg["latent_dim"]
+    if kind == "n":
+        return NaiveEndEffectorStateEstimator(list(cfg["hidden"]), list(cfg["hidden"]), 50, L, False)
+    if kind == "no":
+        return NaiveObjectStateEstimator("cube", list(cfg["hidden"]), 50, L, False, (9,), cfg["use_depth"], False,
+                                         cfg["no_proprioception"])
+    if kind == "td":
+        return TemporallyDependentStateEstimator(cfg["hidden"], cfg["hidden"], 50, L, 2, 0.1, False, (9,),
+                                                 cfg["use_depth"], False)
+    if kind == "tdo":
+        return TemporallyDependentObjectStateEstimator("hammer", cfg["hidden"], 50, L, 2, 0.1, False, (9,),
+                                                       cfg["use_depth"], False, cfg["no_proprioception"])
+    return TemporallyDependentObjectStateEstimatorV2("robot1_eef", cfg["hidden"], cfg["proprio_hidden"], 50, L, 2, 0.1,
+                                                     False, (9,), cfg["use_depth"], False)
+
+
+def load_values(model, kind, sd):
+    real = {k: v for k, v in sd.items() if not k.startswith("~")}
+    missing = model.load_state_dict(real, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    if kind == "td":  # unregistered heads (plain lists): assign directly
+        with torch.no_grad():
+            model.aux_nets[0][0].weight.copy_(sd["~aux_nets.0.0.weight"])
+            model.aux_nets[0][0].bias.copy_(sd["~aux_nets.0.0.bias"])
+            model.depth_nets[0][2].weight.copy_(sd["~depth_nets.0.2.weight"])
+            model.depth_nets[0][2].bias.copy_(sd["~depth_nets.0.2.bias"])
+
+
+def digest(t):
+    t = t.detach().double().flatten()
+    return np.array([t.sum().item(), t.norm().item(), t.abs().max().item() if t.numel() else 0.0])
+
+
+def run_case(kind):
+    cfg, lead, wseed, dseed = CASES[kind]
+    torch.manual_seed(0)
+    model = build(kind, cfg)
+    sd = po.make_state(kind, cfg, wseed)
+    # the key table itself is part of what is pinned
+    ref_keys = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    mine = [(k, tuple(s)) for k, s in po.model_keys(kind, cfg) if not k.startswith("~")]
+    assert ref_keys == mine, "state_dict key table mismatch for %s" % kind
+    load_values(model, kind, sd)
+    model.train()
+    model.reset_initial_state(lead[-1])
+    crit = PoseDistanceLoss(**LOSS_CFG)
+    val = PoseDistanceLoss(mode="val")
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    rec = {"keys": np.array([k for k, _ in ref_keys])}
+
+    def eval_pass(tag):
+        # eval-mode forward (BN running-stats path) and the rollout contract (carried (h, c))
+        model.eval()
+        model.rollout = False
+        model.reset_initial_state(lead[-1])
+        with torch.no_grad():
+            b = po.synth_batch(lead, dseed + 9, with_depth=cfg.get("use_depth", False))
+            depth = b["depth"] if b["depth"] is not None else torch.empty(*b["img"].shape)
+            out = model(b["img"], depth, b["x0bar"])
+            if isinstance(out, tuple):
+                rec[tag + "eval_out0"], rec[tag + "eval_out1"] = out[0].numpy(), out[1].numpy()
+            else:
+                rec[tag + "eval_out0"] = out.numpy()
+            if kind in ("td", "tdo", "tdo_v2"):
+                model.rollout = True
+                model.reset_initial_state(lead[-1])
+                o1 = model(b["img"][:1], depth[:1], b["x0bar"][:1])
+                o2 = model(b["img"][1:], depth[1:], b["x0bar"][1:])
+                o1 = o1[-1] if isinstance(o1, tuple) else o1
+                o2 = o2[-1] if isinstance(o2, tuple) else o2
+                rec[tag + "rollout_out"] = torch.cat([o1, o2], 0).numpy()
+                model.rollout = False
+        model.train()
+        model.reset_initial_state(lead[-1])
+
+    eval_pass("pre_")
+    for step in (1, 2):
+        b = po.synth_batch(lead, dseed + step, with_depth=cfg.get("use_depth", False))
+        depth = b["depth"] if b["depth"] is not None else torch.empty(*b["img"].shape)
+        opt.zero_grad()
+        out = model(b["img"], depth, b["x0bar"])
+        if kind in ("n", "td"):
+            loss = crit(out[0], b["x0"]) + crit(out[1], b["x1"])
+            pos_err, ori_err = val(out[1], b["x1"])
+            rec["out0_s%d" % step] = out[0].detach().numpy()
+            rec["out1_s%d" % step] = out[1].detach().numpy()
+        else:
+            loss = crit(out, b["obj"])
+            pos_err, ori_err = val(out, b["obj"])
+            rec["out0_s%d" % step] = out.detach().numpy()
+        loss.backward()
+        rec["loss_s%d" % step] = np.array(loss.item())
+        rec["pos_err_s%d" % step] = np.array(float(pos_err))
+        rec["ori_err_s%d" % step] = np.array(float(ori_err))
+        gnames, gdig = [], []
+        for name, p in model.named_parameters():
+            if p.grad is not None:
+                gnames.append(name)
+                gdig.append(digest(p.grad))
+        rec["grad_keys_s%d" % step] = np.array(gnames)
+        rec["grad_digest_s%d" % step] = np.stack(gdig)
+        if step == 1:  # a few raw gradient tensors (small ones) for element-wise checks
+            named = dict(model.named_parameters())
+            for name in gnames:
+                if named[name].numel() <= 4096:
+                    rec["grad::" + name] = named[name].grad.detach().numpy().copy()
+        opt.step()
+    fin = model.state_dict()
+    rec["final_digest"] = np.stack([digest(fin[k]) for k, _ in ref_keys])
+    for k, _ in ref_keys:  # small tensors kept element-wise (biases, BN stats of the stem, heads)
+        if fin[k].numel() <= 4096 and fin[k].dtype.is_floating_point:
+            rec["final::" + k] = fin[k].detach().numpy().copy()
+    eval_pass("post_")
+    np.savez_compressed(os.path.join(OUT, "model_%s.npz" % kind), **rec)
+    print(kind, "loss", rec["loss_s1"], rec["loss_s2"], "pos/ori err", rec["pos_err_s1"], rec["ori_err_s1"])
+
+
+def run_loss():
+    g = torch.Generator().manual_seed(7)
+    rec = {}
+    pred = torch.randn(3, 5, 7, generator=g)
+    pred[0, 0, 3:] *= -1  # make sure some predicted w are negative (penalty branch)
+    truth = po._rand_pose((3, 5), g)
+    rec["pred"], rec["truth"] = pred.numpy(), truth.numpy()
+    for metric in ("l1", "l2", "linf", "combined"):
+        for mode in ("position", "pose"):
+            for scale, alpha in ((1.0, 1.0), (2.5, 0.5)):
+                p = pred.clone().requires_grad_(True)
+                l = PoseDistanceLoss(metric, scale, alpha, 1e-4, mode)(p, truth)
+                l.backward()
+                tag = "%s_%s_%g_%g" % (metric, mode, scale, alpha)
+                rec["loss::" + tag] = np.array(l.item())
+                rec["grad::" + tag] = p.grad.numpy().copy()
+    pe, oe = PoseDistanceLoss(mode="val")(pred, truth)
+    rec["val_pos"], rec["val_ori"] = np.array(float(pe)), np.array(float(oe))
+    for bad in (dict(distance_metric="l3"), dict(mode="train")):
+        try:
+            PoseDistanceLoss(**bad)
+            raise AssertionError("expected ValueError")
+        except ValueError:
+            pass
+    np.savez_compressed(os.path.join(OUT, "pose_loss.npz"), **rec)
+    print("loss fixtures written")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["loss"] + list(CASES)
+    for w in which:
+        if w == "loss":
+            run_loss()
+        else:
+            run_case(w)
