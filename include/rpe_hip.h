@@ -1,0 +1,201 @@
+/*
+ * rpe_hip.h -- C ABI of librpe_hip.so: the MI355X (gfx950) implementation of the
+ * RGB + proprioception pose-regression TRAIN STEP of
+ * cremebrule/rgb-proprioceptive-pose-estimator.
+ *
+ * The reference has no FFI / plugin layer: the path sits behind Python classes
+ * (models/naive.py, models/time_sensitive.py, models/losses.py, util/learn_utils.py).
+ * Every entry point below therefore replaces the torch op(s) a reference line
+ * dispatches; the citation after "replaces:" is the reference file:line.  The Python
+ * host side (rgb-proprioceptive-pose-estimator_amd/) binds these with ctypes and
+ * keeps the reference's class / constructor / state_dict surface.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer unless its name ends in _host.  Buffers are
+ *    borrowed: nothing is freed or retained past the call except by the engine
+ *    object, which retains exactly what rpe_resnet50_bind() hands it.
+ *  - `stream` is a hipStream_t passed as void*.  Calls only enqueue work; no entry
+ *    point synchronises, allocates or frees device memory (hipGraph-capturable).
+ *  - Activations of the conv trunk are NHWC ([B][H][W][C], C contiguous) in the
+ *    compute dtype (RPE_F32 or RPE_BF16; accumulation is always fp32).  Head tensors
+ *    (features, MLP / LSTM, loss) are fp32 with a leading dimension `ld`.
+ *  - Operands must be 16-byte aligned and channel counts / leading dimensions
+ *    multiples of the 16-byte chunk (4 fp32 / 8 bf16) unless stated otherwise.
+ *  - Return value: 0 on success, an RPE_ERR_* code otherwise; rpe_last_error()
+ *    returns a thread-local message.  No exceptions cross the boundary.
+ */
+#ifndef RPE_HIP_H
+#define RPE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPE_ABI_VERSION 1
+
+enum { RPE_F32 = 0, RPE_BF16 = 1 };
+enum {
+    RPE_OK = 0,
+    RPE_ERR_SHAPE = 1,     /* bad dimension / unsupported configuration */
+    RPE_ERR_DTYPE = 2,
+    RPE_ERR_ALIGN = 3,
+    RPE_ERR_HIP = 4,       /* a HIP runtime call failed */
+    RPE_ERR_WORKSPACE = 5, /* caller-provided workspace too small */
+    RPE_ERR_STATE = 6      /* engine used before bind / forward */
+};
+
+int rpe_abi_version(void);
+const char* rpe_last_error(void);
+
+/* ------------------------------------------------------------------ convolution */
+/* replaces: nn.Conv2d(bias=False) forward/backward inside torchvision resnet50
+ * (constructed at util/model_utils.py:136, called at models/naive.py:84,316 and
+ * models/time_sensitive.py:185,472,733). */
+typedef struct {
+    int batch, in_h, in_w, in_c; /* NHWC input */
+    int out_c, kh, kw;
+    int stride, pad;             /* stride 1 or 2 */
+} rpe_conv_desc;
+
+int rpe_conv_out_hw(const rpe_conv_desc* d, int* ho, int* wo);
+/* number of 128-row tiles = rows of the BN partial-sum buffer [tiles][2][out_c] */
+long rpe_conv_stats_tiles(long rows);
+
+/* y[B][Ho][Wo][out_c] = conv(x, w);  w_krsc = [out_c][kh][kw][in_c].
+ * stats_part (nullable): per-128-row-tile column sums and sums of squares of the fp32
+ * accumulators, consumed by rpe_bn_finalize. */
+int rpe_conv2d_fwd(const rpe_conv_desc* d, int dtype, const void* x, const void* w_krsc, void* y, float* stats_part, void* stream);
+/* dx[B][H][W][in_c] = conv_transpose(dy, w) (+ addend);  w_crsk = [in_c][kh][kw][out_c]. */
+int rpe_conv2d_dgrad(const rpe_conv_desc* d, int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, void* stream);
+/* dw_krsc[out_c][kh][kw][in_c] (fp32) += x (*) dy.  Atomic accumulation: zero it first. */
+int rpe_conv2d_wgrad(const rpe_conv_desc* d, int dtype, const void* x, const void* dy, float* dw_krsc, void* stream);
+
+/* ResNet stem conv1 (3->64, 7x7 / 2, pad 3) on the NHWC4 image produced by
+ * rpe_stage_image_nhwc4; w_packed = [64][8][8][4] from rpe_pack_stem_weight. */
+int rpe_stem_conv_fwd(int dtype, const void* x4, const void* w_packed, void* y, float* stats_part, int B, int H, int W, void* stream);
+int rpe_stem_conv_wgrad(int dtype, const void* x4, const void* dy, float* dw_packed, int B, int H, int W, void* stream);
+
+/* weight layouts.  w_krsc_f32 is the fp32 master in channels_last storage. */
+int rpe_pack_conv_weight(int dtype, const float* w_krsc, void* w_fwd, void* w_dgrad, int Co, int R, int S, int Ci, void* stream);
+int rpe_pack_stem_weight(int dtype, const float* w_oihw, void* out, void* stream);
+int rpe_unpack_stem_grad(const float* d_packed, float* dw_oihw, void* stream);
+
+/* replaces: the per-tensor .cuda() staging of util/learn_utils.py:130-138 for `img`
+ * ((B,3,H,W) fp32 NCHW, util/data_utils.py:62-73) -> NHWC4 in the compute dtype. */
+int rpe_stage_image_nhwc4(int dtype, const float* img_nchw, void* out, int B, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------ batch norm */
+/* replaces: nn.BatchNorm2d (train mode: biased batch variance, eps, momentum with
+ * unbiased running variance) + the in-place nn.ReLU and `out += identity` of the
+ * torchvision Bottleneck. */
+int rpe_bn_finalize(const float* part, int tiles, int C, long count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, long long* num_batches, float momentum, float eps, float* scale, float* shift,
+                    float* save_mean, float* save_invstd, void* stream);
+int rpe_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                       float* scale, float* shift, void* stream);
+/* out = relu?(y*scale + shift (+ residual)) */
+int rpe_bn_apply(int dtype, const void* y, const void* residual, void* out, const float* scale, const float* shift, long rows, int C,
+                 int relu, void* stream);
+/* dz = dA * (a_out > 0) (a_out null: no ReLU); dgamma, dbeta; dy = BN backward of dz; dz_out (nullable) = dz.
+ * part: >= 2*1024*C floats of scratch; c1c2: 2*C floats of scratch. */
+int rpe_bn_backward(int dtype, const void* dA, const void* a_out, const void* y, const float* mean, const float* invstd,
+                    const float* gamma, float* dgamma, float* dbeta, void* dy, void* dz_out, long rows, int C, float* part,
+                    long part_floats, float* c1c2, void* stream);
+
+/* ------------------------------------------------------------------ pooling */
+/* replaces: nn.MaxPool2d(3, 2, 1) of the ResNet stem; idx keeps the winning tap. */
+int rpe_maxpool3x3s2_fwd(int dtype, const void* x, void* out, unsigned char* idx, int B, int H, int W, int C, void* stream);
+int rpe_maxpool3x3s2_bwd(int dtype, const void* dout, const unsigned char* idx, const void* addend, void* dx, int B, int H, int W, int C,
+                         void* stream);
+/* replaces: nn.AdaptiveAvgPool2d((1,1)) + flatten; output fp32 [B][C] */
+int rpe_avgpool_fwd(int dtype, const void* x, float* out, int B, int HW, int C, void* stream);
+int rpe_avgpool_bwd(int dtype, const float* dout, void* dx, int B, int HW, int C, void* stream);
+
+/* ------------------------------------------------------------------ heads */
+/* replaces: aux_nets[i] = Conv2d(64->1,1x1) -> MaxPool2d(2) -> Flatten and the
+ * `aux * depth` product (models/naive.py:223-231,318-330; time_sensitive.py:377-385,477-488).
+ * out[b*ld_out + p] = max2x2(a1 . w + bias) * (depth_feat ? depth_feat[b][p] : 1); raw keeps the
+ * un-multiplied value, idx the winning pixel. */
+int rpe_aux_head_fwd(int dtype, const void* a1, const float* w, const float* bias, const float* depth_feat, float* out, long ld_out,
+                     float* raw, unsigned char* idx, int B, int H, int W, void* stream);
+int rpe_aux_head_bwd(int dtype, const float* dout, long ld_dout, const void* a1, const float* w, const float* depth_feat, const float* raw,
+                     const unsigned char* idx, void* d_a1, float* dw, float* dbias, float* d_depth_feat, int B, int H, int W, void* stream);
+/* replaces: depth_nets[i] = AvgPool2d(2) x2 -> InstanceNorm2d(1, affine) -> Flatten (models/naive.py:233-240) */
+int rpe_depth_head_fwd(const float* depth, const float* w, const float* b, float* feat, float* xhat, int B, int H, int W, void* stream);
+int rpe_depth_head_bwd(const float* d_feat, const float* xhat, long n, float* dw, float* db, void* stream);
+
+/* replaces: nn.Linear (+ F.relu) of the proprio-fusion MLP (models/naive.py:343-345), the
+ * ResNet fc (util/model_utils.py:141), the LSTM input/recurrent GEMMs and the fc heads
+ * (models/time_sensitive.py:420-423,510).  y[M][N] = x[M][K] w[N][K]^T (+bias) (+addend) (relu).
+ * The data gradient is the same call with the transposed weight. */
+int rpe_linear_fwd(int dtype, const void* x, int ldx, const void* w, int ldw, const float* bias, void* y, int ldy, int M, int N, int K,
+                   int relu, const void* addend, int ld_add, void* stream);
+/* dw[N][K] (fp32, ld lddw) += dy[M][N]^T x[M][K]  (atomic accumulation) */
+int rpe_linear_wgrad(int dtype, const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int M, int N, int K, void* stream);
+int rpe_transpose_f32(const float* in, float* out, int rows, int cols, int ldi, int ldo, void* stream);
+int rpe_relu_bwd(const float* out, const float* dy, float* dx, long n, void* stream);
+int rpe_colsum(const float* x, long rows, int cols, int ld, float* out, int accumulate, void* stream);
+int rpe_copy2d(const float* src, int ld_src, float* dst, int ld_dst, long rows, int cols, void* stream);
+
+/* replaces: the pointwise part of nn.LSTM (models/time_sensitive.py:212,235,501,759,768); gate order i,f,g,o.
+ * gates[N][4H] holds x W_ih^T + h W_hh^T (no biases) and is overwritten with the activated gates. */
+int rpe_lstm_cell_fwd(float* gates, const float* b_ih, const float* b_hh, const float* c_prev, float* c_out, float* h_out, int N, int Hd,
+                      void* stream);
+int rpe_lstm_cell_bwd(const float* gates_act, const float* c_prev, const float* c_cur, const float* dh, float* dc_io, float* dgates, int N,
+                      int Hd, void* stream);
+
+/* replaces: PoseDistanceLoss.forward (models/losses.py:47-128) and its autograd backward.
+ * metric 0 l2 / 1 l1 / 2 linf / 3 combined; mode 0 position / 1 pose.
+ * out3 = { loss, sum_i sqrt(|dp_i|^2+eps) , sum_i |angle_i| } -- the last two are the "val" mode
+ * outputs (losses.py:95-113) computed on device instead of the per-sample numpy loop.
+ * grad (nullable) = d loss / d pred. */
+int rpe_pose_loss(const float* pred, const float* truth, long n, int metric, int mode, float scale, float alpha, float eps, float* out3,
+                  float* grad, void* stream);
+
+/* replaces: torch.optim.Adam(model.parameters(), lr).step() (scripts/train_model.py:228,
+ * util/learn_utils.py:179) over one flat parameter / gradient / moment buffer. */
+int rpe_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, int step, void* stream);
+
+/* ------------------------------------------------------------------ ResNet-50 trunk engine */
+/* One object = one (batch, dtype) plan for the whole torchvision-shaped ResNet-50 body:
+ * stage image -> conv1/bn1/relu -> maxpool -> 16 bottlenecks -> avgpool -> fc, forward and
+ * backward, launched back to back on one stream with no host round trips.
+ * replaces: self.feature_net(img) and its autograd backward (models/naive.py:316,
+ * models/time_sensitive.py:472) including the bn1 forward hook (models/naive.py:211,282-283). */
+typedef struct rpe_resnet50 rpe_resnet50_t;
+
+#define RPE_RESNET50_NUM_CONV 53
+/* parameter table order: see rpe_resnet50_param_name(); 161 fp32 tensors (53 conv w, 53 x (gamma, beta), fc w, fc b) */
+#define RPE_RESNET50_NUM_PARAMS 161
+/* buffer table: 53 x (running_mean, running_var) fp32 + 53 num_batches_tracked (int64) */
+#define RPE_RESNET50_NUM_BUFFERS 106
+
+int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, int width, int dtype, int latent_dim);
+void rpe_resnet50_destroy(rpe_resnet50_t* e);
+/* bytes of device workspace the engine needs (activations, gradients, packed weights, scratch) */
+long rpe_resnet50_workspace_bytes(const rpe_resnet50_t* e);
+/* state_dict key (torchvision naming, e.g. "layer1.0.conv1.weight") and element count of parameter i */
+const char* rpe_resnet50_param_name(const rpe_resnet50_t* e, int i);
+long rpe_resnet50_param_numel(const rpe_resnet50_t* e, int i);
+/* host arrays of device pointers: params/grads [NUM_PARAMS] fp32 (conv weights in channels_last
+ * storage = [Co][kh][kw][Ci]; conv1.weight plain OIHW), running stats [2*53], num_batches [53] */
+int rpe_resnet50_bind(rpe_resnet50_t* e, void* workspace, long workspace_bytes, float* const* params_host, float* const* grads_host,
+                      float* const* running_host, long long* const* num_batches_host);
+/* re-pack compute-dtype copies of the weights (call after every optimizer step / load_state_dict) */
+int rpe_resnet50_pack_weights(rpe_resnet50_t* e, void* stream);
+/* img: (B,3,H,W) fp32 NCHW.  features: fp32 [B][ld_features] (first latent_dim columns written).
+ * training != 0: batch statistics + running-stat update and everything backward needs is kept. */
+int rpe_resnet50_forward(rpe_resnet50_t* e, const float* img_nchw, float* features, long ld_features, int training, void* stream);
+/* the hooked early feature relu(bn1(conv1 x)): NHWC [B][H/2][W/2][64] in the compute dtype (inside the workspace) */
+const void* rpe_resnet50_early_feature(const rpe_resnet50_t* e);
+/* gradient buffer of the early feature; the caller writes d(loss)/d(early) there (or passes use_d_early = 0) */
+void* rpe_resnet50_early_grad(rpe_resnet50_t* e);
+/* parameter gradients are WRITTEN (not accumulated) into the bound grad tensors */
+int rpe_resnet50_backward(rpe_resnet50_t* e, const float* d_features, long ld_d_features, int use_d_early, void* stream);
+/* debugging / parity: device pointer, rows and channels of a named intermediate (e.g. "layer1.0.y1") */
+int rpe_resnet50_tensor(const rpe_resnet50_t* e, const char* name, const void** ptr, long* rows, int* channels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPE_HIP_H */

@@ -1,0 +1,128 @@
+"""ctypes binding of librpe_hip.so (the C ABI declared in include/rpe_hip.h).
+
+The library is the product: if it is missing or does not export a declared symbol
+the import of this module raises -- there is no eager / CPU fallback anywhere in the
+package.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_longlong, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librpe_hip.so")
+
+RPE_F32, RPE_BF16 = 0, 1
+ABI_VERSION = 1
+
+
+class RpeError(RuntimeError):
+    """A librpe_hip.so entry point returned a non-zero status."""
+
+
+class ConvDesc(Structure):
+    _fields_ = [(n, c_int) for n in ("batch", "in_h", "in_w", "in_c", "out_c", "kh", "kw", "stride", "pad")]
+
+
+P, I, L, F = c_void_p, c_int, c_long, c_float
+PD = POINTER(ConvDesc)
+
+# name -> (restype, argtypes).  Status-returning functions (restype int) are wrapped to raise.
+_SPEC = {
+    "rpe_abi_version": (I, []),
+    "rpe_last_error": (c_char_p, []),
+    "rpe_conv_out_hw": (I, [PD, POINTER(c_int), POINTER(c_int)]),
+    "rpe_conv_stats_tiles": (L, [L]),
+    "rpe_conv2d_fwd": (I, [PD, I, P, P, P, P, P]),
+    "rpe_conv2d_dgrad": (I, [PD, I, P, P, P, P, P]),
+    "rpe_conv2d_wgrad": (I, [PD, I, P, P, P, P]),
+    "rpe_stem_conv_fwd": (I, [I, P, P, P, P, I, I, I, P]),
+    "rpe_stem_conv_wgrad": (I, [I, P, P, P, I, I, I, P]),
+    "rpe_pack_conv_weight": (I, [I, P, P, P, I, I, I, I, P]),
+    "rpe_pack_stem_weight": (I, [I, P, P, P]),
+    "rpe_unpack_stem_grad": (I, [P, P, P]),
+    "rpe_stage_image_nhwc4": (I, [I, P, P, I, I, I, P]),
+    "rpe_bn_finalize": (I, [P, I, I, L, P, P, P, P, P, F, F, P, P, P, P, P]),
+    "rpe_bn_eval_affine": (I, [I, P, P, P, P, F, P, P, P]),
+    "rpe_bn_apply": (I, [I, P, P, P, P, P, L, I, I, P]),
+    "rpe_bn_backward": (I, [I, P, P, P, P, P, P, P, P, P, P, L, I, P, L, P, P]),
+    "rpe_maxpool3x3s2_fwd": (I, [I, P, P, P, I, I, I, I, P]),
+    "rpe_maxpool3x3s2_bwd": (I, [I, P, P, P, P, I, I, I, I, P]),
+    "rpe_avgpool_fwd": (I, [I, P, P, I, I, I, P]),
+    "rpe_avgpool_bwd": (I, [I, P, P, I, I, I, P]),
+    "rpe_aux_head_fwd": (I, [I, P, P, P, P, P, L, P, P, I, I, I, P]),
+    "rpe_aux_head_bwd": (I, [I, P, L, P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "rpe_depth_head_fwd": (I, [P, P, P, P, P, I, I, I, P]),
+    "rpe_depth_head_bwd": (I, [P, P, L, P, P, P]),
+    "rpe_linear_fwd": (I, [I, P, I, P, I, P, P, I, I, I, I, I, P, I, P]),
+    "rpe_linear_wgrad": (I, [I, P, I, P, I, P, I, I, I, I, P]),
+    "rpe_transpose_f32": (I, [P, P, I, I, I, I, P]),
+    "rpe_relu_bwd": (I, [P, P, P, L, P]),
+    "rpe_colsum": (I, [P, L, I, I, P, I, P]),
+    "rpe_copy2d": (I, [P, I, P, I, L, I, P]),
+    "rpe_lstm_cell_fwd": (I, [P, P, P, P, P, P, I, I, P]),
+    "rpe_lstm_cell_bwd": (I, [P, P, P, P, P, P, I, I, P]),
+    "rpe_pose_loss": (I, [P, P, L, I, I, F, F, F, P, P, P]),
+    "rpe_adam_step": (I, [P, P, P, P, L, F, F, F, F, I, P]),
+    "rpe_resnet50_create": (I, [POINTER(c_void_p), I, I, I, I, I]),
+    "rpe_resnet50_destroy": (None, [P]),
+    "rpe_resnet50_workspace_bytes": (L, [P]),
+    "rpe_resnet50_param_name": (c_char_p, [P, I]),
+    "rpe_resnet50_param_numel": (L, [P, I]),
+    "rpe_resnet50_bind": (I, [P, P, L, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
+    "rpe_resnet50_pack_weights": (I, [P, P]),
+    "rpe_resnet50_forward": (I, [P, P, P, L, I, P]),
+    "rpe_resnet50_early_feature": (c_void_p, [P]),
+    "rpe_resnet50_early_grad": (c_void_p, [P]),
+    "rpe_resnet50_backward": (I, [P, P, L, I, P]),
+    "rpe_resnet50_tensor": (I, [P, c_char_p, POINTER(c_void_p), POINTER(c_long), POINTER(c_int)]),
+}
+# entry points whose int return value is data, not a status
+_NOT_STATUS = {"rpe_abi_version"}
+
+EXPORTS = tuple(_SPEC)
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "librpe_hip.so not found at %s -- build it with `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950); there is no fallback path." % LIB_PATH
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SPEC.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError("librpe_hip.so does not export %s (stale build?)" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.rpe_abi_version() != ABI_VERSION:
+        raise ImportError("librpe_hip.so ABI version %d != expected %d" % (lib.rpe_abi_version(), ABI_VERSION))
+    return lib
+
+
+_raw = _load()
+
+
+class _Checked:
+    """Attribute access returns a callable that raises RpeError on a non-zero status."""
+
+    def __getattr__(self, name):
+        fn = getattr(_raw, name)
+        res = _SPEC[name][0]
+        if res is I and name not in _NOT_STATUS:
+
+            def call(*a, _fn=fn, _name=name):
+                rc = _fn(*a)
+                if rc != 0:
+                    raise RpeError("%s failed (%d): %s" % (_name, rc, _raw.rpe_last_error().decode()))
+                return 0
+
+            setattr(self, name, call)
+            return call
+        setattr(self, name, fn)
+        return fn
+
+
+lib = _Checked()
+raw = _raw

@@ -1,0 +1,111 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the pose
+// train-step path.  Wave size is 64 everywhere; no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rpe_hip.h"
+
+namespace rpe {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+constexpr int kWave = 64;
+
+// ---- element traits ---------------------------------------------------------
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int kChunk = 4;  // elements per 16-byte chunk
+    static constexpr int kDtype = RPE_F32;
+    __device__ static inline float to_f(float v) { return v; }
+    __device__ static inline float from_f(float v) { return v; }
+};
+template <> struct Elem<bf16> {
+    static constexpr int kChunk = 8;
+    static constexpr int kDtype = RPE_BF16;
+    __device__ static inline float to_f(bf16 v) { return (float)v; }
+    __device__ static inline bf16 from_f(float v) { return (bf16)v; }
+};
+
+// 16 bytes of T viewed as raw dwords (used for staging through registers / LDS)
+struct alignas(16) Chunk16 {
+    u32x4 v;
+};
+
+__device__ inline float bf16_bits_to_f(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+
+// unpack a 16-byte chunk of T into floats (N = Elem<T>::kChunk)
+template <typename T> __device__ inline void chunk_to_f(const u32x4& c, float* f);
+template <> __device__ inline void chunk_to_f<float>(const u32x4& c, float* f) {
+    f[0] = __uint_as_float(c.x); f[1] = __uint_as_float(c.y); f[2] = __uint_as_float(c.z); f[3] = __uint_as_float(c.w);
+}
+template <> __device__ inline void chunk_to_f<bf16>(const u32x4& c, float* f) {
+    f[0] = __uint_as_float(c.x << 16); f[1] = __uint_as_float(c.x & 0xffff0000u);
+    f[2] = __uint_as_float(c.y << 16); f[3] = __uint_as_float(c.y & 0xffff0000u);
+    f[4] = __uint_as_float(c.z << 16); f[5] = __uint_as_float(c.z & 0xffff0000u);
+    f[6] = __uint_as_float(c.w << 16); f[7] = __uint_as_float(c.w & 0xffff0000u);
+}
+__device__ inline unsigned pack_bf16x2(float lo, float hi) {
+    // plain casts: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserving)
+    bf16 a = (bf16)lo, b = (bf16)hi;
+    unsigned short ua = __builtin_bit_cast(unsigned short, a), ub = __builtin_bit_cast(unsigned short, b);
+    return (unsigned)ua | ((unsigned)ub << 16);
+}
+template <typename T> __device__ inline u32x4 f_to_chunk(const float* f);
+template <> __device__ inline u32x4 f_to_chunk<float>(const float* f) {
+    u32x4 c; c.x = __float_as_uint(f[0]); c.y = __float_as_uint(f[1]); c.z = __float_as_uint(f[2]); c.w = __float_as_uint(f[3]);
+    return c;
+}
+template <> __device__ inline u32x4 f_to_chunk<bf16>(const float* f) {
+    u32x4 c; c.x = pack_bf16x2(f[0], f[1]); c.y = pack_bf16x2(f[2], f[3]); c.z = pack_bf16x2(f[4], f[5]); c.w = pack_bf16x2(f[6], f[7]);
+    return c;
+}
+
+// ---- fast unsigned division by a runtime constant (valid for n < 2^31) -----
+struct FastDiv {
+    unsigned d, mul, shr;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    f.d = d;
+    if (d <= 1) { f.mul = 0; f.shr = 0; return f; }
+    unsigned lg = 0;
+    while ((1ull << lg) < d) ++lg;  // ceil(log2 d)
+    unsigned p = 31 + lg;
+    f.mul = (unsigned)(((1ull << p) + d - 1) / d);
+    f.shr = p - 32;
+    return f;
+}
+__device__ inline unsigned fd_div(unsigned n, const FastDiv& f) { return f.d <= 1 ? n : (__umulhi(n, f.mul) >> f.shr); }
+
+// ---- wave reductions -------------------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ inline double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace rpe
+
+#define RPE_CHECK_LAUNCH()                                        \
+    do {                                                          \
+        hipError_t e__ = hipGetLastError();                       \
+        if (e__ != hipSuccess) return rpe_set_error_hip(e__, __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" int rpe_set_error(int code, const char* msg);
+int rpe_set_error_hip(hipError_t e, const char* file, int line);

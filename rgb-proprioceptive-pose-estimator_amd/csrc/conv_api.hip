@@ -1,0 +1,196 @@
+// C-ABI entry points for the MFMA implicit-GEMM kernels (conv forward / data-gradient /
+// weight-gradient, stem conv, Linear) and the library's error channel.
+#include <stdio.h>
+#include <string.h>
+
+#include "igemm.h"
+
+namespace rpe {
+template <typename T> int launch_nt(NTArgs<T>& a, int mode, hipStream_t s);
+template <typename T> int launch_tn(TNArgs<T>& a, int mode, hipStream_t s);
+}  // namespace rpe
+using namespace rpe;
+
+static thread_local char g_err[512] = "";
+
+extern "C" int rpe_set_error(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "");
+    return code;
+}
+int rpe_set_error_hip(hipError_t e, const char* file, int line) {
+    snprintf(g_err, sizeof(g_err), "HIP error %d (%s) at %s:%d", (int)e, hipGetErrorString(e), file, line);
+    return RPE_ERR_HIP;
+}
+extern "C" const char* rpe_last_error(void) { return g_err; }
+extern "C" int rpe_abi_version(void) { return RPE_ABI_VERSION; }
+
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+static int check_desc(const rpe_conv_desc* d) {
+    if (!d) return rpe_set_error(RPE_ERR_SHAPE, "conv: null descriptor");
+    if (d->batch <= 0 || d->in_h <= 0 || d->in_w <= 0 || d->in_c <= 0 || d->out_c <= 0 || d->kh <= 0 || d->kw <= 0)
+        return rpe_set_error(RPE_ERR_SHAPE, "conv: non-positive dimension");
+    if (d->stride != 1 && d->stride != 2) return rpe_set_error(RPE_ERR_SHAPE, "conv: stride must be 1 or 2");
+    if (d->pad < 0 || d->pad >= d->kh || d->pad >= d->kw) return rpe_set_error(RPE_ERR_SHAPE, "conv: pad must be smaller than the kernel");
+    return 0;
+}
+static inline int out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
+static inline bool is_dense(const rpe_conv_desc* d) { return d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0; }
+
+template <typename T>
+static int conv_fwd_t(const rpe_conv_desc* d, const void* x, const void* w, void* y, float* stats, hipStream_t s) {
+    const int Ho = out_dim(d->in_h, d->kh, d->stride, d->pad), Wo = out_dim(d->in_w, d->kw, d->stride, d->pad);
+    NTArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.A = (const T*)x; a.Bw = (const T*)w; a.C = (T*)y;
+    a.M = d->batch * Ho * Wo; a.N = d->out_c; a.K = d->kh * d->kw * d->in_c;
+    a.lda = d->in_c; a.ldb = a.K; a.ldc = d->out_c;
+    a.stats_part = stats;
+    if (is_dense(d)) return launch_nt<T>(a, MODE_DENSE, s);
+    Gather& g = a.g;
+    g.H = d->in_h; g.W = d->in_w; g.C = d->in_c; g.Ho = Ho; g.Wo = Wo; g.R = d->kh; g.S = d->kw;
+    g.sn = d->stride; g.sd_shift = 0; g.base_h = -d->pad; g.base_w = -d->pad; g.tap_sign = 1;
+    g.div_hw = make_fastdiv(Ho * Wo); g.div_w = make_fastdiv(Wo);
+    g.img_stride = (long)d->in_h * d->in_w * d->in_c;
+    return launch_nt<T>(a, MODE_CONV, s);
+}
+
+template <typename T>
+static int conv_dgrad_t(const rpe_conv_desc* d, const void* dy, const void* w_crsk, void* dx, const void* addend, hipStream_t s) {
+    const int Ho = out_dim(d->in_h, d->kh, d->stride, d->pad), Wo = out_dim(d->in_w, d->kw, d->stride, d->pad);
+    NTArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.A = (const T*)dy; a.Bw = (const T*)w_crsk; a.C = (T*)dx;
+    a.M = d->batch * d->in_h * d->in_w; a.N = d->in_c; a.K = d->kh * d->kw * d->out_c;
+    a.lda = d->out_c; a.ldb = a.K; a.ldc = d->in_c;
+    a.addend = (const T*)addend; a.ld_add = d->in_c;
+    if (is_dense(d)) return launch_nt<T>(a, MODE_DENSE, s);
+    Gather& g = a.g;
+    g.H = Ho; g.W = Wo; g.C = d->out_c; g.Ho = d->in_h; g.Wo = d->in_w; g.R = d->kh; g.S = d->kw;
+    g.sn = 1; g.sd_shift = ilog2(d->stride); g.base_h = d->pad; g.base_w = d->pad; g.tap_sign = -1;
+    g.div_hw = make_fastdiv(d->in_h * d->in_w); g.div_w = make_fastdiv(d->in_w);
+    g.img_stride = (long)Ho * Wo * d->out_c;
+    return launch_nt<T>(a, MODE_CONV, s);
+}
+
+template <typename T>
+static int conv_wgrad_t(const rpe_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t s) {
+    const int Ho = out_dim(d->in_h, d->kh, d->stride, d->pad), Wo = out_dim(d->in_w, d->kw, d->stride, d->pad);
+    TNArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.P = (const T*)dy; a.Q = (const T*)x; a.D = dw;
+    a.M = d->batch * Ho * Wo; a.I = d->out_c; a.J = d->kh * d->kw * d->in_c;
+    a.ldp = d->out_c; a.ldq = d->in_c; a.ldd = a.J;
+    if (is_dense(d)) return launch_tn<T>(a, MODE_DENSE, s);
+    Gather& g = a.g;
+    g.H = d->in_h; g.W = d->in_w; g.C = d->in_c; g.Ho = Ho; g.Wo = Wo; g.R = d->kh; g.S = d->kw;
+    g.sn = d->stride; g.sd_shift = 0; g.base_h = -d->pad; g.base_w = -d->pad; g.tap_sign = 1;
+    g.div_hw = make_fastdiv(Ho * Wo); g.div_w = make_fastdiv(Wo);
+    g.img_stride = (long)d->in_h * d->in_w * d->in_c;
+    return launch_tn<T>(a, MODE_CONV, s);
+}
+
+static void stem_gather(Gather& g, int H, int W) {
+    const int Ho = out_dim(H, 7, 2, 3), Wo = out_dim(W, 7, 2, 3);
+    g.H = H; g.W = W; g.C = 4; g.Ho = Ho; g.Wo = Wo; g.R = 8; g.S = 8;
+    g.sn = 2; g.sd_shift = 0; g.base_h = -3; g.base_w = -3; g.tap_sign = 1;
+    g.div_hw = make_fastdiv(Ho * Wo); g.div_w = make_fastdiv(Wo);
+    g.img_stride = (long)H * W * 4;
+}
+
+template <typename T>
+static int stem_fwd_t(const void* x4, const void* w, void* y, float* stats, int B, int H, int W, hipStream_t s) {
+    NTArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    stem_gather(a.g, H, W);
+    a.A = (const T*)x4; a.Bw = (const T*)w; a.C = (T*)y;
+    a.M = B * a.g.Ho * a.g.Wo; a.N = 64; a.K = 256;
+    a.lda = 4; a.ldb = 256; a.ldc = 64;
+    a.stats_part = stats;
+    return launch_nt<T>(a, MODE_STEM, s);
+}
+
+template <typename T>
+static int stem_wgrad_t(const void* x4, const void* dy, float* dw_packed, int B, int H, int W, hipStream_t s) {
+    TNArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    stem_gather(a.g, H, W);
+    a.P = (const T*)dy; a.Q = (const T*)x4; a.D = dw_packed;
+    a.M = B * a.g.Ho * a.g.Wo; a.I = 64; a.J = 256;
+    a.ldp = 64; a.ldq = 4; a.ldd = 256;
+    return launch_tn<T>(a, MODE_STEM, s);
+}
+
+template <typename T>
+static int linear_fwd_t(const void* x, int ldx, const void* w, int ldw, const float* bias, void* y, int ldy, int M, int N, int K, int relu,
+                        const void* addend, int ld_add, hipStream_t s) {
+    NTArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.A = (const T*)x; a.Bw = (const T*)w; a.C = (T*)y;
+    a.M = M; a.N = N; a.K = K; a.lda = ldx; a.ldb = ldw; a.ldc = ldy;
+    a.bias = bias; a.addend = (const T*)addend; a.ld_add = ld_add; a.relu = relu;
+    return launch_nt<T>(a, MODE_DENSE, s);
+}
+
+template <typename T>
+static int linear_wgrad_t(const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int M, int N, int K, hipStream_t s) {
+    TNArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.P = (const T*)dy; a.Q = (const T*)x; a.D = dw;
+    a.M = M; a.I = N; a.J = K; a.ldp = lddy; a.ldq = ldx; a.ldd = lddw;
+    return launch_tn<T>(a, MODE_DENSE, s);
+}
+
+#define DISPATCH(dtype, fn, ...)                                          \
+    do {                                                                  \
+        if ((dtype) == RPE_F32) return fn<float>(__VA_ARGS__);            \
+        if ((dtype) == RPE_BF16) return fn<bf16>(__VA_ARGS__);            \
+        return rpe_set_error(RPE_ERR_DTYPE, #fn ": unsupported dtype");   \
+    } while (0)
+
+extern "C" {
+
+int rpe_conv_out_hw(const rpe_conv_desc* d, int* ho, int* wo) {
+    if (int e = check_desc(d)) return e;
+    *ho = out_dim(d->in_h, d->kh, d->stride, d->pad);
+    *wo = out_dim(d->in_w, d->kw, d->stride, d->pad);
+    return 0;
+}
+
+long rpe_conv_stats_tiles(long rows) { return (rows + 127) / 128; }
+
+int rpe_conv2d_fwd(const rpe_conv_desc* d, int dtype, const void* x, const void* w_krsc, void* y, float* stats_part, void* stream) {
+    if (int e = check_desc(d)) return e;
+    DISPATCH(dtype, conv_fwd_t, d, x, w_krsc, y, stats_part, (hipStream_t)stream);
+}
+
+int rpe_conv2d_dgrad(const rpe_conv_desc* d, int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, void* stream) {
+    if (int e = check_desc(d)) return e;
+    DISPATCH(dtype, conv_dgrad_t, d, dy, w_crsk, dx, addend, (hipStream_t)stream);
+}
+
+int rpe_conv2d_wgrad(const rpe_conv_desc* d, int dtype, const void* x, const void* dy, float* dw_krsc, void* stream) {
+    if (int e = check_desc(d)) return e;
+    DISPATCH(dtype, conv_wgrad_t, d, x, dy, dw_krsc, (hipStream_t)stream);
+}
+
+int rpe_stem_conv_fwd(int dtype, const void* x4, const void* w_packed, void* y, float* stats_part, int B, int H, int W, void* stream) {
+    if (B <= 0 || H < 7 || W < 7) return rpe_set_error(RPE_ERR_SHAPE, "stem_conv: bad shape");
+    DISPATCH(dtype, stem_fwd_t, x4, w_packed, y, stats_part, B, H, W, (hipStream_t)stream);
+}
+
+int rpe_stem_conv_wgrad(int dtype, const void* x4, const void* dy, float* dw_packed, int B, int H, int W, void* stream) {
+    if (B <= 0 || H < 7 || W < 7) return rpe_set_error(RPE_ERR_SHAPE, "stem_conv: bad shape");
+    DISPATCH(dtype, stem_wgrad_t, x4, dy, dw_packed, B, H, W, (hipStream_t)stream);
+}
+
+int rpe_linear_fwd(int dtype, const void* x, int ldx, const void* w, int ldw, const float* bias, void* y, int ldy, int M, int N, int K,
+                   int relu, const void* addend, int ld_add, void* stream) {
+    DISPATCH(dtype, linear_fwd_t, x, ldx, w, ldw, bias, y, ldy, M, N, K, relu, addend, ld_add, (hipStream_t)stream);
+}
+
+int rpe_linear_wgrad(int dtype, const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int M, int N, int K, void* stream) {
+    DISPATCH(dtype, linear_wgrad_t, dy, lddy, x, ldx, dw, lddw, M, N, K, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,357 @@
+// ResNet-50 trunk engine: a static launch plan for one (batch, resolution, dtype).
+// Host-side C++ only walks tables and enqueues kernels on the caller's stream; there is no
+// Python, allocation or synchronisation between the first and last launch of a pass.
+//
+// Topology (torchvision ResNet-50 v1.5, the architecture util/model_utils.py:136 constructs):
+//   stage -> conv1 7x7/2 -> bn1 -> relu [= hooked early feature] -> maxpool 3x3/2
+//   -> layer1..4 = [3,4,6,3] bottlenecks (1x1 -> 3x3 (stride) -> 1x1 x4, downsample on block 0)
+//   -> global avgpool -> fc(2048 -> latent)
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+using namespace rpe;
+
+namespace {
+
+struct ConvL {
+    std::string name, bn;
+    rpe_conv_desc d;
+    int Ho, Wo;
+    long rows;       // B*Ho*Wo
+    int p_w, p_g, p_b;  // parameter table indices
+    int bn_i;           // BN index (running buffers)
+    // workspace pointers
+    void* wf = nullptr;  // packed forward weight (compute dtype) [Co][K]; fp32 dense layers use the master directly
+    void* wd = nullptr;  // packed dgrad weight [Ci][R][S][Co]
+    void* y = nullptr;   // raw conv output
+    void* a = nullptr;   // after BN (+residual) (+ReLU)
+    float *scale = nullptr, *shift = nullptr, *mean = nullptr, *invstd = nullptr;
+};
+
+struct Block {
+    int c1, c2, c3, cd;  // conv indices (cd = -1: identity shortcut)
+};
+
+struct Named {
+    std::string name;
+    const void* ptr;
+    long rows;
+    int ch;
+};
+
+}  // namespace
+
+struct rpe_resnet50 {
+    int B, H, W, dtype, latent;
+    size_t esz;
+    std::vector<ConvL> convs;
+    std::vector<Block> blocks;
+    std::vector<std::string> pnames;
+    std::vector<long> pnumel;
+    // bound tables
+    std::vector<float*> params, grads, running;
+    std::vector<long long*> nbt;
+    bool bound = false, fwd_done = false;
+    // workspace
+    long ws_bytes = 0;
+    char* ws = nullptr;
+    struct Slot { void** dst; long bytes; };
+    std::vector<Slot> slots;
+    void* x4 = nullptr;          // staged NHWC4 image
+    void* pool = nullptr;        // maxpool output
+    unsigned char* pool_idx = nullptr;
+    float* pooled = nullptr;     // avgpool output [B][2048]
+    float* d_pooled = nullptr;
+    float* fc_wt = nullptr;      // fc weight transposed [2048][latent_pad]
+    int latent_pad = 0;
+    void* early_grad = nullptr;
+    void* G[4] = {nullptr, nullptr, nullptr, nullptr};  // gradient scratch, each max activation size
+    float* stats_part = nullptr;
+    long stats_floats = 0;
+    float* bwd_part = nullptr;
+    long bwd_part_floats = 0;
+    float* c1c2 = nullptr;
+    float* stem_dw = nullptr;    // [64][8][8][4]
+    std::vector<Named> named;
+    int train_mode = 0;
+};
+
+static int add_conv(rpe_resnet50* e, const std::string& name, const std::string& bn, int in_h, int in_w, int in_c, int out_c, int k,
+                    int stride, int pad) {
+    ConvL c;
+    c.name = name; c.bn = bn;
+    c.d = rpe_conv_desc{e->B, in_h, in_w, in_c, out_c, k, k, stride, pad};
+    c.Ho = (in_h + 2 * pad - k) / stride + 1;
+    c.Wo = (in_w + 2 * pad - k) / stride + 1;
+    c.rows = (long)e->B * c.Ho * c.Wo;
+    c.bn_i = (int)e->convs.size();
+    c.p_w = (int)e->pnames.size();
+    e->pnames.push_back(name + ".weight"); e->pnumel.push_back((long)out_c * in_c * k * k);
+    c.p_g = (int)e->pnames.size();
+    e->pnames.push_back(bn + ".weight"); e->pnumel.push_back(out_c);
+    c.p_b = (int)e->pnames.size();
+    e->pnames.push_back(bn + ".bias"); e->pnumel.push_back(out_c);
+    e->convs.push_back(c);
+    return (int)e->convs.size() - 1;
+}
+
+static void want(rpe_resnet50* e, void** dst, long bytes) {
+    bytes = (bytes + 255) / 256 * 256;
+    e->slots.push_back({dst, bytes});
+    e->ws_bytes += bytes;
+}
+
+extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, int width, int dtype, int latent_dim) {
+    if (!out) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_create: null out");
+    if (batch <= 0 || latent_dim <= 0) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_create: bad batch/latent");
+    if (height < 32 || width < 32 || (height % 32) || (width % 32)) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_create: H, W must be multiples of 32");
+    if (dtype != RPE_F32 && dtype != RPE_BF16) return rpe_set_error(RPE_ERR_DTYPE, "resnet50_create: dtype must be RPE_F32 or RPE_BF16");
+    rpe_resnet50* e = new rpe_resnet50();
+    e->B = batch; e->H = height; e->W = width; e->dtype = dtype; e->latent = latent_dim;
+    e->esz = dtype == RPE_F32 ? 4 : 2;
+    add_conv(e, "conv1", "bn1", height, width, 3, 64, 7, 2, 3);
+    int h = e->convs[0].Ho / 2, w = e->convs[0].Wo / 2;  // after maxpool 3x3/2 pad 1 (even sizes)
+    int inpl = 64;
+    const int planes[4] = {64, 128, 256, 512}, nblk[4] = {3, 4, 6, 3}, strides[4] = {1, 2, 2, 2};
+    for (int li = 0; li < 4; ++li) {
+        for (int b = 0; b < nblk[li]; ++b) {
+            const std::string p = "layer" + std::to_string(li + 1) + "." + std::to_string(b);
+            const int s = b == 0 ? strides[li] : 1;
+            Block blk;
+            blk.c1 = add_conv(e, p + ".conv1", p + ".bn1", h, w, inpl, planes[li], 1, 1, 0);
+            blk.c2 = add_conv(e, p + ".conv2", p + ".bn2", h, w, planes[li], planes[li], 3, s, 1);
+            const int h2 = e->convs[blk.c2].Ho, w2 = e->convs[blk.c2].Wo;
+            blk.c3 = add_conv(e, p + ".conv3", p + ".bn3", h2, w2, planes[li], planes[li] * 4, 1, 1, 0);
+            blk.cd = -1;
+            if (b == 0) blk.cd = add_conv(e, p + ".downsample.0", p + ".downsample.1", h, w, inpl, planes[li] * 4, 1, s, 0);
+            e->blocks.push_back(blk);
+            inpl = planes[li] * 4;
+            h = h2; w = w2;
+        }
+    }
+    e->pnames.push_back("fc.weight"); e->pnumel.push_back((long)latent_dim * 2048);
+    e->pnames.push_back("fc.bias"); e->pnumel.push_back(latent_dim);
+    e->latent_pad = (latent_dim + 3) / 4 * 4;
+
+    // ---- workspace plan ----
+    const size_t es = e->esz;
+    want(e, &e->x4, (long)batch * height * width * 4 * es);
+    long max_act = 0;
+    for (auto& c : e->convs) {
+        const long n = c.rows * c.d.out_c;
+        if (n > max_act) max_act = n;
+        want(e, &c.y, n * es);
+        want(e, &c.a, n * es);
+        const long wn = (long)c.d.out_c * c.d.kh * c.d.kw * c.d.in_c;
+        if (&c == &e->convs[0]) {
+            want(e, &c.wf, 64L * 256 * es);
+        } else {
+            if (dtype != RPE_F32) want(e, &c.wf, wn * es);
+            want(e, &c.wd, wn * es);
+        }
+        want(e, (void**)&c.scale, c.d.out_c * 4L);
+        want(e, (void**)&c.shift, c.d.out_c * 4L);
+        want(e, (void**)&c.mean, c.d.out_c * 4L);
+        want(e, (void**)&c.invstd, c.d.out_c * 4L);
+        const long sf = rpe_conv_stats_tiles(c.rows) * 2 * c.d.out_c;
+        if (sf > e->stats_floats) e->stats_floats = sf;
+    }
+    const ConvL& st = e->convs[0];
+    const long pool_n = (long)batch * (st.Ho / 2) * (st.Wo / 2) * 64;
+    want(e, &e->pool, pool_n * es);
+    want(e, (void**)&e->pool_idx, pool_n);
+    want(e, (void**)&e->pooled, (long)batch * 2048 * 4);
+    want(e, (void**)&e->d_pooled, (long)batch * 2048 * 4);
+    want(e, (void**)&e->fc_wt, 2048L * e->latent_pad * 4);
+    want(e, &e->early_grad, st.rows * 64 * es);
+    for (int i = 0; i < 4; ++i) want(e, &e->G[i], max_act * es);
+    want(e, (void**)&e->stats_part, e->stats_floats * 4);
+    e->bwd_part_floats = 1024L * 2 * 2048;
+    want(e, (void**)&e->bwd_part, e->bwd_part_floats * 4);
+    want(e, (void**)&e->c1c2, 2 * 2048 * 4L);
+    want(e, (void**)&e->stem_dw, 64L * 256 * 4);
+    *out = e;
+    return 0;
+}
+
+extern "C" void rpe_resnet50_destroy(rpe_resnet50_t* e) { delete e; }
+extern "C" long rpe_resnet50_workspace_bytes(const rpe_resnet50_t* e) { return e ? e->ws_bytes : 0; }
+extern "C" const char* rpe_resnet50_param_name(const rpe_resnet50_t* e, int i) {
+    return (e && i >= 0 && i < (int)e->pnames.size()) ? e->pnames[i].c_str() : nullptr;
+}
+extern "C" long rpe_resnet50_param_numel(const rpe_resnet50_t* e, int i) {
+    return (e && i >= 0 && i < (int)e->pnumel.size()) ? e->pnumel[i] : -1;
+}
+
+extern "C" int rpe_resnet50_bind(rpe_resnet50_t* e, void* workspace, long workspace_bytes, float* const* params_host, float* const* grads_host,
+                                 float* const* running_host, long long* const* num_batches_host) {
+    if (!e || !workspace || !params_host) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_bind: null argument");
+    if (workspace_bytes < e->ws_bytes) return rpe_set_error(RPE_ERR_WORKSPACE, "resnet50_bind: workspace smaller than rpe_resnet50_workspace_bytes()");
+    if (((uintptr_t)workspace) & 255) return rpe_set_error(RPE_ERR_ALIGN, "resnet50_bind: workspace must be 256-byte aligned");
+    e->ws = (char*)workspace;
+    char* p = e->ws;
+    for (auto& s : e->slots) { *s.dst = p; p += s.bytes; }
+    const int np = (int)e->pnames.size(), nb = (int)e->convs.size();
+    e->params.assign(params_host, params_host + np);
+    if (grads_host) e->grads.assign(grads_host, grads_host + np); else e->grads.assign(np, nullptr);
+    if (running_host) e->running.assign(running_host, running_host + 2 * nb); else e->running.assign(2 * nb, nullptr);
+    if (num_batches_host) e->nbt.assign(num_batches_host, num_batches_host + nb); else e->nbt.assign(nb, nullptr);
+    for (int i = 0; i < np; ++i)
+        if (!e->params[i] || (((uintptr_t)e->params[i]) & 15)) return rpe_set_error(RPE_ERR_ALIGN, "resnet50_bind: parameter pointers must be non-null and 16-byte aligned");
+    // debugging table
+    e->named.clear();
+    for (auto& c : e->convs) {
+        e->named.push_back({c.name + ".y", c.y, c.rows, c.d.out_c});
+        e->named.push_back({c.name + ".a", c.a, c.rows, c.d.out_c});
+    }
+    e->named.push_back({"pool", e->pool, (long)e->B * (e->convs[0].Ho / 2) * (e->convs[0].Wo / 2), 64});
+    e->named.push_back({"x4", e->x4, (long)e->B * e->H * e->W, 4});
+    for (int i = 0; i < 4; ++i) e->named.push_back({"G" + std::to_string(i), e->G[i], 0, 0});
+    e->bound = true;
+    e->fwd_done = false;
+    return 0;
+}
+
+#define TRY(x) do { if (int err__ = (x)) return err__; } while (0)
+
+extern "C" int rpe_resnet50_pack_weights(rpe_resnet50_t* e, void* stream) {
+    if (!e || !e->bound) return rpe_set_error(RPE_ERR_STATE, "resnet50_pack_weights: engine not bound");
+    TRY(rpe_pack_stem_weight(e->dtype, e->params[e->convs[0].p_w], e->convs[0].wf, stream));
+    for (size_t i = 1; i < e->convs.size(); ++i) {
+        ConvL& c = e->convs[i];
+        TRY(rpe_pack_conv_weight(e->dtype, e->params[c.p_w], e->dtype == RPE_F32 ? nullptr : c.wf, c.wd, c.d.out_c, c.d.kh, c.d.kw, c.d.in_c, stream));
+    }
+    const int np = (int)e->pnames.size();
+    TRY(rpe_transpose_f32(e->params[np - 2], e->fc_wt, e->latent, 2048, 2048, e->latent_pad, stream));
+    return 0;
+}
+
+static const void* fwd_weight(rpe_resnet50* e, ConvL& c) { return (e->dtype == RPE_F32 && &c != &e->convs[0]) ? (const void*)e->params[c.p_w] : c.wf; }
+
+// conv -> batch statistics -> BN apply (+residual) (+relu)
+static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residual, int relu, void* stream) {
+    const bool train = e->train_mode != 0;
+    if (&c == &e->convs[0]) TRY(rpe_stem_conv_fwd(e->dtype, x, c.wf, c.y, train ? e->stats_part : nullptr, e->B, e->H, e->W, stream));
+    else TRY(rpe_conv2d_fwd(&c.d, e->dtype, x, fwd_weight(e, c), c.y, train ? e->stats_part : nullptr, stream));
+    float* rm = e->running[2 * c.bn_i];
+    float* rv = e->running[2 * c.bn_i + 1];
+    if (train) {
+        TRY(rpe_bn_finalize(e->stats_part, (int)rpe_conv_stats_tiles(c.rows), c.d.out_c, c.rows, e->params[c.p_g], e->params[c.p_b], rm, rv,
+                            e->nbt[c.bn_i], 0.1f, 1e-5f, c.scale, c.shift, c.mean, c.invstd, stream));
+    } else {
+        if (!rm || !rv) return rpe_set_error(RPE_ERR_STATE, "resnet50_forward: eval mode needs running statistics");
+        TRY(rpe_bn_eval_affine(c.d.out_c, e->params[c.p_g], e->params[c.p_b], rm, rv, 1e-5f, c.scale, c.shift, stream));
+    }
+    TRY(rpe_bn_apply(e->dtype, c.y, residual, c.a, c.scale, c.shift, c.rows, c.d.out_c, relu, stream));
+    return 0;
+}
+
+extern "C" int rpe_resnet50_forward(rpe_resnet50_t* e, const float* img_nchw, float* features, long ld_features, int training, void* stream) {
+    if (!e || !e->bound) return rpe_set_error(RPE_ERR_STATE, "resnet50_forward: engine not bound");
+    if (!img_nchw || !features || ld_features < e->latent) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_forward: bad img/features");
+    e->train_mode = training;
+    TRY(rpe_stage_image_nhwc4(e->dtype, img_nchw, e->x4, e->B, e->H, e->W, stream));
+    ConvL& st = e->convs[0];
+    TRY(conv_bn(e, st, e->x4, nullptr, 1, stream));
+    TRY(rpe_maxpool3x3s2_fwd(e->dtype, st.a, e->pool, e->pool_idx, e->B, st.Ho, st.Wo, 64, stream));
+    const void* x = e->pool;
+    for (auto& b : e->blocks) {
+        ConvL &c1 = e->convs[b.c1], &c2 = e->convs[b.c2], &c3 = e->convs[b.c3];
+        TRY(conv_bn(e, c1, x, nullptr, 1, stream));
+        TRY(conv_bn(e, c2, c1.a, nullptr, 1, stream));
+        const void* idn = x;
+        if (b.cd >= 0) { ConvL& cd = e->convs[b.cd]; TRY(conv_bn(e, cd, x, nullptr, 0, stream)); idn = cd.a; }
+        TRY(conv_bn(e, c3, c2.a, idn, 1, stream));
+        x = c3.a;
+    }
+    ConvL& last = e->convs[e->blocks.back().c3];
+    TRY(rpe_avgpool_fwd(e->dtype, last.a, e->pooled, e->B, last.Ho * last.Wo, 2048, stream));
+    const int np = (int)e->pnames.size();
+    TRY(rpe_linear_fwd(RPE_F32, e->pooled, 2048, e->params[np - 2], 2048, e->params[np - 1], features, (int)ld_features, e->B, e->latent, 2048, 0,
+                       nullptr, 0, stream));
+    e->fwd_done = training != 0;
+    return 0;
+}
+
+extern "C" const void* rpe_resnet50_early_feature(const rpe_resnet50_t* e) { return e ? e->convs[0].a : nullptr; }
+extern "C" void* rpe_resnet50_early_grad(rpe_resnet50_t* e) { return e ? e->early_grad : nullptr; }
+
+// BN backward of layer c: dA (grad wrt c.a) -> dy (may alias dA); dz_out optional
+static int bn_back(rpe_resnet50* e, ConvL& c, const void* dA, int relu, void* dy, void* dz_out, void* stream) {
+    return rpe_bn_backward(e->dtype, dA, relu ? c.a : nullptr, c.y, c.mean, c.invstd, e->params[c.p_g], e->grads[c.p_g], e->grads[c.p_b], dy,
+                           dz_out, c.rows, c.d.out_c, e->bwd_part, e->bwd_part_floats, e->c1c2, stream);
+}
+
+static int wgrad(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, void* stream) {
+    float* dw = e->grads[c.p_w];
+    hipError_t he = hipMemsetAsync(dw, 0, (size_t)e->pnumel[c.p_w] * 4, (hipStream_t)stream);
+    if (he != hipSuccess) return rpe_set_error_hip(he, __FILE__, __LINE__);
+    return rpe_conv2d_wgrad(&c.d, e->dtype, x, dy, dw, stream);
+}
+
+extern "C" int rpe_resnet50_backward(rpe_resnet50_t* e, const float* d_features, long ld_d_features, int use_d_early, void* stream) {
+    if (!e || !e->bound) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward: engine not bound");
+    if (!e->fwd_done) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward: no training-mode forward to differentiate");
+    const int np = (int)e->pnames.size();
+    for (int i = 0; i < np; ++i)
+        if (!e->grads[i]) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward: gradient tensors were not bound");
+    hipStream_t s = (hipStream_t)stream;
+    // fc
+    float* dWfc = e->grads[np - 2];
+    if (hipError_t he = hipMemsetAsync(dWfc, 0, (size_t)e->latent * 2048 * 4, s)) return rpe_set_error_hip(he, __FILE__, __LINE__);
+    TRY(rpe_linear_wgrad(RPE_F32, d_features, (int)ld_d_features, e->pooled, 2048, dWfc, 2048, e->B, e->latent, 2048, stream));
+    TRY(rpe_colsum(d_features, e->B, e->latent, (int)ld_d_features, e->grads[np - 1], 0, stream));
+    // d_pooled[B][2048] = d_features[B][latent] * Wfc[latent][2048]  ==  NT with weight fc_wt [2048][latent_pad].
+    // K runs to latent_pad: the extra columns of d_features (whatever the caller keeps there) meet zero weights.
+    if ((ld_d_features & 3) || ld_d_features < e->latent_pad)
+        return rpe_set_error(RPE_ERR_ALIGN, "resnet50_backward: ld_d_features must be a multiple of 4 and >= pad4(latent_dim)");
+    TRY(rpe_linear_fwd(RPE_F32, d_features, (int)ld_d_features, e->fc_wt, e->latent_pad, nullptr, e->d_pooled, 2048, e->B, 2048, e->latent_pad, 0,
+                       nullptr, 0, stream));
+    ConvL& last = e->convs[e->blocks.back().c3];
+    void *g0 = e->G[0], *g1 = e->G[1], *g2 = e->G[2], *g3 = e->G[3];
+    TRY(rpe_avgpool_bwd(e->dtype, e->d_pooled, g0, e->B, last.Ho * last.Wo, 2048, stream));
+    // g0 holds the gradient wrt the current block's output
+    for (int bi = (int)e->blocks.size() - 1; bi >= 0; --bi) {
+        Block& b = e->blocks[bi];
+        ConvL &c1 = e->convs[b.c1], &c2 = e->convs[b.c2], &c3 = e->convs[b.c3];
+        const void* x_in = bi == 0 ? (const void*)e->pool : (const void*)e->convs[e->blocks[bi - 1].c3].a;
+        // bn3 (+ residual split): dy3 in place in g0, dz (identity-branch gradient) -> g2
+        TRY(bn_back(e, c3, g0, 1, g0, g2, stream));
+        TRY(wgrad(e, c3, c2.a, g0, stream));
+        TRY(rpe_conv2d_dgrad(&c3.d, e->dtype, g0, c3.wd, g1, nullptr, stream));  // dA2 -> g1
+        TRY(bn_back(e, c2, g1, 1, g1, nullptr, stream));
+        TRY(wgrad(e, c2, c1.a, g1, stream));
+        TRY(rpe_conv2d_dgrad(&c2.d, e->dtype, g1, c2.wd, g0, nullptr, stream));  // dA1 -> g0
+        TRY(bn_back(e, c1, g0, 1, g0, nullptr, stream));
+        TRY(wgrad(e, c1, x_in, g0, stream));
+        const void* shortcut = g2;
+        if (b.cd >= 0) {
+            ConvL& cd = e->convs[b.cd];
+            TRY(bn_back(e, cd, g2, 0, g2, nullptr, stream));
+            TRY(wgrad(e, cd, x_in, g2, stream));
+            TRY(rpe_conv2d_dgrad(&cd.d, e->dtype, g2, cd.wd, g1, nullptr, stream));  // -> g1
+            shortcut = g1;
+        }
+        TRY(rpe_conv2d_dgrad(&c1.d, e->dtype, g0, c1.wd, g3, shortcut, stream));  // dX_in -> g3
+        void* t = g0; g0 = g3; g3 = t;
+    }
+    // stem: g0 = gradient wrt maxpool output
+    ConvL& st = e->convs[0];
+    TRY(rpe_maxpool3x3s2_bwd(e->dtype, g0, e->pool_idx, use_d_early ? e->early_grad : nullptr, g1, e->B, st.Ho, st.Wo, 64, stream));
+    TRY(bn_back(e, st, g1, 1, g1, nullptr, stream));
+    if (hipError_t he = hipMemsetAsync(e->stem_dw, 0, 64 * 256 * 4, s)) return rpe_set_error_hip(he, __FILE__, __LINE__);
+    TRY(rpe_stem_conv_wgrad(e->dtype, e->x4, g1, e->stem_dw, e->B, e->H, e->W, stream));
+    TRY(rpe_unpack_stem_grad(e->stem_dw, e->grads[st.p_w], stream));
+    return 0;
+}
+
+extern "C" int rpe_resnet50_tensor(const rpe_resnet50_t* e, const char* name, const void** ptr, long* rows, int* channels) {
+    if (!e || !e->bound || !name) return rpe_set_error(RPE_ERR_STATE, "resnet50_tensor: engine not bound");
+    for (auto& n : e->named)
+        if (n.name == name) { *ptr = n.ptr; *rows = n.rows; *channels = n.ch; return 0; }
+    return rpe_set_error(RPE_ERR_SHAPE, "resnet50_tensor: unknown tensor name");
+}

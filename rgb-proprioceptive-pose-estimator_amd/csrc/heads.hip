@@ -1,0 +1,541 @@
+// Head-side kernels of the pose path: early-feature auxiliary head, depth head, LSTM cell,
+// PoseDistanceLoss (+ on-device validation metrics), Adam, weight packing.  All fp32 except
+// where a tensor of the conv trunk (compute type T) is read or written.
+#include "common.h"
+
+namespace rpe {
+
+// ---------------------------------------------------------------------------------------------
+// aux head: Conv2d(64 -> 1, 1x1, bias) -> MaxPool2d(2) -> Flatten  [* depth feature]
+// reference: models/naive.py:223-231,318-330.  a1 = relu(bn1(conv1 x)) is [B][H][W][64] (T).
+// A group of LPP = 64/CE lanes owns one output pixel (2x2 input window).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void aux_fwd_kernel(const T* __restrict__ a1, const float* __restrict__ w, const float* __restrict__ bias,
+                                                     const float* __restrict__ depth_feat, float* __restrict__ out, long ld_out,
+                                                     float* __restrict__ raw, unsigned char* __restrict__ idx, int B, int H, int W) {
+    constexpr int CE = Elem<T>::kChunk, LPP = 64 / CE;
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)B * Ho * Wo;
+    const int sub = threadIdx.x % LPP;
+    float wv[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) wv[e] = w[sub * CE + e];
+    const float bv = bias[0];
+    const int groups = blockDim.x / LPP;
+    for (long o = (long)blockIdx.x * groups + threadIdx.x / LPP; o < total; o += (long)gridDim.x * groups) {
+        long t = o;
+        const int ow = (int)(t % Wo); t /= Wo;
+        const int oh = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        float best = -INFINITY;
+        int bi = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ih = oh * 2 + (k >> 1), iw = ow * 2 + (k & 1);
+            float v[CE];
+            chunk_to_f<T>(*(const u32x4*)(a1 + (((long)b * H + ih) * W + iw) * 64 + sub * CE), v);
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < CE; ++e) d += v[e] * wv[e];
+#pragma unroll
+            for (int s = 1; s < LPP; s <<= 1) d += __shfl_xor(d, s);
+            d += bv;
+            if (d > best || d != d) { best = d; bi = k; }
+        }
+        if (sub == 0) {
+            const long pos = (long)oh * Wo + ow;
+            const float df = depth_feat ? depth_feat[(long)b * Ho * Wo + pos] : 1.f;
+            out[(long)b * ld_out + pos] = best * df;
+            raw[(long)b * Ho * Wo + pos] = best;
+            idx[(long)b * Ho * Wo + pos] = (unsigned char)bi;
+        }
+    }
+}
+
+// backward: d_a1 (full tensor, zero except the winning pixel), dw (64), dbias, d_depth_feat
+template <typename T>
+__global__ __launch_bounds__(256) void aux_bwd_kernel(const float* __restrict__ dout, long ld_dout, const T* __restrict__ a1,
+                                                     const float* __restrict__ w, const float* __restrict__ depth_feat,
+                                                     const float* __restrict__ raw, const unsigned char* __restrict__ idx,
+                                                     T* __restrict__ d_a1, float* __restrict__ dw, float* __restrict__ dbias,
+                                                     float* __restrict__ d_depth_feat, int B, int H, int W) {
+    constexpr int CE = Elem<T>::kChunk, LPP = 64 / CE;
+    __shared__ float sh_dw[64];
+    __shared__ float sh_db;
+    if (threadIdx.x < 64) sh_dw[threadIdx.x] = 0.f;
+    if (threadIdx.x == 0) sh_db = 0.f;
+    __syncthreads();
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)B * Ho * Wo;
+    const int sub = threadIdx.x % LPP;
+    float wv[CE], gw[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { wv[e] = w[sub * CE + e]; gw[e] = 0.f; }
+    float gb = 0.f;
+    const int groups = blockDim.x / LPP;
+    for (long o = (long)blockIdx.x * groups + threadIdx.x / LPP; o < total; o += (long)gridDim.x * groups) {
+        long t = o;
+        const int ow = (int)(t % Wo); t /= Wo;
+        const int oh = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        const long pos = (long)oh * Wo + ow;
+        const long flat = (long)b * Ho * Wo + pos;
+        float d = dout[(long)b * ld_dout + pos];
+        if (depth_feat) {
+            if (sub == 0 && d_depth_feat) d_depth_feat[flat] = d * raw[flat];
+            d *= depth_feat[flat];
+        }
+        const int bi = idx[flat];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ih = oh * 2 + (k >> 1), iw = ow * 2 + (k & 1);
+            const long off = (((long)b * H + ih) * W + iw) * 64 + sub * CE;
+            float g[CE];
+            if (k == bi) {
+                float v[CE];
+                chunk_to_f<T>(*(const u32x4*)(a1 + off), v);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) { g[e] = d * wv[e]; gw[e] += d * v[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < CE; ++e) g[e] = 0.f;
+            }
+            *(u32x4*)(d_a1 + off) = f_to_chunk<T>(g);
+        }
+        if (sub == 0) gb += d;
+    }
+#pragma unroll
+    for (int e = 0; e < CE; ++e) atomicAdd(&sh_dw[sub * CE + e], gw[e]);
+    if (sub == 0) atomicAdd(&sh_db, gb);
+    __syncthreads();
+    if (threadIdx.x < 64) atomicAdd(&dw[threadIdx.x], sh_dw[threadIdx.x]);
+    if (threadIdx.x == 0) atomicAdd(dbias, sh_db);
+}
+
+// ---------------------------------------------------------------------------------------------
+// depth head: AvgPool2d(2) x2 -> InstanceNorm2d(1, affine, eps 1e-5) -> Flatten
+// reference: models/naive.py:233-240.  depth is [B][1][H][W] fp32; one block per image.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void depth_fwd_kernel(const float* __restrict__ depth, const float* __restrict__ w, const float* __restrict__ b,
+                                                       float* __restrict__ feat, float* __restrict__ xhat, int H, int W) {
+    extern __shared__ float pooled[];  // Ho*Wo
+    __shared__ double red[2][4];
+    const int Ho = H / 4, Wo = W / 4, n = Ho * Wo;
+    const float* img = depth + (long)blockIdx.x * H * W;
+    double s = 0.0, q = 0.0;
+    for (int o = threadIdx.x; o < n; o += blockDim.x) {
+        const int oh = o / Wo, ow = o - oh * Wo;
+        // avg of the four 2x2 averages (same association as two AvgPool2d(2) passes)
+        float acc = 0.f;
+        for (int a = 0; a < 2; ++a)
+            for (int c = 0; c < 2; ++c) {
+                const float* p = img + (long)(oh * 4 + a * 2) * W + ow * 4 + c * 2;
+                acc += (p[0] + p[1] + p[W] + p[W + 1]) * 0.25f;
+            }
+        acc *= 0.25f;
+        pooled[o] = acc;
+        s += acc;
+        q += (double)acc * acc;
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float wv = w[0], bv = b[0];
+    for (int o = threadIdx.x; o < n; o += blockDim.x) {
+        const float xh = (pooled[o] - (float)mean) * invstd;
+        xhat[(long)blockIdx.x * n + o] = xh;
+        feat[(long)blockIdx.x * n + o] = xh * wv + bv;
+    }
+}
+
+// dw += sum d*xhat ; db += sum d   (the depth image itself needs no gradient)
+__global__ __launch_bounds__(256) void depth_bwd_kernel(const float* __restrict__ d_feat, const float* __restrict__ xhat, long n, float* dw, float* db) {
+    __shared__ float red[2][4];
+    float s = 0.f, q = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float d = d_feat[i];
+        s += d * xhat[i];
+        q += d;
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(dw, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(db, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LSTM cell (torch gate order i, f, g, o).  gates: [N][4H] pre-activations WITHOUT biases
+// (x W_ih^T + h W_hh^T); overwritten with the activated gates, which the backward re-reads.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(float* __restrict__ gates, const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                                           const float* __restrict__ c_prev, float* __restrict__ c_out, float* __restrict__ h_out,
+                                                           int N, int Hd) {
+    const long total = (long)N * Hd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / Hd), j = (int)(i - (long)n * Hd);
+        float* g = gates + (long)n * 4 * Hd;
+        const float gi = sigmoidf_(g[j] + b_ih[j] + b_hh[j]);
+        const float gf = sigmoidf_(g[Hd + j] + b_ih[Hd + j] + b_hh[Hd + j]);
+        const float gg = tanhf(g[2 * Hd + j] + b_ih[2 * Hd + j] + b_hh[2 * Hd + j]);
+        const float go = sigmoidf_(g[3 * Hd + j] + b_ih[3 * Hd + j] + b_hh[3 * Hd + j]);
+        const float c = gf * (c_prev ? c_prev[i] : 0.f) + gi * gg;
+        g[j] = gi; g[Hd + j] = gf; g[2 * Hd + j] = gg; g[3 * Hd + j] = go;
+        c_out[i] = c;
+        h_out[i] = go * tanhf(c);
+    }
+}
+
+// dh: total gradient wrt h_t (output grad + recurrent); dc_io: in = dL/dc_t from step t+1, out = dL/dc_{t-1}
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ gates_act, const float* __restrict__ c_prev,
+                                                           const float* __restrict__ c_cur, const float* __restrict__ dh,
+                                                           float* __restrict__ dc_io, float* __restrict__ dgates, int N, int Hd) {
+    const long total = (long)N * Hd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / Hd), j = (int)(i - (long)n * Hd);
+        const float* g = gates_act + (long)n * 4 * Hd;
+        const float gi = g[j], gf = g[Hd + j], gg = g[2 * Hd + j], go = g[3 * Hd + j];
+        const float tc = tanhf(c_cur[i]);
+        const float dhv = dh[i];
+        const float dc = dc_io[i] + dhv * go * (1.f - tc * tc);
+        const float cp = c_prev ? c_prev[i] : 0.f;
+        float* dg = dgates + (long)n * 4 * Hd;
+        dg[j] = dc * gg * gi * (1.f - gi);
+        dg[Hd + j] = dc * cp * gf * (1.f - gf);
+        dg[2 * Hd + j] = dc * gi * (1.f - gg * gg);
+        dg[3 * Hd + j] = dhv * tc * go * (1.f - go);
+        dc_io[i] = dc * gf;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// PoseDistanceLoss forward + gradient + validation metrics in one launch (single block).
+// reference: models/losses.py:47-128.  metric: 0 l2, 1 l1, 2 linf, 3 combined; mode: 0 position, 1 pose.
+// out[0] = loss, out[1] = sum_i sqrt(|dp_i|^2 + eps) (val position error), out[2] = sum_i |angle_i| (val orientation error)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pose_loss_kernel(const float* __restrict__ pred, const float* __restrict__ truth, long n, int metric,
+                                                       int mode, float scale, float alpha, float eps, float* __restrict__ out,
+                                                       float* __restrict__ grad) {
+    __shared__ double red[3][4];
+    double l_acc = 0.0, p_acc = 0.0, a_acc = 0.0;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) {
+        const float* p = pred + i * 7;
+        const float* t = truth + i * 7;
+        float d[3], ad[3], g[7];
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { d[k] = p[k] - t[k]; ad[k] = fabsf(d[k]); sq += d[k] * d[k]; g[k] = 0.f; }
+        const float l2 = sqrtf(sq + eps);
+        float pos = 0.f;
+        if (metric == 0 || metric == 3) {
+            pos += l2;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) g[k] += d[k] / l2;
+        }
+        if (metric == 1 || metric == 3) {
+            pos += ad[0] + ad[1] + ad[2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) g[k] += (d[k] > 0.f) ? 1.f : ((d[k] < 0.f) ? -1.f : 0.f);
+        }
+        if (metric == 2 || metric == 3) {
+            int am = 0;  // torch.max(dim) gradient goes to the first maximal index
+            if (ad[1] > ad[am]) am = 1;
+            if (ad[2] > ad[am]) am = 2;
+            pos += ad[am];
+            g[am] += (d[am] > 0.f) ? 1.f : ((d[am] < 0.f) ? -1.f : 0.f);
+        }
+        // quaternion part: qhat = q / |q| (no eps: an all-zero quaternion yields NaN, as in the reference)
+        const float q0 = p[3], q1 = p[4], q2 = p[5], q3 = p[6];
+        const float mag = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+        const float h0 = q0 / mag, h1 = q1 / mag, h2 = q2 / mag, h3 = q3 / mag;
+        const float ip = h0 * t[3] + h1 * t[4] + h2 * t[5] + h3 * t[6];
+        float ori = 0.f;
+        float gh[4] = {0.f, 0.f, 0.f, 0.f};  // dL/d qhat
+        if (mode == 1) {
+            ori = (1.f - ip * ip) + fmaxf(-h3, 0.f);
+            const float c = -2.f * ip;
+            gh[0] = c * t[3]; gh[1] = c * t[4]; gh[2] = c * t[5]; gh[3] = c * t[6];
+            if (-h3 >= 0.f) gh[3] -= 1.f;  // torch.clamp(min=0) passes the gradient at the boundary
+        }
+        // d qhat / d q = (I - qhat qhat^T) / |q|
+        const float hd = gh[0] * h0 + gh[1] * h1 + gh[2] * h2 + gh[3] * h3;
+        g[3] = (gh[0] - h0 * hd) / mag; g[4] = (gh[1] - h1 * hd) / mag; g[5] = (gh[2] - h2 * hd) / mag; g[6] = (gh[3] - h3 * hd) / mag;
+        if (grad) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) grad[i * 7 + k] = scale * g[k];
+#pragma unroll
+            for (int k = 3; k < 7; ++k) grad[i * 7 + k] = scale * alpha * g[k];
+        }
+        l_acc += (double)pos + (double)alpha * (double)ori;
+        p_acc += (double)l2;
+        // validation angle: w of qhat * truth^-1 (xyzw), clipped; 2 acos(w) wrapped to [-pi, pi]; |.|
+        const float tt = t[3] * t[3] + t[4] * t[4] + t[5] * t[5] + t[6] * t[6];
+        float w = ip / tt;
+        w = fminf(fmaxf(w, -1.f), 1.f);
+        double ang = 0.0;
+        if (sqrt(1.0 - (double)w * (double)w) != 0.0) ang = 2.0 * acos((double)w);
+        if (ang > 3.14159265358979323846) ang -= 2.0 * 3.14159265358979323846;
+        a_acc += fabs(ang);
+    }
+    l_acc = wave_sum_d(l_acc); p_acc = wave_sum_d(p_acc); a_acc = wave_sum_d(a_acc);
+    if ((threadIdx.x & 63) == 0) { const int wv = threadIdx.x >> 6; red[0][wv] = l_acc; red[1][wv] = p_acc; red[2][wv] = a_acc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = scale * (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        out[1] = (float)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        out[2] = (float)(red[2][0] + red[2][1] + red[2][2] + red[2][3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam over flat fp32 buffers (torch.optim.Adam defaults: no amsgrad, no weight decay)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                  long n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 pp = ((f32x4*)p)[i], gg = ((const f32x4*)g)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mm[k] = mm[k] + (gg[k] - mm[k]) * (1.f - b1);
+            vv[k] = vv[k] * b2 + gg[k] * gg[k] * (1.f - b2);
+            const float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
+            pp[k] -= (lr / bc1) * (mm[k] / denom);
+        }
+        ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = (n4 << 2) + threadIdx.x;
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+        const float vi = v[i] * b2 + gi * gi * (1.f - b2);
+        m[i] = mi; v[i] = vi;
+        p[i] -= (lr / bc1) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing / small utilities
+// ---------------------------------------------------------------------------------------------
+// w: [Co][R][S][Ci] fp32 (channels_last storage of an OIHW parameter)
+//   -> fwd  [Co][R*S*Ci]   (T, only when T != float: the fp32 master already has this layout)
+//   -> dgrad [Ci][R][S][Co] (T)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Co, int RS, int Ci) {
+    const long total = (long)Co * RS * Ci;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Ci);
+        const long t = i / Ci;
+        const int rs = (int)(t % RS), co = (int)(t / RS);
+        const float v = w[i];
+        if (wf) wf[i] = Elem<T>::from_f(v);
+        if (wd) wd[((long)ci * RS + rs) * Co + co] = Elem<T>::from_f(v);
+    }
+}
+
+// stem: OIHW [64][3][7][7] fp32 -> [64][8][8][4] T (taps and channel zero padded)
+template <typename T>
+__global__ void pack_stem_weight_kernel(const float* __restrict__ w, T* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 64 * 256) return;
+    const int c = i & 3, s = (i >> 2) & 7, r = (i >> 5) & 7, co = i >> 8;
+    float v = 0.f;
+    if (c < 3 && s < 7 && r < 7) v = w[((co * 3 + c) * 7 + r) * 7 + s];
+    out[i] = Elem<T>::from_f(v);
+}
+__global__ void unpack_stem_grad_kernel(const float* __restrict__ d, float* __restrict__ dw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 64 * 3 * 49) return;
+    const int s = i % 7, r = (i / 7) % 7, c = (i / 49) % 3, co = i / 147;
+    dw[i] = d[((co * 8 + r) * 8 + s) * 4 + c];
+}
+
+// out[c][r] = in[r][c]  (fp32, out leading dimension ldo >= rows, zero padded)
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int ldi, int ldo) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = by + k, c = bx + tx;
+        tile[k][tx] = (r < rows && c < cols) ? in[(long)r * ldi + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = bx + k, r = by + tx;
+        if (c < cols && r < ldo) out[(long)c * ldo + r] = (r < rows) ? tile[tx][k] : 0.f;
+    }
+}
+
+// dy *= (out > 0)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ out, const float* __restrict__ dy, float* __restrict__ dx, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dx[i] = out[i] > 0.f ? dy[i] : 0.f;
+}
+
+// db[c] (+)= sum_r x[r][c]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long rows, int cols, int ld, float* __restrict__ out, int accumulate) {
+    __shared__ float sh[8][32];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s = 0.f;
+    if (c < cols)
+        for (long r = rl; r < rows; r += 8) s += x[r * ld + c];
+    sh[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        for (int i = 1; i < 8; ++i) s += sh[i][cl];
+        out[c] = accumulate ? out[c] + s : s;
+    }
+}
+
+// dst[r][off + c] = src[r][c]  (fp32 strided copy used to assemble the fused feature rows)
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, long rows, int cols) {
+    const long total = rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        dst[r * ldd + c] = src[r * lds_ + c];
+    }
+}
+
+static inline int ew_grid(long n, int per_block = 256) {
+    long g = (n + per_block - 1) / per_block;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace rpe
+
+using namespace rpe;
+
+extern "C" {
+
+int rpe_aux_head_fwd(int dtype, const void* a1, const float* w, const float* bias, const float* depth_feat, float* out, long ld_out,
+                     float* raw, unsigned char* idx, int B, int H, int W, void* stream) {
+    if ((H | W) & 1) return rpe_set_error(RPE_ERR_SHAPE, "aux_head: H and W must be even");
+    const long total = (long)B * (H / 2) * (W / 2);
+    if (dtype == RPE_F32) hipLaunchKernelGGL((aux_fwd_kernel<float>), dim3(ew_grid(total, 16)), dim3(256), 0, (hipStream_t)stream, (const float*)a1, w, bias, depth_feat, out, ld_out, raw, idx, B, H, W);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((aux_fwd_kernel<bf16>), dim3(ew_grid(total, 32)), dim3(256), 0, (hipStream_t)stream, (const bf16*)a1, w, bias, depth_feat, out, ld_out, raw, idx, B, H, W);
+    else return rpe_set_error(RPE_ERR_DTYPE, "aux_head: unsupported dtype");
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_aux_head_bwd(int dtype, const float* dout, long ld_dout, const void* a1, const float* w, const float* depth_feat, const float* raw,
+                     const unsigned char* idx, void* d_a1, float* dw, float* dbias, float* d_depth_feat, int B, int H, int W, void* stream) {
+    const long total = (long)B * (H / 2) * (W / 2);
+    if (dtype == RPE_F32) hipLaunchKernelGGL((aux_bwd_kernel<float>), dim3(ew_grid(total, 16 * 8)), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, (const float*)a1, w, depth_feat, raw, idx, (float*)d_a1, dw, dbias, d_depth_feat, B, H, W);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((aux_bwd_kernel<bf16>), dim3(ew_grid(total, 32 * 8)), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, (const bf16*)a1, w, depth_feat, raw, idx, (bf16*)d_a1, dw, dbias, d_depth_feat, B, H, W);
+    else return rpe_set_error(RPE_ERR_DTYPE, "aux_head: unsupported dtype");
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_depth_head_fwd(const float* depth, const float* w, const float* b, float* feat, float* xhat, int B, int H, int W, void* stream) {
+    if ((H | W) & 3) return rpe_set_error(RPE_ERR_SHAPE, "depth_head: H and W must be multiples of 4");
+    const size_t sh = (size_t)(H / 4) * (W / 4) * sizeof(float);
+    hipLaunchKernelGGL(depth_fwd_kernel, dim3(B), dim3(256), sh, (hipStream_t)stream, depth, w, b, feat, xhat, H, W);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_depth_head_bwd(const float* d_feat, const float* xhat, long n, float* dw, float* db, void* stream) {
+    hipLaunchKernelGGL(depth_bwd_kernel, dim3(ew_grid(n, 256 * 16)), dim3(256), 0, (hipStream_t)stream, d_feat, xhat, n, dw, db);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_lstm_cell_fwd(float* gates, const float* b_ih, const float* b_hh, const float* c_prev, float* c_out, float* h_out, int N, int Hd,
+                      void* stream) {
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(ew_grid((long)N * Hd)), dim3(256), 0, (hipStream_t)stream, gates, b_ih, b_hh, c_prev, c_out, h_out, N, Hd);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_lstm_cell_bwd(const float* gates_act, const float* c_prev, const float* c_cur, const float* dh, float* dc_io, float* dgates, int N,
+                      int Hd, void* stream) {
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(ew_grid((long)N * Hd)), dim3(256), 0, (hipStream_t)stream, gates_act, c_prev, c_cur, dh, dc_io, dgates, N, Hd);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_pose_loss(const float* pred, const float* truth, long n, int metric, int mode, float scale, float alpha, float eps, float* out3,
+                  float* grad, void* stream) {
+    if (metric < 0 || metric > 3 || mode < 0 || mode > 1) return rpe_set_error(RPE_ERR_SHAPE, "pose_loss: invalid metric/mode");
+    if (n <= 0) return rpe_set_error(RPE_ERR_SHAPE, "pose_loss: empty batch");
+    hipLaunchKernelGGL(pose_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, truth, n, metric, mode, scale, alpha, eps, out3, grad);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, int step, void* stream) {
+    if (n <= 0) return 0;
+    if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return rpe_set_error(RPE_ERR_ALIGN, "adam: buffers must be 16-byte aligned");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2s);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_pack_conv_weight(int dtype, const float* w_krsc, void* w_fwd, void* w_dgrad, int Co, int R, int S, int Ci, void* stream) {
+    const long n = (long)Co * R * S * Ci;
+    if (dtype == RPE_F32) hipLaunchKernelGGL((pack_conv_weight_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, w_krsc, (float*)w_fwd, (float*)w_dgrad, Co, R * S, Ci);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((pack_conv_weight_kernel<bf16>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, w_krsc, (bf16*)w_fwd, (bf16*)w_dgrad, Co, R * S, Ci);
+    else return rpe_set_error(RPE_ERR_DTYPE, "pack_conv_weight: unsupported dtype");
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_pack_stem_weight(int dtype, const float* w_oihw, void* out, void* stream) {
+    if (dtype == RPE_F32) hipLaunchKernelGGL((pack_stem_weight_kernel<float>), dim3(64), dim3(256), 0, (hipStream_t)stream, w_oihw, (float*)out);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((pack_stem_weight_kernel<bf16>), dim3(64), dim3(256), 0, (hipStream_t)stream, w_oihw, (bf16*)out);
+    else return rpe_set_error(RPE_ERR_DTYPE, "pack_stem_weight: unsupported dtype");
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_unpack_stem_grad(const float* d_packed, float* dw_oihw, void* stream) {
+    hipLaunchKernelGGL(unpack_stem_grad_kernel, dim3((64 * 147 + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_packed, dw_oihw);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_transpose_f32(const float* in, float* out, int rows, int cols, int ldi, int ldo, void* stream) {
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3((cols + 31) / 32, (ldo + 31) / 32), dim3(256), 0, (hipStream_t)stream, in, out, rows, cols, ldi, ldo);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_relu_bwd(const float* out, const float* dy, float* dx, long n, void* stream) {
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, out, dy, dx, n);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_colsum(const float* x, long rows, int cols, int ld, float* out, int accumulate, void* stream) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, out, accumulate);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_copy2d(const float* src, int ld_src, float* dst, int ld_dst, long rows, int cols, void* stream) {
+    hipLaunchKernelGGL(copy2d_kernel, dim3(ew_grid(rows * cols)), dim3(256), 0, (hipStream_t)stream, src, ld_src, dst, ld_dst, rows, cols);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+// Implicit-GEMM argument blocks shared by the conv / linear entry points.
+#pragma once
+#include "common.h"
+
+namespace rpe {
+
+enum { MODE_DENSE = 0, MODE_CONV = 1, MODE_STEM = 2 };
+
+// How row m and column k of the implicit "im2col" matrix map onto an NHWC tensor.
+//   m = (b*Ho + oh)*Wo + ow ;  k = (r*S + s)*C + c
+//   numerator  nh = oh*sn + base_h + tap_sign*r   (same for w)
+//   source row ih = nh >> sd_shift, valid iff nh >= 0, nh divisible by 1<<sd_shift, ih < H
+// forward conv : sn = stride, sd_shift = 0, base = -pad, tap_sign = +1 (tensor = x)
+// data gradient: sn = 1, sd_shift = log2(stride), base = +pad, tap_sign = -1 (tensor = dy)
+struct Gather {
+    int H, W, C;
+    int Ho, Wo;
+    int R, S;
+    int sn, sd_shift;
+    int base_h, base_w;
+    int tap_sign;
+    FastDiv div_hw, div_w;
+    long img_stride;
+};
+
+template <typename T> struct NTArgs {
+    const T* A;     // activations (dense [M][lda] or NHWC tensor described by g)
+    const T* Bw;    // weights [N][ldb], K contiguous
+    T* C;           // output [M][ldc]
+    int M, N, K;
+    int lda, ldb, ldc;
+    Gather g;
+    const float* bias;   // [N] or null
+    const T* addend;     // [M][ld_add] or null : C = acc (+bias) + addend
+    int ld_add;
+    int relu;
+    float* stats_part;   // [tiles_m][2][N] per-tile column sum / sum of squares of acc, or null
+    int tiles_m, tiles_n;
+};
+
+template <typename T> struct TNArgs {
+    const T* P;     // [M][ldp]   (dy / upstream gradient), columns i (Cout)
+    const T* Q;     // im2col source (dense [M][ldq] or NHWC tensor described by g), columns j (K)
+    float* D;       // [I][ldd] fp32, accumulated with atomics: D[i][j] += sum_m P[m][i] * Q[m][j]
+    int M, I, J;
+    int ldp, ldq, ldd;
+    Gather g;
+    int tiles_i, tiles_j, splits;
+    int rows_per_split;  // multiple of the m-step
+};
+
+}  // namespace rpe

@@ -1,0 +1,461 @@
+// BatchNorm (train / eval), ReLU, residual add, pooling, layout staging: HBM-bound NHWC kernels.
+// All tensors are [rows][C] with C contiguous; every thread moves 16-byte chunks.
+#include "common.h"
+
+namespace rpe {
+
+// ---------------------------------------------------------------------------------------------
+// BN forward: finalize batch statistics from the conv epilogue's per-tile partial sums
+// ---------------------------------------------------------------------------------------------
+// part: [tiles][2][C] (sum, sum of squares of the fp32 accumulators).  One thread column per channel,
+// 8 row lanes per block; accumulation in double so E[x^2] - mean^2 does not cancel in fp32.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int tiles, int C, double count,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* running_mean, float* running_var, long long* num_batches,
+                                                         float momentum, float eps, float* scale, float* shift,
+                                                         float* save_mean, float* save_invstd) {
+    __shared__ double sh[2][8][32];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        for (int t = rl; t < tiles; t += 8) {
+            s += (double)part[((long)t * 2 + 0) * C + c];
+            q += (double)part[((long)t * 2 + 1) * C + c];
+        }
+    }
+    sh[0][rl][cl] = s;
+    sh[1][rl][cl] = q;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int i = 1; i < 8; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        save_mean[c] = (float)mean;
+        save_invstd[c] = invstd;
+        if (running_mean) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    }
+    if (num_batches && blockIdx.x == 0 && threadIdx.x == 0) *num_batches += 1;
+}
+
+__global__ void bn_eval_affine_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BN apply (+ residual) (+ ReLU):  a = relu(y*scale + shift + res)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ out,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      long nchunks, int C, int relu) {
+    constexpr int CE = Elem<T>::kChunk;
+    const int cpr = C / CE;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cpr) * CE;
+        float v[CE], r[CE];
+        chunk_to_f<T>(*(const u32x4*)(y + i * CE), v);
+        if (res) chunk_to_f<T>(*(const u32x4*)(res + i * CE), r);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+            float t = v[e] * scale[c0 + e] + shift[c0 + e];
+            if (res) t += r[e];
+            v[e] = relu ? fmaxf(t, 0.f) : t;
+        }
+        *(u32x4*)(out + i * CE) = f_to_chunk<T>(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BN backward, pass 1: per-block partial sums of dz and dz*xhat, dz = dA * (a_out > 0)
+// ---------------------------------------------------------------------------------------------
+// grid = (row blocks, column slabs); slab width SW = min(C, 256*CE); TPR = SW/CE threads per row.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dA, const T* __restrict__ a_out, const T* __restrict__ y,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           long M, int C, int SW, int rows_per_block, float* __restrict__ part) {
+    constexpr int CE = Elem<T>::kChunk;
+    __shared__ float sh[2 * 256 * CE];
+    const int TPR = SW / CE, RPI = 256 / TPR;
+    const int cc = threadIdx.x % TPR, rr = threadIdx.x / TPR;
+    const int col = blockIdx.y * SW + cc * CE;
+    float mu[CE], is[CE], s1[CE], s2[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { mu[e] = mean[col + e]; is[e] = invstd[col + e]; s1[e] = 0.f; s2[e] = 0.f; }
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    for (long r = r0 + rr; r < r1; r += RPI) {
+        float d[CE], yy[CE], a[CE];
+        chunk_to_f<T>(*(const u32x4*)(dA + r * C + col), d);
+        chunk_to_f<T>(*(const u32x4*)(y + r * C + col), yy);
+        if (a_out) chunk_to_f<T>(*(const u32x4*)(a_out + r * C + col), a);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+            const float dz = (a_out && !(a[e] > 0.f)) ? 0.f : d[e];
+            s1[e] += dz;
+            s2[e] += dz * (yy[e] - mu[e]) * is[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+        sh[(rr * SW + cc * CE + e) * 2 + 0] = s1[e];
+        sh[(rr * SW + cc * CE + e) * 2 + 1] = s2[e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SW * 2; i += 256) {
+        float t = 0.f;
+        for (int k = 0; k < RPI; ++k) t += sh[k * SW * 2 + i];
+        const int c = i >> 1, which = i & 1;
+        part[((long)blockIdx.x * 2 + which) * C + blockIdx.y * SW + c] = t;
+    }
+}
+
+// pass 2: reduce partials -> dgamma, dbeta and the two per-channel coefficients of pass 3
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, double count,
+                                                             float* dgamma, float* dbeta, float* c1, float* c2) {
+    __shared__ double sh[2][8][32];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        for (int t = rl; t < nblocks; t += 8) {
+            s += (double)part[((long)t * 2 + 0) * C + c];
+            q += (double)part[((long)t * 2 + 1) * C + c];
+        }
+    }
+    sh[0][rl][cl] = s;
+    sh[1][rl][cl] = q;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int i = 1; i < 8; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
+        if (dbeta) dbeta[c] = (float)s;
+        if (dgamma) dgamma[c] = (float)q;
+        c1[c] = (float)(s / count);
+        c2[c] = (float)(q / count);
+    }
+}
+
+// pass 3: dy = gamma*invstd*(dz - c1 - xhat*c2); optionally also emits dz (gradient of the residual branch)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dA, const T* __restrict__ a_out, const T* __restrict__ y,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ c1,
+                                                          const float* __restrict__ c2, T* __restrict__ dy, T* __restrict__ dz_out,
+                                                          long nchunks, int C) {
+    constexpr int CE = Elem<T>::kChunk;
+    const int cpr = C / CE;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cpr) * CE;
+        float d[CE], yy[CE], a[CE], o[CE];
+        chunk_to_f<T>(*(const u32x4*)(dA + i * CE), d);
+        chunk_to_f<T>(*(const u32x4*)(y + i * CE), yy);
+        if (a_out) chunk_to_f<T>(*(const u32x4*)(a_out + i * CE), a);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+            const int c = c0 + e;
+            const float dz = (a_out && !(a[e] > 0.f)) ? 0.f : d[e];
+            const float xh = (yy[e] - mean[c]) * invstd[c];
+            o[e] = gamma[c] * invstd[c] * (dz - c1[c] - xh * c2[c]);
+            d[e] = dz;
+        }
+        *(u32x4*)(dy + i * CE) = f_to_chunk<T>(o);
+        if (dz_out) *(u32x4*)(dz_out + i * CE) = f_to_chunk<T>(d);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool 3x3 / stride 2 / pad 1 (ResNet stem).  Forward keeps the winning tap (0..8) per output
+// element so the backward is a gather.  Ties: first tap in (kh, kw) scan order, as torch does.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, unsigned char* __restrict__ idx,
+                                                         int B, int H, int W, int C, int Ho, int Wo) {
+    constexpr int CE = Elem<T>::kChunk;
+    const int cpr = C / CE;
+    const long total = (long)B * Ho * Wo * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cpr);
+        long pix = i / cpr;
+        const int ow = (int)(pix % Wo); pix /= Wo;
+        const int oh = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        float best[CE];
+        unsigned char bi[CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * 2 - 1 + kh;
+            if (ih < 0 || ih >= H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * 2 - 1 + kw;
+                if (iw < 0 || iw >= W) continue;
+                float v[CE];
+                chunk_to_f<T>(*(const u32x4*)(x + (((long)b * H + ih) * W + iw) * C + cc * CE), v);
+#pragma unroll
+                for (int e = 0; e < CE; ++e)
+                    if (v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = (unsigned char)(kh * 3 + kw); }
+            }
+        }
+        *(u32x4*)(out + i * CE) = f_to_chunk<T>(best);
+        unsigned char* ip = idx + i * CE;
+#pragma unroll
+        for (int e = 0; e < CE; ++e) ip[e] = bi[e];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dout, const unsigned char* __restrict__ idx,
+                                                         const T* __restrict__ addend, T* __restrict__ dx,
+                                                         int B, int H, int W, int C, int Ho, int Wo) {
+    constexpr int CE = Elem<T>::kChunk;
+    const int cpr = C / CE;
+    const long total = (long)B * H * W * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cpr);
+        long pix = i / cpr;
+        const int w = (int)(pix % W); pix /= W;
+        const int h = (int)(pix % H);
+        const int b = (int)(pix / H);
+        float acc[CE];
+        if (addend) chunk_to_f<T>(*(const u32x4*)(addend + i * CE), acc);
+        else {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) acc[e] = 0.f;
+        }
+        // windows (oh, ow) with ih = oh*2 - 1 + kh == h
+        for (int kh = 0; kh < 3; ++kh) {
+            const int t = h + 1 - kh;
+            if (t < 0 || (t & 1)) continue;
+            const int oh = t >> 1;
+            if (oh >= Ho) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int u = w + 1 - kw;
+                if (u < 0 || (u & 1)) continue;
+                const int ow = u >> 1;
+                if (ow >= Wo) continue;
+                const long o = (((long)b * Ho + oh) * Wo + ow) * C + cc * CE;
+                float d[CE];
+                chunk_to_f<T>(*(const u32x4*)(dout + o), d);
+                const unsigned char* ip = idx + o;
+#pragma unroll
+                for (int e = 0; e < CE; ++e)
+                    if (ip[e] == (unsigned char)(kh * 3 + kw)) acc[e] += d[e];
+            }
+        }
+        *(u32x4*)(dx + i * CE) = f_to_chunk<T>(acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Global average pool [B][HW][C] (T) -> [B][C] (f32), and its backward
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, float* __restrict__ out, int B, int HW, int C) {
+    constexpr int CE = Elem<T>::kChunk;
+    const int cpr = C / CE;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * cpr) return;
+    const int cc = (int)(i % cpr), b = (int)(i / cpr);
+    float acc[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) acc[e] = 0.f;
+    for (int p = 0; p < HW; ++p) {
+        float v[CE];
+        chunk_to_f<T>(*(const u32x4*)(x + ((long)b * HW + p) * C + cc * CE), v);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) acc[e] += v[e];
+    }
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) out[(long)b * C + cc * CE + e] = acc[e] * inv;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dout, T* __restrict__ dx, int B, int HW, int C) {
+    constexpr int CE = Elem<T>::kChunk;
+    const int cpr = C / CE;
+    const long total = (long)B * HW * cpr;
+    const float inv = 1.f / (float)HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cpr);
+        const int b = (int)(i / ((long)cpr * HW));
+        float v[CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) v[e] = dout[(long)b * C + cc * CE + e] * inv;
+        *(u32x4*)(dx + i * CE) = f_to_chunk<T>(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device staging: NCHW fp32 image batch -> NHWC4 (channel 3 = 0) in the compute type
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int HW) {
+    const long total = (long)B * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / HW, p = i - b * HW;
+        const float* src = img + b * 3 * HW + p;
+        const float r = src[0], g = src[HW], bl = src[2 * (long)HW];
+        if (sizeof(T) == 4) {
+            *(f32x4*)(out + i * 4) = f32x4{r, g, bl, 0.f};
+        } else {
+            u32x2 t; t.x = pack_bf16x2(r, g); t.y = pack_bf16x2(bl, 0.f);
+            *(u32x2*)(out + i * 4) = t;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static inline int ew_grid(long n, int per_block = 256) {
+    long g = (n + per_block - 1) / per_block;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+template <typename T>
+int bn_apply_launch(const void* y, const void* res, void* out, const float* scale, const float* shift, long M, int C, int relu, hipStream_t s) {
+    constexpr int CE = Elem<T>::kChunk;
+    if (C % CE) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply: C must be a multiple of the 16-byte chunk");
+    const long n = M * C / CE;
+    hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, s, (const T*)y, (const T*)res, (T*)out, scale, shift, n, C, relu);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T>
+int bn_bwd_launch(const void* dA, const void* a_out, const void* y, const float* mean, const float* invstd, const float* gamma,
+                  float* dgamma, float* dbeta, void* dy, void* dz_out, long M, int C, float* part, long part_floats, float* c1c2,
+                  hipStream_t s) {
+    constexpr int CE = Elem<T>::kChunk;
+    if (C % CE) return rpe_set_error(RPE_ERR_SHAPE, "bn_bwd: C must be a multiple of the 16-byte chunk");
+    int SW = C < 256 * CE ? C : 256 * CE;
+    if (256 % (SW / CE)) return rpe_set_error(RPE_ERR_SHAPE, "bn_bwd: C/chunk must divide 256");
+    const int slabs = C / SW;
+    const int RPI = 256 / (SW / CE);
+    long nb = (M + (long)RPI * 8 - 1) / ((long)RPI * 8);  // >= 8 iterations per block
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    long rpb = (M + nb - 1) / nb;
+    nb = (M + rpb - 1) / rpb;
+    if (nb * 2 * C > part_floats) return rpe_set_error(RPE_ERR_WORKSPACE, "bn_bwd: partial-sum workspace too small");
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3((unsigned)nb, slabs), dim3(256), 0, s, (const T*)dA, (const T*)a_out, (const T*)y, mean,
+                       invstd, M, C, SW, (int)rpb, part);
+    RPE_CHECK_LAUNCH();
+    float* c1 = c1c2;
+    float* c2 = c1c2 + C;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, (const float*)part, (int)nb, C, (double)M, dgamma, dbeta, c1, c2);
+    RPE_CHECK_LAUNCH();
+    const long n = M * C / CE;
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, s, (const T*)dA, (const T*)a_out, (const T*)y, mean, invstd, gamma,
+                       (const float*)c1, (const float*)c2, (T*)dy, (T*)dz_out, n, C);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace rpe
+
+using namespace rpe;
+
+extern "C" {
+
+int rpe_bn_finalize(const float* part, int tiles, int C, long count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, long long* num_batches, float momentum, float eps, float* scale, float* shift,
+                    float* save_mean, float* save_invstd, void* stream) {
+    if (tiles <= 0 || C <= 0 || count <= 0) return rpe_set_error(RPE_ERR_SHAPE, "bn_finalize: empty problem");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, tiles, C, (double)count, gamma, beta,
+                       running_mean, running_var, num_batches, momentum, eps, scale, shift, save_mean, save_invstd);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                       float* scale, float* shift, void* stream) {
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma, beta, running_mean,
+                       running_var, eps, scale, shift);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_bn_apply(int dtype, const void* y, const void* residual, void* out, const float* scale, const float* shift, long rows, int C,
+                 int relu, void* stream) {
+    if (dtype == RPE_F32) return bn_apply_launch<float>(y, residual, out, scale, shift, rows, C, relu, (hipStream_t)stream);
+    if (dtype == RPE_BF16) return bn_apply_launch<bf16>(y, residual, out, scale, shift, rows, C, relu, (hipStream_t)stream);
+    return rpe_set_error(RPE_ERR_DTYPE, "bn_apply: unsupported dtype");
+}
+
+int rpe_bn_backward(int dtype, const void* dA, const void* a_out, const void* y, const float* mean, const float* invstd,
+                    const float* gamma, float* dgamma, float* dbeta, void* dy, void* dz_out, long rows, int C, float* part,
+                    long part_floats, float* c1c2, void* stream) {
+    if (dtype == RPE_F32)
+        return bn_bwd_launch<float>(dA, a_out, y, mean, invstd, gamma, dgamma, dbeta, dy, dz_out, rows, C, part, part_floats, c1c2, (hipStream_t)stream);
+    if (dtype == RPE_BF16)
+        return bn_bwd_launch<bf16>(dA, a_out, y, mean, invstd, gamma, dgamma, dbeta, dy, dz_out, rows, C, part, part_floats, c1c2, (hipStream_t)stream);
+    return rpe_set_error(RPE_ERR_DTYPE, "bn_backward: unsupported dtype");
+}
+
+int rpe_maxpool3x3s2_fwd(int dtype, const void* x, void* out, unsigned char* idx, int B, int H, int W, int C, void* stream) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long n = (long)B * Ho * Wo * C;
+    if (dtype == RPE_F32) hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)out, idx, B, H, W, C, Ho, Wo);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((maxpool_fwd_kernel<bf16>), dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out, idx, B, H, W, C, Ho, Wo);
+    else return rpe_set_error(RPE_ERR_DTYPE, "maxpool: unsupported dtype");
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_maxpool3x3s2_bwd(int dtype, const void* dout, const unsigned char* idx, const void* addend, void* dx, int B, int H, int W, int C,
+                         void* stream) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long n = (long)B * H * W * C;
+    if (dtype == RPE_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)dout, idx, (const float*)addend, (float*)dx, B, H, W, C, Ho, Wo);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16>), dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout, idx, (const bf16*)addend, (bf16*)dx, B, H, W, C, Ho, Wo);
+    else return rpe_set_error(RPE_ERR_DTYPE, "maxpool: unsupported dtype");
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_avgpool_fwd(int dtype, const void* x, float* out, int B, int HW, int C, void* stream) {
+    if (dtype == RPE_F32) hipLaunchKernelGGL((avgpool_fwd_kernel<float>), dim3(ceil_div((long)B * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, out, B, HW, C);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((avgpool_fwd_kernel<bf16>), dim3(ceil_div((long)B * C / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, out, B, HW, C);
+    else return rpe_set_error(RPE_ERR_DTYPE, "avgpool: unsupported dtype");
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_avgpool_bwd(int dtype, const float* dout, void* dx, int B, int HW, int C, void* stream) {
+    const long n = (long)B * HW * C;
+    if (dtype == RPE_F32) hipLaunchKernelGGL((avgpool_bwd_kernel<float>), dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, dout, (float*)dx, B, HW, C);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((avgpool_bwd_kernel<bf16>), dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, dout, (bf16*)dx, B, HW, C);
+    else return rpe_set_error(RPE_ERR_DTYPE, "avgpool: unsupported dtype");
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_stage_image_nhwc4(int dtype, const float* img_nchw, void* out, int B, int H, int W, void* stream) {
+    const long n = (long)B * H * W;
+    if (dtype == RPE_F32) hipLaunchKernelGGL((nchw_to_nhwc4_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, img_nchw, (float*)out, B, H * W);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((nchw_to_nhwc4_kernel<bf16>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, img_nchw, (bf16*)out, B, H * W);
+    else return rpe_set_error(RPE_ERR_DTYPE, "stage_image: unsupported dtype");
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

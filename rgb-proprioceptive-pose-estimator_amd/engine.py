@@ -1,0 +1,207 @@
+"""Host side of the ResNet-50 trunk: a torchvision-shaped parameter container (same attribute
+names and state_dict keys as the module util/model_utils.py:136-141 builds) whose compute is the
+native launch plan in csrc/engine.hip.  The nn.Conv2d / nn.BatchNorm2d / nn.Linear objects below
+only HOLD parameters and buffers (names, shapes, initialisers, state_dict, .cuda()); their
+forward() is never called -- calling this module without the HIP library or on CPU tensors raises.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import lib
+
+_STAGES = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))
+
+
+class _Shortcut(nn.Sequential):
+    pass
+
+
+class _BottleneckParams(nn.Module):
+    def __init__(self, inplanes, planes, stride, project):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        if project:
+            self.downsample = _Shortcut(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(planes * 4))
+
+    def forward(self, *a, **k):
+        raise RuntimeError("parameter container only: the trunk runs as one native plan (ResNet50Trunk.run)")
+
+
+class ResNet50Trunk(nn.Module):
+    """ResNet-50 v1.5 parameters + native forward/backward plan.
+
+    compute_dtype: torch.bfloat16 (default; fp32 accumulate, fp32 master weights) or torch.float32
+    (exact-fp32 MFMA path used for the 1e-4 parity bar).
+    """
+
+    def __init__(self, num_outputs=1000, compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        inpl = 64
+        for li, (planes, n, stride) in enumerate(_STAGES, start=1):
+            blocks = []
+            for b in range(n):
+                blocks.append(_BottleneckParams(inpl, planes, stride if b == 0 else 1, b == 0))
+                inpl = planes * 4
+            setattr(self, "layer%d" % li, nn.Sequential(*blocks))
+        self.fc = nn.Linear(2048, num_outputs)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        self.compute_dtype = compute_dtype
+        self._plans = {}      # (B, H, W, dtype, latent) -> _Plan
+        self._active = None
+
+    # -- plumbing ---------------------------------------------------------------------------------
+    def _ordered(self):
+        """(conv, bn) pairs and the parameter / buffer tables in the engine's order."""
+        pairs = [(self.conv1, self.bn1)]
+        for li in range(1, 5):
+            for blk in getattr(self, "layer%d" % li):
+                pairs += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2), (blk.conv3, blk.bn3)]
+                if hasattr(blk, "downsample"):
+                    pairs.append((blk.downsample[0], blk.downsample[1]))
+        params = []
+        for conv, bn in pairs:
+            params += [conv.weight, bn.weight, bn.bias]
+        params += [self.fc.weight, self.fc.bias]
+        running = []
+        for _, bn in pairs:
+            running += [bn.running_mean, bn.running_var]
+        nbt = [bn.num_batches_tracked for _, bn in pairs]
+        return pairs, params, running, nbt
+
+    def ensure_layout(self):
+        """Conv weights (except the stem) are kept in channels_last storage = [Co][kh][kw][Ci], the
+        layout the implicit-GEMM kernels read; values/shape/state_dict are unchanged."""
+        pairs, _, _, _ = self._ordered()
+        for i, (conv, _) in enumerate(pairs):
+            w = conv.weight
+            if i == 0:
+                if not w.data.is_contiguous():
+                    w.data = w.data.contiguous()
+            elif not w.data.permute(0, 2, 3, 1).is_contiguous():
+                w.data = w.data.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+    def _plan(self, batch, h, w):
+        key = (batch, h, w, self.compute_dtype, self.fc.out_features, self.fc.weight.device)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = _Plan(self, batch, h, w)
+            self._plans[key] = plan
+        plan.rebind_if_needed()
+        return plan
+
+    def weights_changed(self):
+        """Call after an optimizer step or load_state_dict: compute-dtype weight copies are stale."""
+        for p in self._plans.values():
+            p.packed = False
+
+    # -- compute ----------------------------------------------------------------------------------
+    def run(self, img, features, training):
+        """img (B,3,H,W) fp32 device tensor; features: fp32 2-D device tensor whose first `latent`
+        columns receive the ResNet output.  Returns the plan (early feature / backward handle)."""
+        if not img.is_cuda:
+            raise RuntimeError("ResNet50Trunk needs device tensors: the HIP path has no CPU fallback")
+        b, c, h, w = img.shape
+        assert c == 3 and img.dtype == torch.float32 and img.is_contiguous()
+        plan = self._plan(b, h, w)
+        s = ops._stream()
+        if training or not plan.packed:
+            # training: the optimizer moved the fp32 masters since the last step -> refresh the
+            # compute-dtype / transposed copies (53 tiny kernels, ~0.2 GB of traffic)
+            lib.rpe_resnet50_pack_weights(plan.handle, s)
+            plan.packed = True
+        lib.rpe_resnet50_forward(plan.handle, ops._p(img), ops._p(features), features.stride(0), int(training), s)
+        self._active = plan
+        return plan
+
+    def forward(self, img):
+        """Inference-style call (no autograd): returns the latent features (B, latent)."""
+        lat = self.fc.out_features
+        out = torch.empty((img.shape[0], ops.pad4(lat)), dtype=torch.float32, device=img.device)
+        self.run(img, out, self.training)
+        return out[:, :lat]
+
+
+class _Plan:
+    """One native engine object + its workspace for a fixed (batch, H, W, dtype)."""
+
+    def __init__(self, trunk, batch, h, w):
+        self.trunk = trunk
+        self.batch, self.h, self.w = batch, h, w
+        self.dtype = trunk.compute_dtype
+        hp = ctypes.c_void_p()
+        lib.rpe_resnet50_create(ctypes.byref(hp), batch, h, w, ops.dtype_code(self.dtype), trunk.fc.out_features)
+        self.handle = hp
+        nbytes = lib.rpe_resnet50_workspace_bytes(hp)
+        self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=trunk.fc.weight.device)
+        self._ptr_sig = None
+        self.packed = False
+        self.grad_views = None
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib.rpe_resnet50_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def rebind_if_needed(self):
+        t = self.trunk
+        t.ensure_layout()
+        _, params, running, nbt = t._ordered()
+        grads = [getattr(p, "_rpe_grad", None) for p in params]
+        sig = tuple(p.data_ptr() for p in params) + tuple(0 if g is None else g.data_ptr() for g in grads) + tuple(r.data_ptr() for r in running)
+        if sig == self._ptr_sig:
+            return
+        n = len(params)
+        PA = ctypes.c_void_p * n
+        pa = PA(*[p.data_ptr() for p in params])
+        have_grads = all(g is not None for g in grads)
+        ga = PA(*[g.data_ptr() for g in grads]) if have_grads else None
+        RA = ctypes.c_void_p * len(running)
+        ra = RA(*[r.data_ptr() for r in running])
+        NA = ctypes.c_void_p * len(nbt)
+        na = NA(*[x.data_ptr() for x in nbt])
+        base = self.workspace.data_ptr()
+        off = (-base) % 256
+        lib.rpe_resnet50_bind(self.handle, ctypes.c_void_p(base + off), self.workspace.numel() - off, pa, ga, ra, na)
+        self._ptr_sig = sig
+        self.packed = False
+
+    # early feature relu(bn1(conv1 x)) as an NHWC tensor aliasing the workspace
+    def early_feature(self):
+        ptr = lib.rpe_resnet50_early_feature(self.handle)
+        return self._alias(ptr, (self.batch, self.h // 2, self.w // 2, 64))
+
+    def early_grad(self):
+        ptr = lib.rpe_resnet50_early_grad(self.handle)
+        return self._alias(ptr, (self.batch, self.h // 2, self.w // 2, 64))
+
+    def _alias(self, ptr, shape):
+        base = self.workspace.data_ptr()
+        esz = 4 if self.dtype == torch.float32 else 2
+        n = 1
+        for s in shape:
+            n *= s
+        off = ptr - base
+        return self.workspace[off:off + n * esz].view(self.dtype).view(shape)
+
+    def tensor(self, name):
+        ptr, rows, ch = ctypes.c_void_p(), ctypes.c_long(), ctypes.c_int()
+        lib.rpe_resnet50_tensor(self.handle, name.encode(), ctypes.byref(ptr), ctypes.byref(rows), ctypes.byref(ch))
+        return self._alias(ptr.value, (rows.value, ch.value))
+
+    def backward(self, d_features, use_d_early):
+        lib.rpe_resnet50_backward(self.handle, ops._p(d_features), d_features.stride(0), int(use_d_early), ops._stream())

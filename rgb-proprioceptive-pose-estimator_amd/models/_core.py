@@ -1,0 +1,205 @@
+"""Shared machinery of the five pose estimators: device materialisation (flat parameter arena +
+native trunk plan), the early-feature aux/depth heads, and the bridge into torch autograd.
+
+The reference repeats the ResNet-import / bn1-hook / aux-head construction in four classes
+(models/naive.py:188-253, models/time_sensitive.py:66-118,346-407,606-666); here it lives once.
+Forward and backward of a model are explicit compositions of C-ABI ops (headops.py, engine.py):
+autograd sees one node per model call, and parameter gradients are written by the kernels
+directly into the arena's gradient views.
+"""
+import math
+import warnings
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..engine import ResNet50Trunk
+from ..headops import AuxHeadOp, new_rows
+from ..params import ParamArena
+from ..util.model_utils import import_resnet
+
+_DEFAULT_COMPUTE_DTYPE = torch.bfloat16
+
+
+def set_default_compute_dtype(dtype):
+    """torch.bfloat16 (fast path; fp32 accumulate + fp32 master weights) or torch.float32 (parity path)."""
+    global _DEFAULT_COMPUTE_DTYPE
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+    _DEFAULT_COMPUTE_DTYPE = dtype
+
+
+def default_compute_dtype():
+    return _DEFAULT_COMPUTE_DTYPE
+
+
+class Replicated(nn.Module):
+    """Stands where the reference wraps a sub-module in nn.DataParallel (e.g. models/naive.py:224,253,274):
+    contributes the same ``module.`` segment to state_dict keys and the same ``.module`` attribute.
+    Replication itself is process-per-GPU + RCCL all-reduce (dist.py), not thread-per-replica."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+
+class _AuxStack(nn.Sequential):
+    """Conv2d(C->1, 1x1) -> MaxPool2d(2) -> Flatten : parameter holder for the aux head."""
+
+
+class _DepthStack(nn.Sequential):
+    """AvgPool2d(2) x k -> InstanceNorm2d(1, affine) -> Flatten : parameter holder for the depth head."""
+
+
+def _make_aux(c):
+    return _AuxStack(nn.Conv2d(c, 1, 1), nn.MaxPool2d(2), nn.Flatten())
+
+
+def _make_depth(h, w):
+    n_pool = int(math.log(224 ** 2 / (h * w // 4), 4))
+    return _DepthStack(*([nn.AvgPool2d(2) for _ in range(n_pool)] + [nn.InstanceNorm2d(1, affine=True), nn.Flatten()]))
+
+
+class _ModelFn(torch.autograd.Function):
+    """One autograd node for a whole model call.  `anchor` is a trainable parameter: it only makes the
+    node part of the graph -- gradients are written into the arena by the kernels, not returned."""
+
+    @staticmethod
+    def forward(ctx, model, anchor, img, depth, x0bar):
+        ctx.model = model
+        outs = model._forward_impl(img, depth, x0bar, save=True)
+        ctx.n_out = len(outs)
+        return outs if len(outs) > 1 else outs[0]
+
+    @staticmethod
+    def backward(ctx, *d_outs):
+        model = ctx.model
+        model._backward_impl(list(d_outs))
+        model._arena.publish_grads()
+        return None, None, None, None, None
+
+
+class PoseModelBase(nn.Module):
+    """Common state: ``feature_net`` (ResNet-50 trunk), optional ``aux_nets`` / ``depth_nets``."""
+
+    EARLY_SHAPE = (64, 112, 112)  # bn1 output for a 224x224 input; what the reference's dummy forward measures
+
+    def _init_features(self, num_resnet_layers, latent_dim, feature_extract, use_pretrained, feature_layer_nums, use_depth,
+                       wrap, register_heads, compute_dtype):
+        self.compute_dtype = compute_dtype or default_compute_dtype()
+        self.latent_dim = latent_dim
+        self.use_depth = use_depth
+        self.aux_latent_dim = 0
+        self.early_features = None
+        self.aux_nets = None
+        self.depth_nets = None
+        trunk, _ = import_resnet(num_resnet_layers, latent_dim, feature_extract, use_pretrained=use_pretrained,
+                                 compute_dtype=self.compute_dtype)
+        self.feature_net = trunk  # registered first, as in the reference, so state_dict order matches
+        if feature_layer_nums is not None:
+            layers = tuple(feature_layer_nums)
+            if layers != (9,):
+                raise NotImplementedError("only the bn1 hook (feature_layer_nums=(9,)) is on the accelerated path; got %r" % (layers,))
+            self.early_features = []
+            c, h, w = self.EARLY_SHAPE
+            aux, dep = _make_aux(c), _make_depth(h, w)
+            if wrap:
+                aux, dep = Replicated(aux), Replicated(dep)
+            if register_heads:
+                self.aux_nets = nn.ModuleList([aux])
+                self.depth_nets = nn.ModuleList([dep])
+            else:  # TD model: plain lists, invisible to parameters()/state_dict()/.cuda() (time_sensitive.py:102-115)
+                self.aux_nets = [aux]
+                self.depth_nets = [dep]
+            self.aux_latent_dim += h * w // 4
+        if wrap:
+            self.feature_net = Replicated(trunk)
+        self._heads_registered = register_heads
+        self._arena = None
+        self._aux_op = None
+        self.rollout = False
+
+    # -- helpers --------------------------------------------------------------------------------
+    @property
+    def trunk(self):
+        f = self.feature_net
+        return f.module if isinstance(f, Replicated) else f
+
+    def _aux_modules(self):
+        aux, dep = self.aux_nets[0], self.depth_nets[0]
+        if isinstance(aux, Replicated):
+            aux, dep = aux.module, dep.module
+        return aux[0], dep[-2]  # Conv2d, InstanceNorm2d
+
+    def _materialize(self, device):
+        """First call on a device: put every parameter into one flat arena and bind gradient views."""
+        p0 = next(self.parameters())
+        if p0.device != device:
+            raise RuntimeError("model parameters are on %s but the batch is on %s: call model.cuda() first" % (p0.device, device))
+        if device.type != "cuda":
+            raise RuntimeError("the pose models run on the MI355X HIP path only; there is no CPU fallback (got %s tensors)" % device)
+        self.trunk.compute_dtype = self.compute_dtype
+        self.trunk.ensure_layout()
+        if self._arena is None or not self._arena.is_current():
+            self._arena = ParamArena(self)
+        if self.aux_nets is not None and self._aux_op is None or (self._aux_op is not None and self._aux_op.conv_w.device != device):
+            conv, inorm = self._aux_modules()
+            if not self._heads_registered:
+                for m in (conv, inorm):
+                    m.to(device)
+            self._aux_op = AuxHeadOp(conv.weight, conv.bias, inorm.weight, inorm.bias, trainable=self._heads_registered)
+
+    def _anchor(self):
+        for p in self.parameters():
+            if p.requires_grad:
+                return p
+        return None
+
+    def _call(self, img, depth, self_measurement):
+        self._materialize(img.device)
+        img = img.contiguous().float()
+        x0bar = None if self_measurement is None else self_measurement.contiguous().float()
+        anchor = self._anchor()
+        if torch.is_grad_enabled() and self.training and anchor is not None:
+            return _ModelFn.apply(self, anchor, img, depth, x0bar)
+        with torch.no_grad():
+            outs = self._forward_impl(img, depth, x0bar, save=False)
+        return outs if len(outs) > 1 else outs[0]
+
+    def _features_fwd(self, img, depth, rows, save):
+        """img (B,3,H,W); rows [B, ld] fp32: columns [0,L) <- ResNet latent, [L, L+aux) <- aux head."""
+        plan = self.trunk.run(img, rows, self.training)
+        if self.aux_nets is not None:
+            L = self.latent_dim
+            self._aux_op.fwd(plan, depth if self.use_depth else None, rows[:, L:L + self.aux_latent_dim], self.use_depth, save=save)
+        self._plan = plan
+        return plan
+
+    def _features_bwd(self, d_rows):
+        """d_rows [B, ld >= L + aux] gradient of the fused feature rows."""
+        use_early = self.aux_nets is not None
+        if use_early:
+            L = self.latent_dim
+            self._aux_op.bwd(d_rows[:, L:L + self.aux_latent_dim])
+        self._plan.backward(d_rows, use_early)
+
+    @staticmethod
+    def _pad_rows(t, cols):
+        """(…, cols) tensor -> [rows, cols] view of a zero-padded [rows, pad4(cols)] buffer"""
+        t2 = t.reshape(-1, cols)
+        out = new_rows(t2.shape[0], cols, t.device)
+        ops.copy2d(t2.contiguous().float(), out, cols=cols)
+        return out
+
+    def optimizer_stepped(self):
+        """The trunk caches compute-dtype copies of its weights; tell it they are stale."""
+        self.trunk.weights_changed()
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.trunk.weights_changed()
+        return r

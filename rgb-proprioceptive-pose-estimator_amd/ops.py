@@ -1,0 +1,255 @@
+"""Thin tensor-level wrappers over the C ABI (include/rpe_hip.h).
+
+PyTorch is used for device memory and streams only: every function here allocates its
+outputs with torch.empty on the input's device, passes raw device pointers plus the
+current HIP stream to librpe_hip.so, and returns the output tensors.  Activations of the
+conv trunk are NHWC tensors ([B, H, W, C], contiguous) in fp32 or bf16.
+"""
+import ctypes
+
+import torch
+
+from ._lib import RPE_BF16, RPE_F32, ConvDesc, lib
+
+_DT = {torch.float32: RPE_F32, torch.bfloat16: RPE_BF16}
+
+
+def dtype_code(t):
+    try:
+        return _DT[t if isinstance(t, torch.dtype) else t.dtype]
+    except KeyError:
+        raise TypeError("unsupported compute dtype %r (fp32 or bf16)" % (t,))
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("librpe_hip ops need device tensors (got a CPU tensor): the HIP path has no CPU fallback")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name):
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
+def pad4(n):
+    return (n + 3) // 4 * 4
+
+
+def conv_desc(x_shape, out_c, k, stride, pad):
+    b, h, w, c = x_shape
+    return ConvDesc(b, h, w, c, out_c, k, k, stride, pad)
+
+
+def conv_out_hw(d):
+    return (d.in_h + 2 * d.pad - d.kh) // d.stride + 1, (d.in_w + 2 * d.pad - d.kw) // d.stride + 1
+
+
+def stats_tiles(rows):
+    return (rows + 127) // 128
+
+
+def conv2d_fwd(x, w_krsc, stride, pad, want_stats=False):
+    """x [B,H,W,Ci], w_krsc [Co,kh,kw,Ci] (same dtype) -> y [B,Ho,Wo,Co] (+ stats partials [tiles,2,Co] fp32)."""
+    _chk(x, "x"), _chk(w_krsc, "w")
+    co, k = w_krsc.shape[0], w_krsc.shape[1]
+    d = conv_desc(x.shape, co, k, stride, pad)
+    ho, wo = conv_out_hw(d)
+    y = torch.empty((x.shape[0], ho, wo, co), dtype=x.dtype, device=x.device)
+    st = None
+    if want_stats:
+        st = torch.empty((stats_tiles(x.shape[0] * ho * wo), 2, co), dtype=torch.float32, device=x.device)
+    lib.rpe_conv2d_fwd(ctypes.byref(d), dtype_code(x), _p(x), _p(w_krsc), _p(y), _p(st), _stream())
+    return (y, st) if want_stats else y
+
+
+def conv2d_dgrad(dy, w_crsk, x_shape, stride, pad, addend=None):
+    """dy [B,Ho,Wo,Co], w_crsk [Ci,kh,kw,Co] -> dx [B,H,W,Ci] (+ addend)."""
+    _chk(dy, "dy"), _chk(w_crsk, "w")
+    ci, k, co = w_crsk.shape[0], w_crsk.shape[1], w_crsk.shape[3]
+    d = conv_desc(x_shape, co, k, stride, pad)
+    dx = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device)
+    lib.rpe_conv2d_dgrad(ctypes.byref(d), dtype_code(dy), _p(dy), _p(w_crsk), _p(dx), _p(addend), _stream())
+    return dx
+
+
+def conv2d_wgrad(x, dy, k, stride, pad):
+    """-> dw [Co,kh,kw,Ci] fp32"""
+    _chk(x, "x"), _chk(dy, "dy")
+    co = dy.shape[3]
+    d = conv_desc(x.shape, co, k, stride, pad)
+    dw = torch.zeros((co, k, k, x.shape[3]), dtype=torch.float32, device=x.device)
+    lib.rpe_conv2d_wgrad(ctypes.byref(d), dtype_code(x), _p(x), _p(dy), _p(dw), _stream())
+    return dw
+
+
+def pack_conv_weight(w_krsc_f32, dtype):
+    """fp32 [Co,kh,kw,Ci] -> (forward copy in `dtype`, dgrad copy [Ci,kh,kw,Co] in `dtype`)."""
+    co, kh, kw, ci = w_krsc_f32.shape
+    wf = torch.empty((co, kh, kw, ci), dtype=dtype, device=w_krsc_f32.device)
+    wd = torch.empty((ci, kh, kw, co), dtype=dtype, device=w_krsc_f32.device)
+    lib.rpe_pack_conv_weight(dtype_code(dtype), _p(_chk(w_krsc_f32, "w")), _p(wf), _p(wd), co, kh, kw, ci, _stream())
+    return wf, wd
+
+
+def stage_image(img_nchw, dtype):
+    b, c, h, w = img_nchw.shape
+    assert c == 3 and img_nchw.dtype == torch.float32
+    out = torch.empty((b, h, w, 4), dtype=dtype, device=img_nchw.device)
+    lib.rpe_stage_image_nhwc4(dtype_code(dtype), _p(_chk(img_nchw, "img")), _p(out), b, h, w, _stream())
+    return out
+
+
+def pack_stem_weight(w_oihw, dtype):
+    out = torch.empty((64, 8, 8, 4), dtype=dtype, device=w_oihw.device)
+    lib.rpe_pack_stem_weight(dtype_code(dtype), _p(_chk(w_oihw, "w")), _p(out), _stream())
+    return out
+
+
+def stem_conv_fwd(x4, w_packed, want_stats=False):
+    b, h, w, _ = x4.shape
+    ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+    y = torch.empty((b, ho, wo, 64), dtype=x4.dtype, device=x4.device)
+    st = torch.empty((stats_tiles(b * ho * wo), 2, 64), dtype=torch.float32, device=x4.device) if want_stats else None
+    lib.rpe_stem_conv_fwd(dtype_code(x4), _p(x4), _p(w_packed), _p(y), _p(st), b, h, w, _stream())
+    return (y, st) if want_stats else y
+
+
+def stem_conv_wgrad(x4, dy):
+    b, h, w, _ = x4.shape
+    dwp = torch.zeros((64, 8, 8, 4), dtype=torch.float32, device=x4.device)
+    lib.rpe_stem_conv_wgrad(dtype_code(x4), _p(x4), _p(dy), _p(dwp), b, h, w, _stream())
+    dw = torch.empty((64, 3, 7, 7), dtype=torch.float32, device=x4.device)
+    lib.rpe_unpack_stem_grad(_p(dwp), _p(dw), _stream())
+    return dw
+
+
+def bn_finalize(part, count, gamma, beta, running_mean=None, running_var=None, num_batches=None, momentum=0.1, eps=1e-5):
+    tiles, _, c = part.shape
+    dev = part.device
+    scale, shift, mean, invstd = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(4))
+    lib.rpe_bn_finalize(_p(part), tiles, c, count, _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(num_batches),
+                        momentum, eps, _p(scale), _p(shift), _p(mean), _p(invstd), _stream())
+    return scale, shift, mean, invstd
+
+
+def bn_apply(y, scale, shift, residual=None, relu=True):
+    out = torch.empty_like(y)
+    c = y.shape[-1]
+    lib.rpe_bn_apply(dtype_code(y), _p(_chk(y, "y")), _p(residual), _p(out), _p(scale), _p(shift), y.numel() // c, c, int(relu), _stream())
+    return out
+
+
+def bn_backward(dA, a_out, y, mean, invstd, gamma, want_dz=False):
+    c = y.shape[-1]
+    dev = y.device
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    dy = torch.empty_like(y)
+    dz = torch.empty_like(y) if want_dz else None
+    part = torch.empty(2 * 1024 * c, dtype=torch.float32, device=dev)
+    c1c2 = torch.empty(2 * c, dtype=torch.float32, device=dev)
+    lib.rpe_bn_backward(dtype_code(y), _p(dA), _p(a_out), _p(y), _p(mean), _p(invstd), _p(gamma), _p(dgamma), _p(dbeta), _p(dy), _p(dz),
+                        y.numel() // c, c, _p(part), part.numel(), _p(c1c2), _stream())
+    return dy, dgamma, dbeta, dz
+
+
+def maxpool_fwd(x):
+    b, h, w, c = x.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = torch.empty((b, ho, wo, c), dtype=x.dtype, device=x.device)
+    idx = torch.empty((b, ho, wo, c), dtype=torch.uint8, device=x.device)
+    lib.rpe_maxpool3x3s2_fwd(dtype_code(x), _p(_chk(x, "x")), _p(out), _p(idx), b, h, w, c, _stream())
+    return out, idx
+
+
+def maxpool_bwd(dout, idx, x_shape, addend=None):
+    b, h, w, c = x_shape
+    dx = torch.empty(tuple(x_shape), dtype=dout.dtype, device=dout.device)
+    lib.rpe_maxpool3x3s2_bwd(dtype_code(dout), _p(dout), _p(idx), _p(addend), _p(dx), b, h, w, c, _stream())
+    return dx
+
+
+def avgpool_fwd(x):
+    b, h, w, c = x.shape
+    out = torch.empty((b, c), dtype=torch.float32, device=x.device)
+    lib.rpe_avgpool_fwd(dtype_code(x), _p(_chk(x, "x")), _p(out), b, h * w, c, _stream())
+    return out
+
+
+def avgpool_bwd(dout, x_shape, dtype):
+    b, h, w, c = x_shape
+    dx = torch.empty(tuple(x_shape), dtype=dtype, device=dout.device)
+    lib.rpe_avgpool_bwd(dtype_code(dtype), _p(dout), _p(dx), b, h * w, c, _stream())
+    return dx
+
+
+def linear_fwd(x, w, bias=None, relu=False, addend=None, out=None, n=None, k=None):
+    """fp32 (or bf16) y[M, N] = x[M, :K] @ w[:N, :K]^T.  x, w, out, addend are 2-D with arbitrary (chunk-multiple) row strides."""
+    m = x.shape[0]
+    k = x.shape[1] if k is None else k
+    n = w.shape[0] if n is None else n
+    if out is None:
+        out = torch.zeros((m, pad4(n)), dtype=x.dtype, device=x.device)[:, :n]
+    lib.rpe_linear_fwd(dtype_code(x), _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), m, n, k, int(relu),
+                       _p(addend), 0 if addend is None else addend.stride(0), _stream())
+    return out
+
+
+def linear_wgrad(dy, x, dw, n=None, k=None):
+    """dw[:N, :K] (fp32) += dy[M, :N]^T @ x[M, :K]  (atomic accumulation into dw)."""
+    m = x.shape[0]
+    n = dy.shape[1] if n is None else n
+    k = x.shape[1] if k is None else k
+    lib.rpe_linear_wgrad(dtype_code(x), _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw.stride(0), m, n, k, _stream())
+    return dw
+
+
+def transpose_f32(w, ldo=None):
+    rows, cols = w.shape
+    ldo = pad4(rows) if ldo is None else ldo
+    out = torch.empty((cols, ldo), dtype=torch.float32, device=w.device)
+    lib.rpe_transpose_f32(_p(w), _p(out), rows, cols, w.stride(0), ldo, _stream())
+    return out
+
+
+def relu_bwd(out, dy):
+    dx = torch.empty_like(dy)
+    assert out.is_contiguous() and dy.is_contiguous()
+    lib.rpe_relu_bwd(_p(out), _p(dy), _p(dx), dy.numel(), _stream())
+    return dx
+
+
+def colsum(x, cols=None, out=None, accumulate=False):
+    rows = x.shape[0]
+    cols = x.shape[1] if cols is None else cols
+    if out is None:
+        out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    lib.rpe_colsum(_p(x), rows, cols, x.stride(0), _p(out), int(accumulate), _stream())
+    return out
+
+
+def copy2d(src, dst, cols=None):
+    cols = src.shape[1] if cols is None else cols
+    lib.rpe_copy2d(_p(src), src.stride(0), _p(dst), dst.stride(0), src.shape[0], cols, _stream())
+    return dst
+
+
+def pose_loss(pred, truth, metric, mode, scale, alpha, eps, want_grad=True):
+    """pred/truth (..., 7) fp32 contiguous -> (out3 [loss, val_pos, val_ori], grad or None)."""
+    n = pred.numel() // 7
+    out3 = torch.empty(3, dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred) if want_grad else None
+    lib.rpe_pose_loss(_p(_chk(pred, "pred")), _p(_chk(truth, "truth")), n, metric, mode, scale, alpha, eps, _p(out3), _p(grad), _stream())
+    return out3, grad
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
+    lib.rpe_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, _stream())

@@ -1,0 +1,53 @@
+"""Adam over the flat parameter arena: one HIP kernel per trainable segment instead of ~170 per-tensor
+update chains.  Same hyper-parameter defaults and update rule as torch.optim.Adam, which the reference
+constructs at scripts/train_model.py:228 (no weight decay, no amsgrad); parameters whose gradient is
+identically zero (e.g. the unused depth head) do not move, matching torch's `grad is None` skip.
+"""
+import torch
+
+from . import ops
+from .params import arena_of
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
+            raise ValueError("invalid Adam hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._step = 0
+        self._m = self._v = None
+        self._arena = None
+
+    def _ensure(self):
+        params = [p for g in self.param_groups for p in g["params"]]
+        arena = arena_of(params)
+        if arena is None:
+            raise RuntimeError("FusedAdam needs the model's flat parameter arena: run one forward on the device "
+                               "(or call model._materialize) before the first step")
+        if arena is not self._arena:
+            self._arena = arena
+            self._m = torch.zeros_like(arena.flat)
+            self._v = torch.zeros_like(arena.flat)
+        return arena
+
+    def zero_grad(self, set_to_none=True):
+        """The HIP backward overwrites every gradient view, so there is nothing to clear; kept for API parity
+        with the reference loop (util/learn_utils.py:152)."""
+        return None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        arena = self._ensure()
+        self._step += 1
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        for lo, hi in arena.trainable_segments():
+            ops.adam_step(arena.flat[lo:hi], arena.grad[lo:hi], self._m[lo:hi], self._v[lo:hi], g["lr"], b1, b2, g["eps"], self._step)
+        return None
+
+    def state_dict(self):
+        return {"step": self._step, "m": self._m, "v": self._v, "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self._step = sd["step"]
+        self._m, self._v = sd["m"], sd["v"]

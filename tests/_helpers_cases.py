@@ -1,0 +1,10 @@
+"""Golden-case table (must match oracle/gen_golden.py)."""
+CASES = {
+    # kind: (cfg, lead dims, weight seed, data seed) -- must match oracle/gen_golden.py
+    "no": (dict(latent_dim=64, hidden=[32, 16], use_depth=False, no_proprioception=False), (2,), 11, 101),
+    "n": (dict(latent_dim=64, hidden=[32]), (2,), 12, 102),
+    "td": (dict(latent_dim=64, hidden=32, use_depth=False), (2, 2), 13, 103),
+    "tdo": (dict(latent_dim=64, hidden=32, use_depth=True, no_proprioception=False), (2, 2), 14, 104),
+    "tdo_v2": (dict(latent_dim=64, hidden=32, proprio_hidden=8, use_depth=False), (2, 2), 15, 105),
+}
+LOSS_CFG = dict(metric="combined", scale=1.0, alpha=0.5, mode="pose")

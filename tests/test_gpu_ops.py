@@ -1,0 +1,380 @@
+"""GPU parity of every C-ABI kernel against a CPU fp32 torch statement of the same op (and the
+oracle where it has one).  Tolerances: fp32 path 2e-5 of the reference's max magnitude (exact-fp32
+MFMA, different summation order); bf16 path 2e-2 (8-bit mantissa inputs, fp32 accumulation)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from rgb_proprioceptive_pose_estimator_amd import ops
+    from oracle import pose_oracle as po
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 2e-2
+
+
+def rel_err(got, ref):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all(), "non-finite values in the GPU result"
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
+
+
+def q(t, dtype):
+    """round to the compute dtype and back (so the reference sees the same inputs)"""
+    return t.to(dtype).float()
+
+
+def nhwc(t):  # NCHW -> NHWC contiguous
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+# ------------------------------------------------------------------ dense GEMM (MFMA layout check)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,n,k", [(200, 7, 36), (128, 128, 64), (300, 130, 200), (64, 70, 8), (1, 512, 2048)])
+def test_linear_fwd_layout(dtype, m, n, k):
+    g = torch.Generator().manual_seed(m * 1000 + n)
+    kp = (k + 7) // 8 * 8
+    x = torch.zeros(m, kp)
+    w = torch.zeros(n, kp)
+    x[:, :k] = torch.randn(m, k, generator=g)
+    w[:, :k] = torch.randn(n, k, generator=g) + torch.arange(n).float()[:, None] * 0.01  # asymmetric
+    b = torch.randn(n, generator=g)
+    xd, wd = x.to(dtype).to(DEV), w.to(dtype).to(DEV)
+    out = ops.linear_fwd(xd, wd, b.to(DEV), relu=True)
+    ref = F.relu(q(x, dtype) @ q(w, dtype).t() + b)
+    assert rel_err(out, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,n,k", [(333, 7, 36), (1000, 128, 128), (4096, 64, 200), (50, 130, 64)])
+def test_linear_wgrad(dtype, m, n, k):
+    g = torch.Generator().manual_seed(m + n + k)
+    npad, kp = (n + 7) // 8 * 8, (k + 7) // 8 * 8
+    dy = torch.zeros(m, npad)
+    x = torch.zeros(m, kp)
+    dy[:, :n] = torch.randn(m, n, generator=g)
+    x[:, :k] = torch.randn(m, k, generator=g) + torch.arange(k).float()[None, :] * 0.01
+    dw = torch.zeros(n, kp, device=DEV)
+    ops.linear_wgrad(dy.to(dtype).to(DEV), x.to(dtype).to(DEV), dw, n=n, k=kp)
+    ref = q(dy, dtype)[:, :n].t() @ q(x, dtype)
+    assert rel_err(dw, ref) < tol(dtype)
+
+
+# ------------------------------------------------------------------ convolution
+CONVS = [  # (B, H, Cin, Cout, k, stride, pad)
+    (2, 14, 64, 64, 3, 1, 1),
+    (2, 14, 128, 64, 3, 2, 1),
+    (3, 8, 64, 256, 1, 1, 0),
+    (2, 14, 256, 512, 1, 2, 0),
+    (1, 7, 512, 128, 3, 1, 1),
+    (2, 10, 64, 128, 3, 2, 1),  # Ho*Wo not a multiple of anything convenient
+]
+
+
+def _conv_inputs(cfg, dtype):
+    b, h, ci, co, k, s, p = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(b, ci, h, h, generator=g)
+    w = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+    return q(x, dtype), q(w, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_fwd_and_stats(dtype, cfg):
+    b, h, ci, co, k, s, p = cfg
+    x, w = _conv_inputs(cfg, dtype)
+    ref = F.conv2d(x, w, None, s, p)
+    y, st = ops.conv2d_fwd(nhwc(x).to(dtype).to(DEV), nhwc(w).to(dtype).to(DEV), s, p, want_stats=True)
+    assert rel_err(nchw(y), ref) < tol(dtype)
+    sums = st.sum(0).cpu()  # [2, Co]
+    assert rel_err(sums[0], ref.sum((0, 2, 3))) < 1e-3 + tol(dtype)
+    assert rel_err(sums[1], (ref * ref).sum((0, 2, 3))) < 1e-3 + tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_dgrad(dtype, cfg):
+    b, h, ci, co, k, s, p = cfg
+    x, w = _conv_inputs(cfg, dtype)
+    x.requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    g = torch.Generator().manual_seed(5)
+    dy = q(torch.randn(y.shape, generator=g), dtype)
+    add = q(torch.randn(x.shape, generator=g), dtype)
+    (ref,) = torch.autograd.grad(y, x, dy)
+    w_crsk = w.permute(1, 2, 3, 0).contiguous()  # [Ci, kh, kw, Co]
+    dx = ops.conv2d_dgrad(nhwc(dy).to(dtype).to(DEV), w_crsk.to(dtype).to(DEV), (b, h, h, ci), s, p, addend=nhwc(add).to(dtype).to(DEV))
+    assert rel_err(nchw(dx), ref + add) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_wgrad(dtype, cfg):
+    b, h, ci, co, k, s, p = cfg
+    x, w = _conv_inputs(cfg, dtype)
+    w.requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = q(torch.randn(y.shape, generator=torch.Generator().manual_seed(6)), dtype)
+    (ref,) = torch.autograd.grad(y, w, dy)
+    dw = ops.conv2d_wgrad(nhwc(x).to(dtype).to(DEV), nhwc(dy).to(dtype).to(DEV), k, s, p)
+    assert rel_err(dw.permute(0, 3, 1, 2), ref) < tol(dtype)
+
+
+def test_pack_conv_weight():
+    w = torch.randn(64, 3, 3, 128)
+    wf, wd = ops.pack_conv_weight(w.to(DEV), torch.bfloat16)
+    assert torch.equal(wf.cpu(), w.bfloat16())
+    assert torch.equal(wd.cpu(), w.permute(3, 1, 2, 0).contiguous().bfloat16())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_stem_conv(dtype):
+    g = torch.Generator().manual_seed(3)
+    b, h = 2, 64
+    img = q(torch.randn(b, 3, h, h, generator=g), dtype)
+    w = q(torch.randn(64, 3, 7, 7, generator=g) / 12.0, dtype).requires_grad_(True)
+    ref = F.conv2d(img, w, None, 2, 3)
+    x4 = ops.stage_image(img.to(DEV), dtype)
+    assert torch.equal(x4[..., :3].float().cpu(), nhwc(img)) and (x4[..., 3] == 0).all()
+    wp = ops.pack_stem_weight(w.detach().to(DEV), dtype)
+    y, st = ops.stem_conv_fwd(x4, wp, want_stats=True)
+    assert rel_err(nchw(y), ref) < tol(dtype)
+    assert rel_err(st.sum(0)[0], ref.sum((0, 2, 3))) < 1e-3 + tol(dtype)
+    dy = q(torch.randn(ref.shape, generator=g), dtype)
+    (dw_ref,) = torch.autograd.grad(ref, w, dy)
+    dw = ops.stem_conv_wgrad(x4, nhwc(dy).to(dtype).to(DEV))
+    assert rel_err(dw, dw_ref) < tol(dtype)
+
+
+# ------------------------------------------------------------------ batch norm / pooling
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c,rows_hw", [(64, 14), (256, 7), (2048, 3)])
+@pytest.mark.parametrize("residual", [False, True])
+def test_bn_train_fwd_bwd(dtype, c, rows_hw, residual):
+    g = torch.Generator().manual_seed(c + rows_hw)
+    b = 3
+    y = q(torch.randn(b, c, rows_hw, rows_hw, generator=g) * 2 + 0.5, dtype).requires_grad_(True)
+    res = q(torch.randn(b, c, rows_hw, rows_hw, generator=g), dtype) if residual else None
+    gamma = (0.5 + torch.rand(c, generator=g)).requires_grad_(True)
+    beta = (torch.rand(c, generator=g) - 0.5).requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    z = F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    a_ref = F.relu(z + res) if residual else F.relu(z)
+    dA = q(torch.randn(a_ref.shape, generator=g), dtype)
+    dy_ref, dg_ref, db_ref = torch.autograd.grad(a_ref, (y, gamma, beta), dA)
+    # GPU: statistics from per-tile partials as the conv epilogue would produce them
+    yn = nhwc(y.detach())
+    rows = yn.numel() // c
+    tiles = ops.stats_tiles(rows)
+    flat = torch.zeros(tiles * 128, c)
+    flat[:rows] = yn.reshape(rows, c)
+    part = torch.stack([flat.view(tiles, 128, c).sum(1), (flat * flat).view(tiles, 128, c).sum(1)], 1).contiguous()
+    rmd, rvd = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    nbt = torch.zeros((), dtype=torch.long, device=DEV)
+    scale, shift, mean, invstd = ops.bn_finalize(part.to(DEV), rows, gamma.detach().to(DEV), beta.detach().to(DEV), rmd, rvd, nbt)
+    assert rel_err(rmd, rm) < 1e-5 and rel_err(rvd, rv) < 1e-5 and nbt.item() == 1
+    yd = yn.to(dtype).to(DEV)
+    a = ops.bn_apply(yd, scale, shift, None if res is None else nhwc(res).to(dtype).to(DEV), relu=True)
+    assert rel_err(nchw(a), a_ref) < tol(dtype)
+    # backward uses the GPU's own (rounded) activation as the ReLU mask, like the engine does
+    dy, dg, db, dz = ops.bn_backward(nhwc(dA).to(dtype).to(DEV), a, yd, mean, invstd, gamma.detach().to(DEV), want_dz=True)
+    t = 5e-5 if dtype == torch.float32 else 3e-2
+    assert rel_err(nchw(dy), dy_ref) < t
+    assert rel_err(dg, dg_ref) < t and rel_err(db, db_ref) < t
+    assert rel_err(nchw(dz), dA * (a_ref > 0)) < t
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_maxpool_avgpool(dtype):
+    g = torch.Generator().manual_seed(1)
+    x = q(torch.randn(2, 64, 16, 16, generator=g), dtype).clamp_min(0).requires_grad_(True)  # post-ReLU-like (ties at 0)
+    ref = F.max_pool2d(x, 3, 2, 1)
+    out, idx = ops.maxpool_fwd(nhwc(x.detach()).to(dtype).to(DEV))
+    assert rel_err(nchw(out), ref) == 0.0
+    d = q(torch.randn(ref.shape, generator=g), dtype)
+    add = q(torch.randn(x.shape, generator=g), dtype)
+    (dref,) = torch.autograd.grad(ref, x, d)
+    dx = ops.maxpool_bwd(nhwc(d).to(dtype).to(DEV), idx, (2, 16, 16, 64), addend=nhwc(add).to(dtype).to(DEV))
+    # where x == 0 the winner among tied zeros is implementation-defined and irrelevant (ReLU kills it)
+    mask = (x.detach() > 0).float()
+    assert rel_err(nchw(dx) .cpu().float() * mask, (dref + add) * mask) < tol(dtype)
+    x2 = q(torch.randn(3, 2048, 7, 7, generator=g), dtype)
+    p = ops.avgpool_fwd(nhwc(x2).to(dtype).to(DEV))
+    assert rel_err(p, x2.mean((2, 3))) < 1e-5
+    dp = torch.randn(3, 2048, generator=g)
+    dx2 = ops.avgpool_bwd(dp.to(DEV), (3, 7, 7, 2048), dtype)
+    assert rel_err(nchw(dx2), (dp / 49)[:, :, None, None].expand(3, 2048, 7, 7)) < tol(dtype)
+
+
+# ------------------------------------------------------------------ heads
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("use_depth", [False, True])
+def test_aux_and_depth_heads(dtype, use_depth):
+    import ctypes
+    from rgb_proprioceptive_pose_estimator_amd._lib import lib
+    g = torch.Generator().manual_seed(9)
+    b, h = 2, 16
+    a1 = q(torch.randn(b, 64, h, h, generator=g), dtype).clamp_min(0).requires_grad_(True)
+    w = (torch.randn(1, 64, 1, 1, generator=g) * 0.2).requires_grad_(True)
+    bias = torch.tensor([0.1], requires_grad=True)
+    depth = torch.rand(b, 1, 2 * h, 2 * h, generator=g)
+    dw_, db_ = torch.tensor([1.1], requires_grad=True), torch.tensor([-0.2], requires_grad=True)
+    ref = po.aux_head(a1, w, bias)
+    if use_depth:
+        ref = ref * po.depth_head(depth, dw_, db_)
+    n = (h // 2) ** 2
+    ld = n + 8
+    dout = torch.randn(b, n, generator=g)
+    grads = torch.autograd.grad(ref, (a1, w, bias) + ((dw_, db_) if use_depth else ()), dout)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    S = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    a1d = nhwc(a1.detach()).to(dtype).to(DEV)
+    wd, bd = w.detach().reshape(64).to(DEV), bias.detach().to(DEV)
+    feat = xhat = None
+    if use_depth:
+        feat = torch.empty(b, n, device=DEV)
+        xhat = torch.empty(b, n, device=DEV)
+        depth_d, dw_d, db_d = depth.to(DEV), dw_.detach().to(DEV), db_.detach().to(DEV)  # keep alive past the launch
+        lib.rpe_depth_head_fwd(P(depth_d), P(dw_d), P(db_d), P(feat), P(xhat), b, 2 * h, 2 * h, S)
+        assert rel_err(feat, po.depth_head(depth, dw_, db_)) < 1e-4
+    out = torch.zeros(b, ld, device=DEV)
+    raw = torch.empty(b, n, device=DEV)
+    idx = torch.empty(b, n, dtype=torch.uint8, device=DEV)
+    code = ops.dtype_code(dtype)
+    lib.rpe_aux_head_fwd(code, P(a1d), P(wd), P(bd), None if feat is None else P(feat), P(out), ld, P(raw), P(idx), b, h, h, S)
+    assert rel_err(out[:, :n], ref) < (1e-5 if dtype == torch.float32 else 1e-2)
+    doutd = torch.zeros(b, ld, device=DEV)
+    doutd[:, :n] = dout.to(DEV)
+    d_a1 = torch.empty_like(a1d)
+    gw, gb = torch.zeros(64, device=DEV), torch.zeros(1, device=DEV)
+    d_feat = torch.empty(b, n, device=DEV) if use_depth else None
+    lib.rpe_aux_head_bwd(code, P(doutd), ld, P(a1d), P(wd), None if feat is None else P(feat), P(raw), P(idx), P(d_a1), P(gw), P(gb),
+                         None if d_feat is None else P(d_feat), b, h, h, S)
+    t = 1e-4 if dtype == torch.float32 else 2e-2
+    assert rel_err(nchw(d_a1), grads[0]) < t
+    assert rel_err(gw, grads[1].reshape(64)) < t and rel_err(gb, grads[2]) < t
+    if use_depth:
+        gdw, gdb = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+        lib.rpe_depth_head_bwd(P(d_feat), P(xhat), b * n, P(gdw), P(gdb), S)
+        assert rel_err(gdw, grads[3]) < t and rel_err(gdb, grads[4]) < t
+
+
+def test_lstm_cell_matches_oracle():
+    import ctypes
+    from rgb_proprioceptive_pose_estimator_amd._lib import lib
+    g = torch.Generator().manual_seed(2)
+    S_, N, I_, H = 3, 5, 12, 16
+    x = torch.randn(S_, N, I_, generator=g)
+    w_ih = (torch.randn(4 * H, I_, generator=g) * 0.3).requires_grad_(True)
+    w_hh = (torch.randn(4 * H, H, generator=g) * 0.3).requires_grad_(True)
+    b_ih = (torch.randn(4 * H, generator=g) * 0.1).requires_grad_(True)
+    b_hh = (torch.randn(4 * H, generator=g) * 0.1).requires_grad_(True)
+    out_ref, _, _ = po.lstm_forward(x, w_ih, w_hh, b_ih, b_hh)
+    dout = torch.randn(out_ref.shape, generator=g)
+    g_wih, g_whh, g_bih, g_bhh = torch.autograd.grad(out_ref, (w_ih, w_hh, b_ih, b_hh), dout)
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    S = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d = lambda t: t.detach().to(DEV).contiguous()
+    xd, wih, whh, bih, bhh = d(x), d(w_ih), d(w_hh), d(b_ih), d(b_hh)
+    xg = ops.linear_fwd(xd.view(S_ * N, I_), wih).view(S_, N, 4 * H)
+    gates = torch.empty(S_, N, 4 * H, device=DEV)
+    hs = torch.empty(S_, N, H, device=DEV)
+    cs = torch.empty(S_, N, H, device=DEV)
+    for t in range(S_):
+        if t == 0:
+            gates[t].copy_(xg[t])
+        else:
+            ops.linear_fwd(hs[t - 1], whh, addend=xg[t], out=gates[t])
+        lib.rpe_lstm_cell_fwd(P(gates[t]), P(bih), P(bhh), P(cs[t - 1]) if t else None, P(cs[t]), P(hs[t]), N, H, S)
+    assert rel_err(hs, out_ref) < 1e-5
+    # backward through time
+    dgates = torch.empty(S_, N, 4 * H, device=DEV)
+    dc = torch.zeros(N, H, device=DEV)
+    dh_rec = torch.zeros(N, H, device=DEV)
+    whh_t = ops.transpose_f32(whh)  # [H, 4H]
+    doutd = d(dout)
+    for t in reversed(range(S_)):
+        dh = doutd[t] + dh_rec
+        lib.rpe_lstm_cell_bwd(P(gates[t]), P(cs[t - 1]) if t else None, P(cs[t]), P(dh), P(dc), P(dgates[t]), N, H, S)
+        if t:
+            dh_rec = ops.linear_fwd(dgates[t], whh_t, n=H, k=4 * H).contiguous()
+    dg2 = dgates.view(S_ * N, 4 * H)
+    gw_ih = torch.zeros(4 * H, I_, device=DEV)
+    ops.linear_wgrad(dg2, xd.view(S_ * N, I_), gw_ih)
+    gw_hh = torch.zeros(4 * H, H, device=DEV)
+    ops.linear_wgrad(dg2[N:], hs[:-1].reshape((S_ - 1) * N, H), gw_hh)
+    gb = ops.colsum(dg2)
+    assert rel_err(gw_ih, g_wih) < 1e-4 and rel_err(gw_hh, g_whh) < 1e-4
+    assert rel_err(gb, g_bih) < 1e-4 and rel_err(gb, g_bhh) < 1e-4
+
+
+METRICS = {"l2": 0, "l1": 1, "linf": 2, "combined": 3}
+
+
+def test_pose_loss_matches_golden_and_oracle(golden_dir):
+    gold = np.load(os.path.join(golden_dir, "pose_loss.npz"))
+    pred, truth = torch.from_numpy(gold["pred"]), torch.from_numpy(gold["truth"])
+    for metric, mi in METRICS.items():
+        for mode, mo in (("position", 0), ("pose", 1)):
+            for scale, alpha in ((1.0, 1.0), (2.5, 0.5)):
+                out3, grad = ops.pose_loss(pred.to(DEV), truth.to(DEV), mi, mo, scale, alpha, 1e-4)
+                tag = "%s_%s_%g_%g" % (metric, mode, scale, alpha)
+                np.testing.assert_allclose(out3[0].item(), gold["loss::" + tag], rtol=1e-5)
+                np.testing.assert_allclose(grad.cpu().numpy(), gold["grad::" + tag], rtol=1e-4, atol=1e-6)
+    out3, _ = ops.pose_loss(pred.to(DEV), truth.to(DEV), 0, 1, 1.0, 1.0, 1e-4, want_grad=False)
+    np.testing.assert_allclose(out3[1].item(), gold["val_pos"], rtol=1e-5)
+    np.testing.assert_allclose(out3[2].item(), gold["val_ori"], rtol=1e-5)
+    # a larger seeded batch against the oracle
+    b = po.synth_batch((64, 4), 77)
+    p = (b["obj"] + 0.3 * torch.randn(64, 4, 7, generator=torch.Generator().manual_seed(1))).requires_grad_(True)
+    ref = po.pose_loss(p, b["x0"], "combined", 1.0, 0.5, 1e-4, "pose")
+    (gref,) = torch.autograd.grad(ref, p)
+    out3, grad = ops.pose_loss(p.detach().to(DEV), b["x0"].to(DEV), 3, 1, 1.0, 0.5, 1e-4)
+    np.testing.assert_allclose(out3[0].item(), ref.item(), rtol=1e-5)
+    assert rel_err(grad, gref) < 1e-5
+    pe, oe = po.pose_loss(p.detach(), b["x0"], mode="val")
+    np.testing.assert_allclose(out3[1].item(), float(pe), rtol=1e-5)
+    np.testing.assert_allclose(out3[2].item(), oe, rtol=1e-4)
+
+
+def test_adam_matches_oracle():
+    g = torch.Generator().manual_seed(4)
+    n = 10007
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    m, v = torch.zeros(n), torch.zeros(n)
+    pd, md, vd = p.to(DEV), m.to(DEV), v.to(DEV)
+    for step in (1, 2, 3):
+        gstep = gr * step
+        po.adam_update(p, gstep, m, v, step, lr=1e-3)
+        ops.adam_step(pd, gstep.to(DEV), md, vd, 1e-3, 0.9, 0.999, 1e-8, step)
+    assert rel_err(pd, p) < 1e-6 and rel_err(md, m) < 1e-6 and rel_err(vd, v) < 1e-6
+
+
+def test_small_utils():
+    g = torch.Generator().manual_seed(8)
+    w = torch.randn(37, 50, generator=g)
+    wt = ops.transpose_f32(w.to(DEV))
+    assert torch.equal(wt[:, :37].cpu(), w.t()) and (wt[:, 37:] == 0).all()
+    out, dy = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+    assert torch.equal(ops.relu_bwd(out.to(DEV), dy.to(DEV)).cpu(), dy * (out > 0))
+    x = torch.randn(300, 70, generator=g)
+    assert rel_err(ops.colsum(x.to(DEV)), x.sum(0)) < 1e-5
+    dst = torch.zeros(300, 80, device=DEV)
+    ops.copy2d(x.to(DEV), dst[:, 5:], cols=70)
+    assert torch.equal(dst[:, 5:75].cpu(), x)
