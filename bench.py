@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: images/s of one full TRAIN STEP (stage image -> ResNet-50 trunk -> aux head ->
+proprio-fusion MLP -> PoseDistanceLoss (+ on-device val metrics) -> backward -> gradient all-reduce -> Adam)
+of NaiveObjectStateEstimator at 224x224, 256 images per GPU, bf16 compute / fp32 accumulate / fp32 masters
+(BASELINE.json configs[1]); synthetic Robosuite-shaped data resident in HBM, random-init weights.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel family of the step (HIP-event timed in
+a separate profiled pass after the timed region); `cpu_baseline` is the oracle (a CPU port of the reference
+path) timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CATS = ["conv_fwd", "conv_dgrad", "conv_wgrad", "bn_fwd", "bn_bwd", "other"]
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """cores this process may actually use: affinity mask capped by the cgroup CPU quota (a container on a big host)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """Oracle train step (fp32 torch-CPU ops) of the same model family: config C1 = 32 images, NO model."""
+    from oracle import pose_oracle as po
+    torch.set_num_threads(usable_cores())
+    log("[bench] cpu baseline on %d threads (os.cpu_count=%s, affinity=%d)" % (torch.get_num_threads(), os.cpu_count(), len(os.sched_getaffinity(0))))
+    cfg = dict(latent_dim=512, hidden=[1024, 256, 64], use_depth=False, no_proprioception=False)
+    sd = po.make_state("no", cfg, 0)
+    batch = po.synth_batch((32,), 1234)
+    loss_cfg = dict(metric="combined", scale=1.0, alpha=0.5, mode="pose")
+    opt = {}
+    po.train_step("no", cfg, sd, batch, loss_cfg, opt)  # warm-up
+    n, t0 = 0, time.time()
+    while n < 3 or (time.time() - t0 < seconds_budget and n < 8):
+        po.train_step("no", cfg, sd, batch, loss_cfg, opt)
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": round(32 / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d timed train steps (1 warm-up) of 32 images, fp32, NaiveObjectStateEstimator latent 512 hidden [1024,256,64], oracle/pose_oracle.py" % n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from rgb_proprioceptive_pose_estimator_amd import models as M
+    from rgb_proprioceptive_pose_estimator_amd._lib import RPE_F32, lib
+    from rgb_proprioceptive_pose_estimator_amd.dist import GradSync, broadcast_parameters, init_from_env
+    from rgb_proprioceptive_pose_estimator_amd.optim import FusedAdam
+    from rgb_proprioceptive_pose_estimator_amd.util.data_utils import synthetic_batch
+    from rgb_proprioceptive_pose_estimator_amd.util.learn_utils import train_step
+    import torch.distributed as dist
+
+    rank, world, local = init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    torch.manual_seed(0)
+    model = M.NaiveObjectStateEstimator("cube", [1024, 256, 64], 50, 512, False, (9,), False, False, False, compute_dtype=dtype)
+    model.cuda().train()
+    crit = M.PoseDistanceLoss(distance_metric="combined", scale_factor=1.0, alpha=0.5, mode="pose")
+    criterion = {"obj_loss": crit, "val_loss": M.PoseDistanceLoss(mode="val")}
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    b = synthetic_batch((args.batch,), 1234 + rank, device=dev)
+    batch = (b["img"], None, b["x0bar"], b["x0"], None, b["obj"])
+
+    # first step materialises the arena; then make replicas identical and set up the gradient reduction
+    train_step(model, batch, criterion, opt, True, "train", None)
+    sync = None
+    if world > 1:
+        broadcast_parameters(model._arena.flat, list(model.buffers()))
+        sync = GradSync(model._arena.grad)
+    for _ in range(max(0, args.warmup - 1)):
+        train_step(model, batch, criterion, opt, True, "train", sync)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log("[bench] warm-up done; timing %d steps" % args.steps)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _, _ = train_step(model, batch, criterion, opt, True, "train", sync)
+    fence()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+    final_loss = float(loss.item())
+
+    log("[bench] timed region: %.1f ms/step" % (dt / args.steps * 1e3))
+    # ---- profiled pass (not timed): HIP events around every launch of the trunk plan, per kernel family ----
+    plan = model.trunk._active
+    n_prof = 3
+    lib.rpe_resnet50_profile(plan.handle, 1)
+    for _ in range(n_prof):
+        train_step(model, batch, criterion, opt, True, "train", sync)
+    torch.cuda.synchronize()
+    ms = (ctypes.c_float * 6)()
+    launches = (ctypes.c_int * 6)()
+    flops = (ctypes.c_double * 6)()
+    byts = (ctypes.c_double * 6)()
+    lib.rpe_resnet50_profile_read(plan.handle, ms, launches, flops, byts)
+    lib.rpe_resnet50_profile(plan.handle, 0)
+    log("[bench] profiled pass read back")
+    fam = {}
+    for i, c in enumerate(CATS):
+        if launches[i]:
+            fam[c] = {"ms_per_step": ms[i] / n_prof, "launches_per_step": launches[i] // n_prof,
+                      "tflops": (flops[i] / 1e12) / (ms[i] / n_prof / 1e3) if flops[i] else None,
+                      "gbs": (byts[i] / 1e9) / (ms[i] / n_prof / 1e3) if byts[i] else None}
+    dom = max((c for c in fam if c.startswith("conv")), key=lambda c: fam[c]["ms_per_step"])
+    di = CATS.index(dom)
+    dom_ms = ms[di] / launches[di]
+    achieved = (flops[di] / (launches[di] / n_prof)) / 1e12 / (dom_ms / 1e3)   # algorithmic FLOPs per launch / avg launch duration
+    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                "avg_launch_ms": round(dom_ms, 4), "launches_per_step": launches[di] // n_prof,
+                "families": {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in fam.items()}}
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        out = {
+            "metric": "images/sec (train step, 224x224 bs256 per GPU)", "value": round(imgs / dt, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "NaiveObjectStateEstimator train step (BASELINE.json configs[1]): ResNet-50 trunk + bn1 aux head + "
+                                   "proprio MLP [1024,256,64] + PoseDistanceLoss(combined, alpha 0.5) + Adam",
+                       "images_per_gpu": args.batch, "global_batch": args.batch * world, "resolution": 224, "latent_dim": 512,
+                       "parallelism": "dp%d" % world, "final_loss": final_loss},
+            "roofline": roofline,
+        }
+        # whole-step view against both roofs (24.52 GFLOP and 152.9 MB per image)
+        ips = imgs / dt / world
+        out["step_roofline"] = {"tflops_per_gpu": round(ips * 24.52e9 / 1e12, 2), "frac_mfma": round(ips * 24.52e9 / 1e12 / PEAK_TFLOPS[args.dtype], 4),
+                                "ideal_fused_gbs_per_gpu": round(ips * 152.9e6 / 1e9, 1), "frac_hbm": round(ips * 152.9e6 / 1e9 / PEAK_HBM_GBS, 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -154,7 +154,8 @@ int rpe_pose_loss(const float* pred, const float* truth, long n, int metric, int
 
 /* replaces: torch.optim.Adam(model.parameters(), lr).step() (scripts/train_model.py:228,
  * util/learn_utils.py:179) over one flat parameter / gradient / moment buffer. */
-int rpe_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, int step, void* stream);
+int rpe_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2, double eps, int step,
+                  void* stream);
 
 /* ------------------------------------------------------------------ ResNet-50 trunk engine */
 /* One object = one (batch, dtype) plan for the whole torchvision-shaped ResNet-50 body:
@@ -192,6 +193,12 @@ const void* rpe_resnet50_early_feature(const rpe_resnet50_t* e);
 void* rpe_resnet50_early_grad(rpe_resnet50_t* e);
 /* parameter gradients are WRITTEN (not accumulated) into the bound grad tensors */
 int rpe_resnet50_backward(rpe_resnet50_t* e, const float* d_features, long ld_d_features, int use_d_early, void* stream);
+/* Optional measurement aid: HIP events around every launch of the plan (on the launch stream), summed per
+ * category.  enable=1 clears the counters.  Used by bench.py for the roofline line; off in timed regions. */
+enum { RPE_PROF_CONV_FWD = 0, RPE_PROF_CONV_DGRAD = 1, RPE_PROF_CONV_WGRAD = 2, RPE_PROF_BN_FWD = 3, RPE_PROF_BN_BWD = 4,
+       RPE_PROF_OTHER = 5, RPE_PROF_NUM = 6 };
+int rpe_resnet50_profile(rpe_resnet50_t* e, int enable);
+int rpe_resnet50_profile_read(rpe_resnet50_t* e, float* ms, int* launches, double* flops, double* bytes);
 /* debugging / parity: device pointer, rows and channels of a named intermediate (e.g. "layer1.0.y1") */
 int rpe_resnet50_tensor(const rpe_resnet50_t* e, const char* name, const void** ptr, long* rows, int* channels);
 

@@ -6,7 +6,11 @@ package.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_longlong, c_void_p
+
+# torch first: its wheel bundles its own libamdhip64.so.7.  Loading librpe_hip.so before torch would pull in
+# /opt/rocm's copy of the same SONAME and leave the process with two HIP runtimes (ours then sees no device).
+import torch  # noqa: F401
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librpe_hip.so")
@@ -23,7 +27,7 @@ class ConvDesc(Structure):
     _fields_ = [(n, c_int) for n in ("batch", "in_h", "in_w", "in_c", "out_c", "kh", "kw", "stride", "pad")]
 
 
-P, I, L, F = c_void_p, c_int, c_long, c_float
+P, I, L, F, D = c_void_p, c_int, c_long, c_float, c_double
 PD = POINTER(ConvDesc)
 
 # name -> (restype, argtypes).  Status-returning functions (restype int) are wrapped to raise.
@@ -62,7 +66,7 @@ _SPEC = {
     "rpe_lstm_cell_fwd": (I, [P, P, P, P, P, P, I, I, P]),
     "rpe_lstm_cell_bwd": (I, [P, P, P, P, P, P, I, I, P]),
     "rpe_pose_loss": (I, [P, P, L, I, I, F, F, F, P, P, P]),
-    "rpe_adam_step": (I, [P, P, P, P, L, F, F, F, F, I, P]),
+    "rpe_adam_step": (I, [P, P, P, P, L, D, D, D, D, I, P]),
     "rpe_resnet50_create": (I, [POINTER(c_void_p), I, I, I, I, I]),
     "rpe_resnet50_destroy": (None, [P]),
     "rpe_resnet50_workspace_bytes": (L, [P]),
@@ -74,6 +78,8 @@ _SPEC = {
     "rpe_resnet50_early_feature": (c_void_p, [P]),
     "rpe_resnet50_early_grad": (c_void_p, [P]),
     "rpe_resnet50_backward": (I, [P, P, L, I, P]),
+    "rpe_resnet50_profile": (I, [P, I]),
+    "rpe_resnet50_profile_read": (I, [P, POINTER(c_float), POINTER(c_int), POINTER(c_double), POINTER(c_double)]),
     "rpe_resnet50_tensor": (I, [P, c_char_p, POINTER(c_void_p), POINTER(c_long), POINTER(c_int)]),
 }
 # entry points whose int return value is data, not a status

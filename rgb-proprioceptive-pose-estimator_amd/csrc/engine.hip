@@ -78,7 +78,35 @@ struct rpe_resnet50 {
     float* stem_dw = nullptr;    // [64][8][8][4]
     std::vector<Named> named;
     int train_mode = 0;
+    // optional per-category HIP-event timing (rpe_resnet50_profile)
+    bool profiling = false;
+    struct Span { int cat; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_next = 0;
+    double flops[RPE_PROF_NUM] = {0};   // algorithmic FLOPs per pass, per category
+    double bytes[RPE_PROF_NUM] = {0};   // algorithmic bytes per pass, per category
 };
+
+static hipEvent_t next_event(rpe_resnet50* e) {
+    if (e->ev_next == e->ev_pool.size()) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+        e->ev_pool.push_back(ev);
+    }
+    return e->ev_pool[e->ev_next++];
+}
+
+// runs `call` and, when profiling, brackets it with events on the launch stream
+#define PROF(e, cat, stream, call)                                                   \
+    do {                                                                             \
+        hipEvent_t pa__ = nullptr, pb__ = nullptr;                                   \
+        if ((e)->profiling) { pa__ = next_event(e); pb__ = next_event(e);            \
+            if (pa__) (void)hipEventRecord(pa__, (hipStream_t)(stream)); }                 \
+        if (int err__ = (call)) return err__;                                        \
+        if ((e)->profiling && pa__ && pb__) { (void)hipEventRecord(pb__, (hipStream_t)(stream)); \
+            (e)->spans.push_back({(cat), pa__, pb__}); }                             \
+    } while (0)
 
 static int add_conv(rpe_resnet50* e, const std::string& name, const std::string& bn, int in_h, int in_w, int in_c, int out_c, int k,
                     int stride, int pad) {
@@ -174,11 +202,47 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
     want(e, (void**)&e->bwd_part, e->bwd_part_floats * 4);
     want(e, (void**)&e->c1c2, 2 * 2048 * 4L);
     want(e, (void**)&e->stem_dw, 64L * 256 * 4);
+    for (auto& c : e->convs) {
+        const double mnk = 2.0 * (double)c.rows * c.d.out_c * (double)(c.d.kh * c.d.kw * c.d.in_c);
+        const double in_b = (double)batch * c.d.in_h * c.d.in_w * c.d.in_c * es, out_b = (double)c.rows * c.d.out_c * es;
+        e->flops[RPE_PROF_CONV_FWD] += mnk;   e->bytes[RPE_PROF_CONV_FWD] += in_b + out_b;
+        e->flops[RPE_PROF_CONV_WGRAD] += mnk; e->bytes[RPE_PROF_CONV_WGRAD] += in_b + out_b;
+        if (&c != &e->convs[0]) { e->flops[RPE_PROF_CONV_DGRAD] += mnk; e->bytes[RPE_PROF_CONV_DGRAD] += in_b + out_b; }
+        e->bytes[RPE_PROF_BN_FWD] += 2 * out_b;   // read y, write a (+ residual read on block outputs, not counted)
+        e->bytes[RPE_PROF_BN_BWD] += 6 * out_b;   // reduce: dA, a, y ; apply: dA, a, y -> dy  (minimum two-pass form is 5)
+    }
     *out = e;
     return 0;
 }
 
-extern "C" void rpe_resnet50_destroy(rpe_resnet50_t* e) { delete e; }
+extern "C" int rpe_resnet50_profile(rpe_resnet50_t* e, int enable) {
+    if (!e) return rpe_set_error(RPE_ERR_STATE, "resnet50_profile: null engine");
+    e->profiling = enable != 0;
+    e->spans.clear();
+    e->ev_next = 0;
+    return 0;
+}
+
+// Sum of HIP-event elapsed time (ms) and number of bracketed launches per category since the last
+// rpe_resnet50_profile(e, 1); waits for the recorded work to finish.  flops/bytes: algorithmic work of ONE pass.
+extern "C" int rpe_resnet50_profile_read(rpe_resnet50_t* e, float* ms, int* launches, double* flops, double* bytes) {
+    if (!e) return rpe_set_error(RPE_ERR_STATE, "resnet50_profile_read: null engine");
+    for (int i = 0; i < RPE_PROF_NUM; ++i) { ms[i] = 0.f; launches[i] = 0; flops[i] = e->flops[i]; bytes[i] = e->bytes[i]; }
+    for (auto& sp : e->spans) {
+        if (hipError_t he = hipEventSynchronize(sp.b)) return rpe_set_error_hip(he, __FILE__, __LINE__);
+        float t = 0.f;
+        if (hipError_t he = hipEventElapsedTime(&t, sp.a, sp.b)) return rpe_set_error_hip(he, __FILE__, __LINE__);
+        ms[sp.cat] += t;
+        launches[sp.cat] += 1;
+    }
+    return 0;
+}
+
+extern "C" void rpe_resnet50_destroy(rpe_resnet50_t* e) {
+    if (!e) return;
+    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    delete e;
+}
 extern "C" long rpe_resnet50_workspace_bytes(const rpe_resnet50_t* e) { return e ? e->ws_bytes : 0; }
 extern "C" const char* rpe_resnet50_param_name(const rpe_resnet50_t* e, int i) {
     return (e && i >= 0 && i < (int)e->pnames.size()) ? e->pnames[i].c_str() : nullptr;
@@ -220,10 +284,10 @@ extern "C" int rpe_resnet50_bind(rpe_resnet50_t* e, void* workspace, long worksp
 
 extern "C" int rpe_resnet50_pack_weights(rpe_resnet50_t* e, void* stream) {
     if (!e || !e->bound) return rpe_set_error(RPE_ERR_STATE, "resnet50_pack_weights: engine not bound");
-    TRY(rpe_pack_stem_weight(e->dtype, e->params[e->convs[0].p_w], e->convs[0].wf, stream));
+    PROF(e, RPE_PROF_OTHER, stream, rpe_pack_stem_weight(e->dtype, e->params[e->convs[0].p_w], e->convs[0].wf, stream));
     for (size_t i = 1; i < e->convs.size(); ++i) {
         ConvL& c = e->convs[i];
-        TRY(rpe_pack_conv_weight(e->dtype, e->params[c.p_w], e->dtype == RPE_F32 ? nullptr : c.wf, c.wd, c.d.out_c, c.d.kh, c.d.kw, c.d.in_c, stream));
+        PROF(e, RPE_PROF_OTHER, stream, rpe_pack_conv_weight(e->dtype, e->params[c.p_w], e->dtype == RPE_F32 ? nullptr : c.wf, c.wd, c.d.out_c, c.d.kh, c.d.kw, c.d.in_c, stream));
     }
     const int np = (int)e->pnames.size();
     TRY(rpe_transpose_f32(e->params[np - 2], e->fc_wt, e->latent, 2048, 2048, e->latent_pad, stream));
@@ -235,18 +299,18 @@ static const void* fwd_weight(rpe_resnet50* e, ConvL& c) { return (e->dtype == R
 // conv -> batch statistics -> BN apply (+residual) (+relu)
 static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residual, int relu, void* stream) {
     const bool train = e->train_mode != 0;
-    if (&c == &e->convs[0]) TRY(rpe_stem_conv_fwd(e->dtype, x, c.wf, c.y, train ? e->stats_part : nullptr, e->B, e->H, e->W, stream));
-    else TRY(rpe_conv2d_fwd(&c.d, e->dtype, x, fwd_weight(e, c), c.y, train ? e->stats_part : nullptr, stream));
+    if (&c == &e->convs[0]) PROF(e, RPE_PROF_CONV_FWD, stream, rpe_stem_conv_fwd(e->dtype, x, c.wf, c.y, train ? e->stats_part : nullptr, e->B, e->H, e->W, stream));
+    else PROF(e, RPE_PROF_CONV_FWD, stream, rpe_conv2d_fwd(&c.d, e->dtype, x, fwd_weight(e, c), c.y, train ? e->stats_part : nullptr, stream));
     float* rm = e->running[2 * c.bn_i];
     float* rv = e->running[2 * c.bn_i + 1];
     if (train) {
-        TRY(rpe_bn_finalize(e->stats_part, (int)rpe_conv_stats_tiles(c.rows), c.d.out_c, c.rows, e->params[c.p_g], e->params[c.p_b], rm, rv,
+        PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_finalize(e->stats_part, (int)rpe_conv_stats_tiles(c.rows), c.d.out_c, c.rows, e->params[c.p_g], e->params[c.p_b], rm, rv,
                             e->nbt[c.bn_i], 0.1f, 1e-5f, c.scale, c.shift, c.mean, c.invstd, stream));
     } else {
         if (!rm || !rv) return rpe_set_error(RPE_ERR_STATE, "resnet50_forward: eval mode needs running statistics");
         TRY(rpe_bn_eval_affine(c.d.out_c, e->params[c.p_g], e->params[c.p_b], rm, rv, 1e-5f, c.scale, c.shift, stream));
     }
-    TRY(rpe_bn_apply(e->dtype, c.y, residual, c.a, c.scale, c.shift, c.rows, c.d.out_c, relu, stream));
+    PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_apply(e->dtype, c.y, residual, c.a, c.scale, c.shift, c.rows, c.d.out_c, relu, stream));
     return 0;
 }
 
@@ -254,10 +318,10 @@ extern "C" int rpe_resnet50_forward(rpe_resnet50_t* e, const float* img_nchw, fl
     if (!e || !e->bound) return rpe_set_error(RPE_ERR_STATE, "resnet50_forward: engine not bound");
     if (!img_nchw || !features || ld_features < e->latent) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_forward: bad img/features");
     e->train_mode = training;
-    TRY(rpe_stage_image_nhwc4(e->dtype, img_nchw, e->x4, e->B, e->H, e->W, stream));
+    PROF(e, RPE_PROF_OTHER, stream, rpe_stage_image_nhwc4(e->dtype, img_nchw, e->x4, e->B, e->H, e->W, stream));
     ConvL& st = e->convs[0];
     TRY(conv_bn(e, st, e->x4, nullptr, 1, stream));
-    TRY(rpe_maxpool3x3s2_fwd(e->dtype, st.a, e->pool, e->pool_idx, e->B, st.Ho, st.Wo, 64, stream));
+    PROF(e, RPE_PROF_OTHER, stream, rpe_maxpool3x3s2_fwd(e->dtype, st.a, e->pool, e->pool_idx, e->B, st.Ho, st.Wo, 64, stream));
     const void* x = e->pool;
     for (auto& b : e->blocks) {
         ConvL &c1 = e->convs[b.c1], &c2 = e->convs[b.c2], &c3 = e->convs[b.c3];
@@ -282,15 +346,17 @@ extern "C" void* rpe_resnet50_early_grad(rpe_resnet50_t* e) { return e ? e->earl
 
 // BN backward of layer c: dA (grad wrt c.a) -> dy (may alias dA); dz_out optional
 static int bn_back(rpe_resnet50* e, ConvL& c, const void* dA, int relu, void* dy, void* dz_out, void* stream) {
-    return rpe_bn_backward(e->dtype, dA, relu ? c.a : nullptr, c.y, c.mean, c.invstd, e->params[c.p_g], e->grads[c.p_g], e->grads[c.p_b], dy,
-                           dz_out, c.rows, c.d.out_c, e->bwd_part, e->bwd_part_floats, e->c1c2, stream);
+    PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_backward(e->dtype, dA, relu ? c.a : nullptr, c.y, c.mean, c.invstd, e->params[c.p_g], e->grads[c.p_g], e->grads[c.p_b], dy,
+                           dz_out, c.rows, c.d.out_c, e->bwd_part, e->bwd_part_floats, e->c1c2, stream));
+    return 0;
 }
 
 static int wgrad(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, void* stream) {
     float* dw = e->grads[c.p_w];
     hipError_t he = hipMemsetAsync(dw, 0, (size_t)e->pnumel[c.p_w] * 4, (hipStream_t)stream);
     if (he != hipSuccess) return rpe_set_error_hip(he, __FILE__, __LINE__);
-    return rpe_conv2d_wgrad(&c.d, e->dtype, x, dy, dw, stream);
+    PROF(e, RPE_PROF_CONV_WGRAD, stream, rpe_conv2d_wgrad(&c.d, e->dtype, x, dy, dw, stream));
+    return 0;
 }
 
 extern "C" int rpe_resnet50_backward(rpe_resnet50_t* e, const float* d_features, long ld_d_features, int use_d_early, void* stream) {
@@ -322,10 +388,10 @@ extern "C" int rpe_resnet50_backward(rpe_resnet50_t* e, const float* d_features,
         // bn3 (+ residual split): dy3 in place in g0, dz (identity-branch gradient) -> g2
         TRY(bn_back(e, c3, g0, 1, g0, g2, stream));
         TRY(wgrad(e, c3, c2.a, g0, stream));
-        TRY(rpe_conv2d_dgrad(&c3.d, e->dtype, g0, c3.wd, g1, nullptr, stream));  // dA2 -> g1
+        PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&c3.d, e->dtype, g0, c3.wd, g1, nullptr, stream));  // dA2 -> g1
         TRY(bn_back(e, c2, g1, 1, g1, nullptr, stream));
         TRY(wgrad(e, c2, c1.a, g1, stream));
-        TRY(rpe_conv2d_dgrad(&c2.d, e->dtype, g1, c2.wd, g0, nullptr, stream));  // dA1 -> g0
+        PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&c2.d, e->dtype, g1, c2.wd, g0, nullptr, stream));  // dA1 -> g0
         TRY(bn_back(e, c1, g0, 1, g0, nullptr, stream));
         TRY(wgrad(e, c1, x_in, g0, stream));
         const void* shortcut = g2;
@@ -333,18 +399,18 @@ extern "C" int rpe_resnet50_backward(rpe_resnet50_t* e, const float* d_features,
             ConvL& cd = e->convs[b.cd];
             TRY(bn_back(e, cd, g2, 0, g2, nullptr, stream));
             TRY(wgrad(e, cd, x_in, g2, stream));
-            TRY(rpe_conv2d_dgrad(&cd.d, e->dtype, g2, cd.wd, g1, nullptr, stream));  // -> g1
+            PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&cd.d, e->dtype, g2, cd.wd, g1, nullptr, stream));  // -> g1
             shortcut = g1;
         }
-        TRY(rpe_conv2d_dgrad(&c1.d, e->dtype, g0, c1.wd, g3, shortcut, stream));  // dX_in -> g3
+        PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&c1.d, e->dtype, g0, c1.wd, g3, shortcut, stream));  // dX_in -> g3
         void* t = g0; g0 = g3; g3 = t;
     }
     // stem: g0 = gradient wrt maxpool output
     ConvL& st = e->convs[0];
-    TRY(rpe_maxpool3x3s2_bwd(e->dtype, g0, e->pool_idx, use_d_early ? e->early_grad : nullptr, g1, e->B, st.Ho, st.Wo, 64, stream));
+    PROF(e, RPE_PROF_OTHER, stream, rpe_maxpool3x3s2_bwd(e->dtype, g0, e->pool_idx, use_d_early ? e->early_grad : nullptr, g1, e->B, st.Ho, st.Wo, 64, stream));
     TRY(bn_back(e, st, g1, 1, g1, nullptr, stream));
     if (hipError_t he = hipMemsetAsync(e->stem_dw, 0, 64 * 256 * 4, s)) return rpe_set_error_hip(he, __FILE__, __LINE__);
-    TRY(rpe_stem_conv_wgrad(e->dtype, e->x4, g1, e->stem_dw, e->B, e->H, e->W, stream));
+    PROF(e, RPE_PROF_CONV_WGRAD, stream, rpe_stem_conv_wgrad(e->dtype, e->x4, g1, e->stem_dw, e->B, e->H, e->W, stream));
     TRY(rpe_unpack_stem_grad(e->stem_dw, e->grads[st.p_w], stream));
     return 0;
 }

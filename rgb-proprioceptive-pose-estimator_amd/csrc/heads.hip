@@ -304,14 +304,14 @@ __global__ __launch_bounds__(256) void pose_loss_kernel(const float* __restrict_
 // Adam over flat fp32 buffers (torch.optim.Adam defaults: no amsgrad, no weight decay)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                  long n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+                                                  long n, float lr, float omb1, float b2, float omb2, float eps, float bc1, float bc2_sqrt) {
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         f32x4 pp = ((f32x4*)p)[i], gg = ((const f32x4*)g)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            mm[k] = mm[k] + (gg[k] - mm[k]) * (1.f - b1);
-            vv[k] = vv[k] * b2 + gg[k] * gg[k] * (1.f - b2);
+            mm[k] = mm[k] + (gg[k] - mm[k]) * omb1;
+            vv[k] = vv[k] * b2 + gg[k] * gg[k] * omb2;
             const float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
             pp[k] -= (lr / bc1) * (mm[k] / denom);
         }
@@ -320,8 +320,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const long i = (n4 << 2) + threadIdx.x;
         const float gi = g[i];
-        const float mi = m[i] + (gi - m[i]) * (1.f - b1);
-        const float vi = v[i] * b2 + gi * gi * (1.f - b2);
+        const float mi = m[i] + (gi - m[i]) * omb1;
+        const float vi = v[i] * b2 + gi * gi * omb2;
         m[i] = mi; v[i] = vi;
         p[i] -= (lr / bc1) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
     }
@@ -481,12 +481,15 @@ int rpe_pose_loss(const float* pred, const float* truth, long n, int metric, int
     return 0;
 }
 
-int rpe_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, int step, void* stream) {
+int rpe_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2, double eps, int step, void* stream) {
     if (n <= 0) return 0;
     if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return rpe_set_error(RPE_ERR_ALIGN, "adam: buffers must be 16-byte aligned");
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2s);
+    // scalars in double, as torch.optim.Adam computes them on the host (1 - 0.999f != 0.001f)
+    const double b1d = beta1, b2d = beta2;
+    const float bc1 = (float)(1.0 - pow(b1d, (double)step));
+    const float bc2s = (float)sqrt(1.0 - pow(b2d, (double)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)lr, (float)(1.0 - b1d),
+                       (float)beta2, (float)(1.0 - b2d), (float)eps, bc1, bc2s);
     RPE_CHECK_LAUNCH();
     return 0;
 }

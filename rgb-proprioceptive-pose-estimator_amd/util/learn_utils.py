@@ -1,0 +1,129 @@
+"""Training loop of the pose estimators on the MI355X path.
+
+Same signature, phases, criterion dict, statistics and checkpoint naming as train() of the reference
+(util/learn_utils.py:21-255); what changes is underneath:
+  * batches are time-major slices of data already resident in HBM (no DataLoader worker processes, no
+    per-tensor pageable .cuda() copies, util/learn_utils.py:75-76,130-138);
+  * the per-step "val" metric is reduced on the device and only read back once per phase (the reference
+    synchronises twice per step: models/losses.py:99-113 and util/learn_utils.py:182);
+  * with torch.distributed initialised, episodes are sharded over ranks and the flat gradient buffer is
+    SUM-all-reduced (RCCL) between backward and the optimizer step.
+rollout() of the reference needs the simulator and is out of scope.
+"""
+import copy
+import os
+import time
+from datetime import datetime
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ..dist import GradSync, shard_bounds
+
+
+def _writer(logging):
+    if not logging:
+        return None
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        return SummaryWriter()
+    except Exception:  # tensorboard is optional here
+        return None
+
+
+def train_step(model, batch, criterion, optimizer, train_obj_pose, phase="train", grad_sync=None):
+    """One iteration of the reference's hot loop (util/learn_utils.py:152-184).  Returns device scalars
+    (loss, pos_err, ori_err) -- nothing is synchronised to the host."""
+    img, depth, x0bar, x0, x1, obj = batch
+    optimizer.zero_grad()
+    with torch.set_grad_enabled(phase == "train"):
+        if train_obj_pose:
+            obj_out = model(img, depth, x0bar)
+            loss = criterion["obj_loss"](obj_out, obj)
+            pos_err, ori_err = criterion["val_loss"].forward_device(obj_out, obj)
+        else:
+            x0_out, x1_out = model(img, depth, x0bar)
+            loss = criterion["x0_loss"](x0_out, x0) + criterion["x1_loss"](x1_out, x1)
+            pos_err, ori_err = criterion["val_loss"].forward_device(x1_out, x1)
+        if phase == "train":
+            loss.backward()
+            if grad_sync is not None:
+                grad_sync.all_reduce()
+            optimizer.step()
+    return loss.detach(), pos_err, ori_err
+
+
+def train(model, dataset, criterion, optimizer, num_epochs, num_train_episodes_per_epoch, num_val_episodes_per_epoch, params, device,
+          save_path='default', save_model=True, logging=True):
+    """See the module docstring.  Returns (model with the best validation weights, best validation loss)."""
+    train_obj_pose = hasattr(model, "object_name")
+    dt_string = datetime.now().strftime("%d-%m-%Y_%H-%M-%S")
+    since = time.time()
+    best_model = copy.deepcopy(model.state_dict())
+    best_err = np.inf
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    writer = _writer(logging and rank == 0)
+    if device == "cpu":
+        raise RuntimeError("train(): the pose train step runs on the MI355X HIP path only (device='cuda:N'); there is no CPU fallback")
+    model.cuda()
+    seq = model.sequence_length if model.requires_sequence else 1
+    fname = "{}_{}_{}hzn_{}ep_{}.pth".format(type(model).__name__, type(dataset.env).__name__, dataset.env.horizon,
+                                             num_epochs * num_train_episodes_per_epoch, dt_string)
+    if save_model and rank == 0:
+        print("\nFile name saved:\n{}\n".format(fname))
+    grad_sync = None
+    for epoch in range(num_epochs):
+        if logging and rank == 0:
+            print("\n" + "-" * 10 + "\nEpoch {}/{}\n".format(epoch, num_epochs - 1) + "-" * 10)
+        for phase in ["train", "val"]:
+            num_episodes = num_train_episodes_per_epoch if phase == "train" else num_val_episodes_per_epoch
+            model.train() if phase == "train" else model.eval()
+            lo, hi = shard_bounds(num_episodes, rank, world)
+            dataset.refresh_data(hi - lo, params["camera_name"], params["noise_scale"])
+            model.reset_initial_state(hi - lo)
+            sums = torch.zeros(3, dtype=torch.float64, device="cuda")
+            horizon = len(dataset)
+            for t0 in range(0, horizon, seq):
+                img, depth, x0bar, x0, x1, obj = dataset.chunk(t0, min(seq, horizon - t0))
+                if not model.requires_sequence:  # the reference squeezes the leading batch-of-1 dim (learn_utils.py:141-149)
+                    img, x0bar, x0 = img[0], x0bar[0], x0[0]
+                    depth = None if depth is None else depth[0]
+                    x1 = None if x1 is None else x1[0]
+                    obj = None if obj is None else obj[0]
+                if phase == "train" and world > 1 and grad_sync is None and getattr(model, "_arena", None) is not None:
+                    grad_sync = GradSync(model._arena.grad)
+                loss, pe, oe = train_step(model, (img, depth, x0bar, x0, x1, obj), criterion, optimizer, train_obj_pose, phase, grad_sync)
+                if phase == "train" and world > 1 and grad_sync is None:  # arena exists only after the first forward
+                    grad_sync = GradSync(model._arena.grad)
+                sums += torch.stack([loss.double(), pe.double(), oe.double()])
+            if world > 1:
+                dist.all_reduce(sums)
+            tot = sums.tolist()  # the one host synchronisation of the phase
+            denom = horizon * num_episodes
+            epoch_loss, epoch_pos_err, epoch_ori_err = tot[0] / denom, tot[1] / denom, tot[2] / denom
+            time_elapsed = time.time() - since
+            if writer is not None:
+                tag = "train" if phase == "train" else "val"
+                writer.add_scalar("Loss/" + tag, epoch_loss, epoch)
+                writer.add_scalar("Err_pos/" + tag, epoch_pos_err, epoch)
+                writer.add_scalar("Err_ori/" + tag, epoch_ori_err, epoch)
+            if logging and rank == 0:
+                print('{} Loss: {:.4f}, PosErr: {:.4f}, OriErr: {:.4f}. Time elapsed = {:.0f}m {:.0f}s'.format(
+                    phase, epoch_loss, epoch_pos_err, epoch_ori_err, time_elapsed // 60, time_elapsed % 60))
+            if phase == "val" and epoch_loss < best_err:
+                best_err = epoch_loss
+                best_model = copy.deepcopy(model.state_dict())
+                if save_model and rank == 0:
+                    if save_path == 'default':
+                        save_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "log", "runs", fname)
+                    os.makedirs(os.path.dirname(os.path.abspath(save_path)), exist_ok=True)
+                    torch.save(model.state_dict(), save_path)
+    if logging and rank == 0:
+        time_elapsed = time.time() - since
+        print('-' * 10)
+        print('Training completed in {:.0f}m {:.0f}s'.format(time_elapsed // 60, time_elapsed % 60))
+        print('Best val Err: {:.4f}'.format(best_err))
+    model.load_state_dict(best_model)
+    return model, best_err

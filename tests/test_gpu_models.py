@@ -86,6 +86,10 @@ def test_model_fp32_matches_reference_and_oracle(kind, golden_dir):
     opt = FusedAdam(model.parameters(), lr=1e-3)
     b1c = po.synth_batch(lead, dseed + 1, with_depth=cfg.get("use_depth", False))
     ref = po.train_step(kind, cfg, {k: v.clone() for k, v in sd.items()}, b1c, LOSS_CFG, {}, lr=1e-3)
+    # fp64 run of the oracle: the yardstick for how much an fp32 implementation may deviate on this network
+    sd64 = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+    b64 = {k: (None if v is None else v.double()) for k, v in b1c.items()}
+    ref64 = po.train_step(kind, cfg, sd64, b64, LOSS_CFG, {}, lr=1e-3, val_metrics=False)
     opt.zero_grad()
     outs, loss, pe, oe = run_step(model, kind, to_dev(b1c), crit, val)
     for i, o in enumerate(outs):
@@ -93,15 +97,26 @@ def test_model_fp32_matches_reference_and_oracle(kind, golden_dir):
     np.testing.assert_allclose(loss.item(), gold["loss_s1"], rtol=1e-4)
     np.testing.assert_allclose(float(pe), gold["pos_err_s1"], rtol=1e-4)
     np.testing.assert_allclose(oe, gold["ori_err_s1"], rtol=1e-4, atol=1e-4)
+    # Gradients.  With random weights this 50-layer train-mode-BN network amplifies fp32 rounding ~1e5x: torch's own
+    # CPU fp32 gradients differ from an fp64 run by ~2e-2 (median over tensors) and up to ~0.2 (tools/debug_grads.py).
+    # So the bar is set by that yardstick: the HIP fp32 path must be as close to fp64 as the CPU fp32 reference is.
     named = dict(model.named_parameters())
-    worst = (0.0, None)
-    for name, g_ref in ref["grads"].items():
+    e_gpu, e_cpu, cos = {}, {}, {}
+    for name, g64 in ref64["grads"].items():
         g = named[name].grad
         assert g is not None, name
-        e = rel(g, g_ref)
-        if e > worst[0]:
-            worst = (e, name)
-    assert worst[0] < 2e-3, "gradient mismatch %s" % (worst,)
+        gc = g.detach().double().cpu()
+        e_gpu[name] = ((gc - g64).abs().max() / g64.abs().max().clamp_min(1e-30)).item()
+        e_cpu[name] = ((ref["grads"][name].double() - g64).abs().max() / g64.abs().max().clamp_min(1e-30)).item()
+        cos[name] = (torch.dot(gc.flatten(), g64.flatten()) / (gc.norm() * g64.norm()).clamp_min(1e-300)).item()
+    mg, mc = np.median(list(e_gpu.values())), np.median(list(e_cpu.values()))
+    xg, xc = max(e_gpu.values()), max(e_cpu.values())
+    assert mg <= 2.0 * mc + 1e-4, "median gradient error %.3g vs CPU-fp32 yardstick %.3g" % (mg, mc)
+    assert xg <= 3.0 * xc + 1e-3, "max gradient error %.3g vs CPU-fp32 yardstick %.3g (%s)" % (xg, xc, max(e_gpu, key=e_gpu.get))
+    assert min(cos.values()) > 0.97, "gradient direction off: %s" % (min(cos, key=cos.get),)
+    for name in e_gpu:  # the layers after the trunk are well conditioned: tight
+        if "feature_net" not in name and "aux_nets" not in name and "depth_nets" not in name:
+            assert e_gpu[name] < 1e-4 + 3 * e_cpu[name], (name, e_gpu[name], e_cpu[name])
     for name, p in named.items():  # parameters the reference leaves without a gradient stay untouched by Adam
         if name not in ref["grads"]:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
