@@ -88,19 +88,21 @@ int rpe_stage_image_nhwc4(int dtype, const float* img_nchw, void* out, int B, in
 /* replaces: nn.BatchNorm2d (train mode: biased batch variance, eps, momentum with
  * unbiased running variance) + the in-place nn.ReLU and `out += identity` of the
  * torchvision Bottleneck. */
+/* dpart: RPE_BN_MAX_SLICES*2*C doubles of scratch for the staged (deterministic) partial-sum reduction */
+#define RPE_BN_MAX_SLICES 256
 int rpe_bn_finalize(const float* part, int tiles, int C, long count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, long long* num_batches, float momentum, float eps, float* scale, float* shift,
-                    float* save_mean, float* save_invstd, void* stream);
+                    float* save_mean, float* save_invstd, double* dpart, void* stream);
 int rpe_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                        float* scale, float* shift, void* stream);
 /* out = relu?(y*scale + shift (+ residual)) */
 int rpe_bn_apply(int dtype, const void* y, const void* residual, void* out, const float* scale, const float* shift, long rows, int C,
                  int relu, void* stream);
 /* dz = dA * (a_out > 0) (a_out null: no ReLU); dgamma, dbeta; dy = BN backward of dz; dz_out (nullable) = dz.
- * part: >= 2*1024*C floats of scratch; c1c2: 2*C floats of scratch. */
+ * part: >= 2*1024*C floats of scratch; c1c2: 2*C floats of scratch; dpart: as for rpe_bn_finalize. */
 int rpe_bn_backward(int dtype, const void* dA, const void* a_out, const void* y, const float* mean, const float* invstd,
                     const float* gamma, float* dgamma, float* dbeta, void* dy, void* dz_out, long rows, int C, float* part,
-                    long part_floats, float* c1c2, void* stream);
+                    long part_floats, float* c1c2, double* dpart, void* stream);
 
 /* ------------------------------------------------------------------ pooling */
 /* replaces: nn.MaxPool2d(3, 2, 1) of the ResNet stem; idx keeps the winning tap. */

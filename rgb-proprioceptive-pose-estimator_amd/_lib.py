@@ -45,10 +45,10 @@ _SPEC = {
     "rpe_pack_stem_weight": (I, [I, P, P, P]),
     "rpe_unpack_stem_grad": (I, [P, P, P]),
     "rpe_stage_image_nhwc4": (I, [I, P, P, I, I, I, P]),
-    "rpe_bn_finalize": (I, [P, I, I, L, P, P, P, P, P, F, F, P, P, P, P, P]),
+    "rpe_bn_finalize": (I, [P, I, I, L, P, P, P, P, P, F, F, P, P, P, P, P, P]),
     "rpe_bn_eval_affine": (I, [I, P, P, P, P, F, P, P, P]),
     "rpe_bn_apply": (I, [I, P, P, P, P, P, L, I, I, P]),
-    "rpe_bn_backward": (I, [I, P, P, P, P, P, P, P, P, P, P, L, I, P, L, P, P]),
+    "rpe_bn_backward": (I, [I, P, P, P, P, P, P, P, P, P, P, L, I, P, L, P, P, P]),
     "rpe_maxpool3x3s2_fwd": (I, [I, P, P, P, I, I, I, I, P]),
     "rpe_maxpool3x3s2_bwd": (I, [I, P, P, P, P, I, I, I, I, P]),
     "rpe_avgpool_fwd": (I, [I, P, P, I, I, I, P]),

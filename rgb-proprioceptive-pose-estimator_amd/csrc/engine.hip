@@ -75,6 +75,7 @@ struct rpe_resnet50 {
     float* bwd_part = nullptr;
     long bwd_part_floats = 0;
     float* c1c2 = nullptr;
+    double* dpart = nullptr;     // staged BN partial-sum reduction scratch
     float* stem_dw = nullptr;    // [64][8][8][4]
     std::vector<Named> named;
     int train_mode = 0;
@@ -201,6 +202,7 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
     e->bwd_part_floats = 1024L * 2 * 2048;
     want(e, (void**)&e->bwd_part, e->bwd_part_floats * 4);
     want(e, (void**)&e->c1c2, 2 * 2048 * 4L);
+    want(e, (void**)&e->dpart, (long)RPE_BN_MAX_SLICES * 2 * 2048 * 8);
     want(e, (void**)&e->stem_dw, 64L * 256 * 4);
     for (auto& c : e->convs) {
         const double mnk = 2.0 * (double)c.rows * c.d.out_c * (double)(c.d.kh * c.d.kw * c.d.in_c);
@@ -305,7 +307,7 @@ static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residua
     float* rv = e->running[2 * c.bn_i + 1];
     if (train) {
         PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_finalize(e->stats_part, (int)rpe_conv_stats_tiles(c.rows), c.d.out_c, c.rows, e->params[c.p_g], e->params[c.p_b], rm, rv,
-                            e->nbt[c.bn_i], 0.1f, 1e-5f, c.scale, c.shift, c.mean, c.invstd, stream));
+                            e->nbt[c.bn_i], 0.1f, 1e-5f, c.scale, c.shift, c.mean, c.invstd, e->dpart, stream));
     } else {
         if (!rm || !rv) return rpe_set_error(RPE_ERR_STATE, "resnet50_forward: eval mode needs running statistics");
         TRY(rpe_bn_eval_affine(c.d.out_c, e->params[c.p_g], e->params[c.p_b], rm, rv, 1e-5f, c.scale, c.shift, stream));
@@ -347,7 +349,7 @@ extern "C" void* rpe_resnet50_early_grad(rpe_resnet50_t* e) { return e ? e->earl
 // BN backward of layer c: dA (grad wrt c.a) -> dy (may alias dA); dz_out optional
 static int bn_back(rpe_resnet50* e, ConvL& c, const void* dA, int relu, void* dy, void* dz_out, void* stream) {
     PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_backward(e->dtype, dA, relu ? c.a : nullptr, c.y, c.mean, c.invstd, e->params[c.p_g], e->grads[c.p_g], e->grads[c.p_b], dy,
-                           dz_out, c.rows, c.d.out_c, e->bwd_part, e->bwd_part_floats, e->c1c2, stream));
+                           dz_out, c.rows, c.d.out_c, e->bwd_part, e->bwd_part_floats, e->c1c2, e->dpart, stream));
     return 0;
 }
 

@@ -7,19 +7,16 @@ namespace rpe {
 // ---------------------------------------------------------------------------------------------
 // BN forward: finalize batch statistics from the conv epilogue's per-tile partial sums
 // ---------------------------------------------------------------------------------------------
-// part: [tiles][2][C] (sum, sum of squares of the fp32 accumulators).  One thread column per channel,
-// 8 row lanes per block; accumulation in double so E[x^2] - mean^2 does not cancel in fp32.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int tiles, int C, double count,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float* running_mean, float* running_var, long long* num_batches,
-                                                         float momentum, float eps, float* scale, float* shift,
-                                                         float* save_mean, float* save_invstd) {
+// part: [tiles][2][C] fp32 partial sums.  Stage 1 (grid = (C/32, NS)): slice s sums tiles s, s+NS, ... in double
+// -> dpart [NS][2][C].  Stage 2 finishes per channel.  Two small launches keep >= 256 blocks busy even for C = 64
+// (one block per 32 channels alone took 1.1 ms on the stem's 25088 tiles).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int tiles, int C, int NS, double* __restrict__ dpart) {
     __shared__ double sh[2][8][32];
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double s = 0.0, q = 0.0;
     if (c < C) {
-        for (int t = rl; t < tiles; t += 8) {
+        for (int t = blockIdx.y + rl * NS; t < tiles; t += 8 * NS) {
             s += (double)part[((long)t * 2 + 0) * C + c];
             q += (double)part[((long)t * 2 + 1) * C + c];
         }
@@ -29,6 +26,20 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     __syncthreads();
     if (rl == 0 && c < C) {
         for (int i = 1; i < 8; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
+        dpart[((long)blockIdx.y * 2 + 0) * C + c] = s;
+        dpart[((long)blockIdx.y * 2 + 1) * C + c] = q;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ dpart, int NS, int C, double count,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* running_mean, float* running_var, long long* num_batches,
+                                                         float momentum, float eps, float* scale, float* shift,
+                                                         float* save_mean, float* save_invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        double s = 0.0, q = 0.0;
+        for (int i = 0; i < NS; ++i) { s += dpart[((long)i * 2 + 0) * C + c]; q += dpart[((long)i * 2 + 1) * C + c]; }
         const double mean = s / count;
         double var = q / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -125,29 +136,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     }
 }
 
-// pass 2: reduce partials -> dgamma, dbeta and the two per-channel coefficients of pass 3
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, double count,
+// pass 2: (reduce_partials_kernel, then) dgamma, dbeta and the two per-channel coefficients of pass 3
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ dpart, int NS, int C, double count,
                                                              float* dgamma, float* dbeta, float* c1, float* c2) {
-    __shared__ double sh[2][8][32];
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
     double s = 0.0, q = 0.0;
-    if (c < C) {
-        for (int t = rl; t < nblocks; t += 8) {
-            s += (double)part[((long)t * 2 + 0) * C + c];
-            q += (double)part[((long)t * 2 + 1) * C + c];
-        }
-    }
-    sh[0][rl][cl] = s;
-    sh[1][rl][cl] = q;
-    __syncthreads();
-    if (rl == 0 && c < C) {
-        for (int i = 1; i < 8; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
-        if (dbeta) dbeta[c] = (float)s;
-        if (dgamma) dgamma[c] = (float)q;
-        c1[c] = (float)(s / count);
-        c2[c] = (float)(q / count);
-    }
+    for (int i = 0; i < NS; ++i) { s += dpart[((long)i * 2 + 0) * C + c]; q += dpart[((long)i * 2 + 1) * C + c]; }
+    if (dbeta) dbeta[c] = (float)s;
+    if (dgamma) dgamma[c] = (float)q;
+    c1[c] = (float)(s / count);
+    c2[c] = (float)(q / count);
 }
 
 // pass 3: dy = gamma*invstd*(dz - c1 - xhat*c2); optionally also emits dz (gradient of the residual branch)
@@ -330,6 +329,23 @@ static inline int ew_grid(long n, int per_block = 256) {
     return (int)g;
 }
 
+// slices for the staged partial reduction: enough blocks to cover the chip, >= 8 tiles per slice
+static inline int reduce_slices(int tiles, int C) {
+    const int colblocks = (C + 31) / 32;
+    int ns = (512 + colblocks - 1) / colblocks;
+    if (ns > tiles / 8) ns = tiles / 8;
+    if (ns > RPE_BN_MAX_SLICES) ns = RPE_BN_MAX_SLICES;
+    if (ns < 1) ns = 1;
+    return ns;
+}
+static int reduce_partials(const float* part, int tiles, int C, double* dpart, int* ns_out, hipStream_t s) {
+    const int ns = reduce_slices(tiles, C);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 31) / 32, ns), dim3(256), 0, s, part, tiles, C, ns, dpart);
+    RPE_CHECK_LAUNCH();
+    *ns_out = ns;
+    return 0;
+}
+
 template <typename T>
 int bn_apply_launch(const void* y, const void* res, void* out, const float* scale, const float* shift, long M, int C, int relu, hipStream_t s) {
     constexpr int CE = Elem<T>::kChunk;
@@ -343,7 +359,7 @@ int bn_apply_launch(const void* y, const void* res, void* out, const float* scal
 template <typename T>
 int bn_bwd_launch(const void* dA, const void* a_out, const void* y, const float* mean, const float* invstd, const float* gamma,
                   float* dgamma, float* dbeta, void* dy, void* dz_out, long M, int C, float* part, long part_floats, float* c1c2,
-                  hipStream_t s) {
+                  double* dpart, hipStream_t s) {
     constexpr int CE = Elem<T>::kChunk;
     if (C % CE) return rpe_set_error(RPE_ERR_SHAPE, "bn_bwd: C must be a multiple of the 16-byte chunk");
     int SW = C < 256 * CE ? C : 256 * CE;
@@ -361,7 +377,9 @@ int bn_bwd_launch(const void* dA, const void* a_out, const void* y, const float*
     RPE_CHECK_LAUNCH();
     float* c1 = c1c2;
     float* c2 = c1c2 + C;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, (const float*)part, (int)nb, C, (double)M, dgamma, dbeta, c1, c2);
+    int ns = 0;
+    if (int e = reduce_partials(part, (int)nb, C, dpart, &ns, s)) return e;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)dpart, ns, C, (double)M, dgamma, dbeta, c1, c2);
     RPE_CHECK_LAUNCH();
     const long n = M * C / CE;
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, s, (const T*)dA, (const T*)a_out, (const T*)y, mean, invstd, gamma,
@@ -378,10 +396,12 @@ extern "C" {
 
 int rpe_bn_finalize(const float* part, int tiles, int C, long count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, long long* num_batches, float momentum, float eps, float* scale, float* shift,
-                    float* save_mean, float* save_invstd, void* stream) {
+                    float* save_mean, float* save_invstd, double* dpart, void* stream) {
     if (tiles <= 0 || C <= 0 || count <= 0) return rpe_set_error(RPE_ERR_SHAPE, "bn_finalize: empty problem");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, tiles, C, (double)count, gamma, beta,
-                       running_mean, running_var, num_batches, momentum, eps, scale, shift, save_mean, save_invstd);
+    int ns = 0;
+    if (int e = reduce_partials(part, tiles, C, dpart, &ns, (hipStream_t)stream)) return e;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)dpart, ns, C, (double)count, gamma,
+                       beta, running_mean, running_var, num_batches, momentum, eps, scale, shift, save_mean, save_invstd);
     RPE_CHECK_LAUNCH();
     return 0;
 }
@@ -403,11 +423,11 @@ int rpe_bn_apply(int dtype, const void* y, const void* residual, void* out, cons
 
 int rpe_bn_backward(int dtype, const void* dA, const void* a_out, const void* y, const float* mean, const float* invstd,
                     const float* gamma, float* dgamma, float* dbeta, void* dy, void* dz_out, long rows, int C, float* part,
-                    long part_floats, float* c1c2, void* stream) {
+                    long part_floats, float* c1c2, double* dpart, void* stream) {
     if (dtype == RPE_F32)
-        return bn_bwd_launch<float>(dA, a_out, y, mean, invstd, gamma, dgamma, dbeta, dy, dz_out, rows, C, part, part_floats, c1c2, (hipStream_t)stream);
+        return bn_bwd_launch<float>(dA, a_out, y, mean, invstd, gamma, dgamma, dbeta, dy, dz_out, rows, C, part, part_floats, c1c2, dpart, (hipStream_t)stream);
     if (dtype == RPE_BF16)
-        return bn_bwd_launch<bf16>(dA, a_out, y, mean, invstd, gamma, dgamma, dbeta, dy, dz_out, rows, C, part, part_floats, c1c2, (hipStream_t)stream);
+        return bn_bwd_launch<bf16>(dA, a_out, y, mean, invstd, gamma, dgamma, dbeta, dy, dz_out, rows, C, part, part_floats, c1c2, dpart, (hipStream_t)stream);
     return rpe_set_error(RPE_ERR_DTYPE, "bn_backward: unsupported dtype");
 }
 

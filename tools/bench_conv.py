@@ -1,0 +1,40 @@
+"""Diagnostic: per-shape throughput of the implicit-GEMM kernels on the 23 conv shapes of ResNet-50 (B images)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from rgb_proprioceptive_pose_estimator_amd import ops
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+dtype = torch.bfloat16 if (len(sys.argv) < 3 or sys.argv[2] == "bf16") else torch.float32
+SHAPES = [  # Cin, Cout, k, s, Hin, count
+    (64, 64, 1, 1, 56, 1), (64, 64, 3, 1, 56, 3), (64, 256, 1, 1, 56, 4), (256, 64, 1, 1, 56, 2), (256, 128, 1, 1, 56, 1),
+    (128, 128, 3, 2, 56, 1), (128, 512, 1, 1, 28, 4), (256, 512, 1, 2, 56, 1), (512, 128, 1, 1, 28, 3), (128, 128, 3, 1, 28, 3),
+    (512, 256, 1, 1, 28, 1), (256, 256, 3, 2, 28, 1), (256, 1024, 1, 1, 14, 6), (512, 1024, 1, 2, 28, 1), (1024, 256, 1, 1, 14, 5),
+    (256, 256, 3, 1, 14, 5), (1024, 512, 1, 1, 14, 1), (512, 512, 3, 2, 14, 1), (512, 2048, 1, 1, 7, 3), (1024, 2048, 1, 2, 14, 1),
+    (2048, 512, 1, 1, 7, 2), (512, 512, 3, 1, 7, 2),
+]
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+print("%-28s %8s | %8s %7s | %8s %7s | %8s %7s" % ("shape (Cin->Cout k s H)", "GFLOP", "fwd ms", "TF/s", "dgrad ms", "TF/s", "wgrad ms", "TF/s"))
+for ci, co, k, s, h, cnt in SHAPES:
+    p = k // 2
+    ho = (h + 2 * p - k) // s + 1
+    x = torch.randn(B, h, h, ci, device="cuda").to(dtype)
+    w = (torch.randn(co, k, k, ci, device="cuda") / (ci * k * k) ** 0.5).to(dtype)
+    wd = w.permute(3, 1, 2, 0).contiguous()
+    dy = torch.randn(B, ho, ho, co, device="cuda").to(dtype)
+    fl = 2.0 * B * ho * ho * co * ci * k * k
+    tf = timeit(lambda: ops.conv2d_fwd(x, w, s, p, want_stats=True))
+    td = timeit(lambda: ops.conv2d_dgrad(dy, wd, (B, h, h, ci), s, p))
+    tw = timeit(lambda: ops.conv2d_wgrad(x, dy, k, s, p))
+    for key, t in (("fwd", tf), ("dgrad", td), ("wgrad", tw)): tot[key] += t * cnt
+    print("%4d->%4d k%d s%d H%-3d x%d %12.1f | %8.3f %7.1f | %8.3f %7.1f | %8.3f %7.1f" % (ci, co, k, s, h, cnt, fl / 1e9, tf, fl / tf / 1e9, td, fl / td / 1e9, tw, fl / tw / 1e9))
+print("weighted totals per step (ms):", {k: round(v, 2) for k, v in tot.items()})
