@@ -1,0 +1,70 @@
+"""End-to-end GPU test of the training loop and the script entry points (tiny synthetic episodes)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_loop_and_checkpoint(tmp_path):
+    from rgb_proprioceptive_pose_estimator_amd import models as M
+    from rgb_proprioceptive_pose_estimator_amd.optim import FusedAdam
+    from rgb_proprioceptive_pose_estimator_amd.util.data_utils import SyntheticEpisodeDataset
+    from rgb_proprioceptive_pose_estimator_amd.util.learn_utils import train
+
+    torch.manual_seed(0)
+    model = M.TemporallyDependentObjectStateEstimator("hammer", 32, 50, 32, 2, 0.1, False, (9,), True, False, False, compute_dtype=torch.bfloat16)
+    crit = lambda: M.PoseDistanceLoss("combined", 1.0, 0.5, 1e-4, "pose")
+    criterion = {"x0_loss": crit(), "x1_loss": crit(), "obj_loss": crit(), "val_loss": M.PoseDistanceLoss(mode="val")}
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    ds = SyntheticEpisodeDataset(horizon=4, use_depth=True, obj_name="hammer", is_two_arm=False, seed=5)
+    path = str(tmp_path / "best.pth")
+    before = {k: v.detach().clone().cpu() for k, v in model.state_dict().items()}
+    model, best = train(model, ds, criterion, opt, num_epochs=2, num_train_episodes_per_epoch=3, num_val_episodes_per_epoch=2,
+                        params={"camera_name": "frontview", "noise_scale": 0.001}, device="cuda:0", save_path=path, logging=False)
+    assert best < float("inf") and os.path.exists(path)
+    sd = torch.load(path, map_location="cpu")
+    assert list(sd.keys()) == list(before.keys())
+    moved = sum(float((sd[k].float() - before[k].float()).abs().max()) > 0 for k in sd if sd[k].dtype.is_floating_point)
+    assert moved > 100  # parameters and BN statistics were updated
+    # a reference-format checkpoint loads into a fresh model and reproduces the eval-mode output
+    m2 = M.TemporallyDependentObjectStateEstimator("hammer", 32, 50, 32, 2, 0.1, False, (9,), True, False, False, compute_dtype=torch.bfloat16)
+    m2.load_state_dict(sd)
+    m2.cuda().eval()
+    model.eval()
+    img, depth, x0bar, _, _, _ = ds.chunk(0, 2)
+    with torch.no_grad():
+        a, b = model(img, depth, x0bar), m2(img, depth, x0bar)
+    assert torch.allclose(a, b, rtol=1e-3, atol=1e-3)
+
+
+def test_torch_adam_drop_in_matches_fused():
+    """torch.optim.Adam (what the reference constructs) works on the arena's .grad views and agrees with FusedAdam."""
+    from rgb_proprioceptive_pose_estimator_amd import models as M
+    from rgb_proprioceptive_pose_estimator_amd.optim import FusedAdam
+    from rgb_proprioceptive_pose_estimator_amd.util.data_utils import synthetic_batch
+
+    res = []
+    for cls in (FusedAdam, torch.optim.Adam):
+        torch.manual_seed(1)
+        model = M.NaiveObjectStateEstimator("cube", [32], 50, 32, False, (9,), False, False, False, compute_dtype=torch.float32).cuda().train()
+        opt = cls(model.parameters(), lr=1e-3)
+        crit = M.PoseDistanceLoss("l2", 1.0, 0.5, 1e-4, "pose")
+        b = synthetic_batch((4,), 3)
+        for _ in range(2):
+            opt.zero_grad()
+            crit(model(b["img"], None, b["x0bar"]), b["obj"]).backward()
+            opt.step()
+        res.append(torch.cat([p.detach().flatten() for p in model.parameters()]).cpu())
+    # same gradients up to fp32 atomic-order noise; elements at the noise floor may flip sign under Adam
+    assert (res[0] - res[1]).abs().max() < 4.5e-3
+    assert ((res[0] - res[1]).abs() > 1e-5).float().mean() < 0.05
+
+
+def test_train_script_two_arm_smoke():
+    from rgb_proprioceptive_pose_estimator_amd.scripts.train_model import main
+    model, best = main(["--model", "td", "--horizon", "4", "--sequence_length", "2", "--latent_dim", "32", "--hidden_dim", "32",
+                        "--n_train_episodes_per_epoch", "2", "--n_val_episodes_per_epoch", "2", "--n_epochs", "1", "--env", "TwoArmHandoff",
+                        "--distance_metric", "combined", "--no_save"])
+    assert best < float("inf") and model.requires_sequence
