@@ -59,7 +59,7 @@ def test_torch_adam_drop_in_matches_fused():
         res.append(torch.cat([p.detach().flatten() for p in model.parameters()]).cpu())
     # same gradients up to fp32 atomic-order noise; elements at the noise floor may flip sign under Adam
     assert (res[0] - res[1]).abs().max() < 4.5e-3
-    assert ((res[0] - res[1]).abs() > 1e-5).float().mean() < 0.05
+    assert ((res[0] - res[1]).abs() > 2e-4).float().mean() < 0.05
 
 
 def test_train_script_two_arm_smoke():
