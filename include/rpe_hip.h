@@ -67,6 +67,18 @@ long rpe_conv_stats_tiles(long rows);
 int rpe_conv2d_fwd(const rpe_conv_desc* d, int dtype, const void* x, const void* w_krsc, void* y, float* stats_part, void* stream);
 /* dx[B][H][W][in_c] = conv_transpose(dy, w) (+ addend);  w_crsk = [in_c][kh][kw][out_c]. */
 int rpe_conv2d_dgrad(const rpe_conv_desc* d, int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, void* stream);
+/* Data gradient with the BatchNorm-backward reduction of the PRODUCING layer fused into the epilogue:
+ * dz[B][H][W][in_c] = (conv_transpose(dy, w) + addend) * [ReLU mask of that layer's output], and per-128-row-tile partial
+ * sums (sum dz, sum dz*xhat) -> bn->stats_part [tiles][2][in_c], consumed by rpe_bn_backward_from_dz.
+ * mask: a_out != NULL: a_out > 0;  else scale/shift != NULL: y*scale+shift > 0 (BN+ReLU without residual);  else none. */
+typedef struct {
+    const void* y;       /* raw conv output the BN normalised, same shape as dz */
+    const void* a_out;   /* BN(+residual)+ReLU output, or NULL */
+    const float *mean, *invstd, *scale, *shift;
+    float* stats_part;
+} rpe_bn_bwd_epilogue;
+int rpe_conv2d_dgrad_bn(const rpe_conv_desc* d, int dtype, const void* dy, const void* w_crsk, void* dz, const void* addend,
+                        const rpe_bn_bwd_epilogue* bn, void* stream);
 /* dw_krsc[out_c][kh][kw][in_c] (fp32) += x (*) dy.  Atomic accumulation: zero it first. */
 int rpe_conv2d_wgrad(const rpe_conv_desc* d, int dtype, const void* x, const void* dy, float* dw_krsc, void* stream);
 
@@ -103,6 +115,12 @@ int rpe_bn_apply(int dtype, const void* y, const void* residual, void* out, cons
 int rpe_bn_backward(int dtype, const void* dA, const void* a_out, const void* y, const float* mean, const float* invstd,
                     const float* gamma, float* dgamma, float* dbeta, void* dy, void* dz_out, long rows, int C, float* part,
                     long part_floats, float* c1c2, double* dpart, void* stream);
+
+/* second half of the fused form: partial sums -> dgamma, dbeta; dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)).
+ * dy may alias dz. */
+int rpe_bn_backward_from_dz(int dtype, const void* dz, const void* y, const float* mean, const float* invstd, const float* gamma,
+                            const float* stats_part, int tiles, float* dgamma, float* dbeta, void* dy, long rows, int C, float* c1c2,
+                            double* dpart, void* stream);
 
 /* ------------------------------------------------------------------ pooling */
 /* replaces: nn.MaxPool2d(3, 2, 1) of the ResNet stem; idx keeps the winning tap. */

@@ -23,6 +23,10 @@ class RpeError(RuntimeError):
     """A librpe_hip.so entry point returned a non-zero status."""
 
 
+class BnBwdEpilogue(Structure):
+    _fields_ = [(n, c_void_p) for n in ("y", "a_out", "mean", "invstd", "scale", "shift", "stats_part")]
+
+
 class ConvDesc(Structure):
     _fields_ = [(n, c_int) for n in ("batch", "in_h", "in_w", "in_c", "out_c", "kh", "kw", "stride", "pad")]
 
@@ -38,6 +42,8 @@ _SPEC = {
     "rpe_conv_stats_tiles": (L, [L]),
     "rpe_conv2d_fwd": (I, [PD, I, P, P, P, P, P]),
     "rpe_conv2d_dgrad": (I, [PD, I, P, P, P, P, P]),
+    "rpe_conv2d_dgrad_bn": (I, [PD, I, P, P, P, P, POINTER(BnBwdEpilogue), P]),
+    "rpe_bn_backward_from_dz": (I, [I, P, P, P, P, P, P, I, P, P, P, L, I, P, P, P]),
     "rpe_conv2d_wgrad": (I, [PD, I, P, P, P, P]),
     "rpe_stem_conv_fwd": (I, [I, P, P, P, P, I, I, I, P]),
     "rpe_stem_conv_wgrad": (I, [I, P, P, P, I, I, I, P]),

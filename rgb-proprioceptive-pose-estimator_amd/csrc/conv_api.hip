@@ -56,7 +56,8 @@ static int conv_fwd_t(const rpe_conv_desc* d, const void* x, const void* w, void
 }
 
 template <typename T>
-static int conv_dgrad_t(const rpe_conv_desc* d, const void* dy, const void* w_crsk, void* dx, const void* addend, hipStream_t s) {
+static int conv_dgrad_t(const rpe_conv_desc* d, const void* dy, const void* w_crsk, void* dx, const void* addend, const rpe_bn_bwd_epilogue* bn,
+                        hipStream_t s) {
     const int Ho = out_dim(d->in_h, d->kh, d->stride, d->pad), Wo = out_dim(d->in_w, d->kw, d->stride, d->pad);
     NTArgs<T> a;
     memset(&a, 0, sizeof(a));
@@ -64,6 +65,13 @@ static int conv_dgrad_t(const rpe_conv_desc* d, const void* dy, const void* w_cr
     a.M = d->batch * d->in_h * d->in_w; a.N = d->in_c; a.K = d->kh * d->kw * d->out_c;
     a.lda = d->out_c; a.ldb = a.K; a.ldc = d->in_c;
     a.addend = (const T*)addend; a.ld_add = d->in_c;
+    if (bn) {
+        if (!bn->y || !bn->mean || !bn->invstd || !bn->stats_part) return rpe_set_error(RPE_ERR_SHAPE, "conv2d_dgrad_bn: y, mean, invstd, stats_part are required");
+        a.bn_mode = bn->a_out ? 1 : (bn->scale && bn->shift ? 2 : 3);
+        a.bn_y = (const T*)bn->y; a.bn_a = (const T*)bn->a_out;
+        a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bn_scale = bn->scale; a.bn_shift = bn->shift;
+        a.stats_part = bn->stats_part;
+    }
     if (is_dense(d)) return launch_nt<T>(a, MODE_DENSE, s);
     Gather& g = a.g;
     g.H = Ho; g.W = Wo; g.C = d->out_c; g.Ho = d->in_h; g.Wo = d->in_w; g.R = d->kh; g.S = d->kw;
@@ -166,7 +174,14 @@ int rpe_conv2d_fwd(const rpe_conv_desc* d, int dtype, const void* x, const void*
 
 int rpe_conv2d_dgrad(const rpe_conv_desc* d, int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, void* stream) {
     if (int e = check_desc(d)) return e;
-    DISPATCH(dtype, conv_dgrad_t, d, dy, w_crsk, dx, addend, (hipStream_t)stream);
+    DISPATCH(dtype, conv_dgrad_t, d, dy, w_crsk, dx, addend, nullptr, (hipStream_t)stream);
+}
+
+int rpe_conv2d_dgrad_bn(const rpe_conv_desc* d, int dtype, const void* dy, const void* w_crsk, void* dz, const void* addend,
+                        const rpe_bn_bwd_epilogue* bn, void* stream) {
+    if (int e = check_desc(d)) return e;
+    if (!bn) return rpe_set_error(RPE_ERR_SHAPE, "conv2d_dgrad_bn: null epilogue descriptor");
+    DISPATCH(dtype, conv_dgrad_t, d, dy, w_crsk, dz, addend, bn, (hipStream_t)stream);
 }
 
 int rpe_conv2d_wgrad(const rpe_conv_desc* d, int dtype, const void* x, const void* dy, float* dw_krsc, void* stream) {

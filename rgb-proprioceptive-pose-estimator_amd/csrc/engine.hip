@@ -6,6 +6,7 @@
 //   stage -> conv1 7x7/2 -> bn1 -> relu [= hooked early feature] -> maxpool 3x3/2
 //   -> layer1..4 = [3,4,6,3] bottlenecks (1x1 -> 3x3 (stride) -> 1x1 x4, downsample on block 0)
 //   -> global avgpool -> fc(2048 -> latent)
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -85,6 +86,13 @@ struct rpe_resnet50 {
     std::vector<Span> spans;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_next = 0;
+    // weight-gradient GEMMs run on a second stream, overlapping the data-gradient / BN chain (they only feed Adam)
+    hipStream_t side = nullptr;
+    bool overlap = true;
+    std::vector<hipEvent_t> sync_pool;
+    size_t sync_next = 0;
+    const void* pend_buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t pend_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     double flops[RPE_PROF_NUM] = {0};   // algorithmic FLOPs per pass, per category
     double bytes[RPE_PROF_NUM] = {0};   // algorithmic bytes per pass, per category
 };
@@ -211,7 +219,7 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
         e->flops[RPE_PROF_CONV_WGRAD] += mnk; e->bytes[RPE_PROF_CONV_WGRAD] += in_b + out_b;
         if (&c != &e->convs[0]) { e->flops[RPE_PROF_CONV_DGRAD] += mnk; e->bytes[RPE_PROF_CONV_DGRAD] += in_b + out_b; }
         e->bytes[RPE_PROF_BN_FWD] += 2 * out_b;   // read y, write a (+ residual read on block outputs, not counted)
-        e->bytes[RPE_PROF_BN_BWD] += 6 * out_b;   // reduce: dA, a, y ; apply: dA, a, y -> dy  (minimum two-pass form is 5)
+        e->bytes[RPE_PROF_BN_BWD] += 3 * out_b;   // fused form: dz, y -> dy (the reduction rides on the dgrad epilogue)
     }
     *out = e;
     return 0;
@@ -243,6 +251,8 @@ extern "C" int rpe_resnet50_profile_read(rpe_resnet50_t* e, float* ms, int* laun
 extern "C" void rpe_resnet50_destroy(rpe_resnet50_t* e) {
     if (!e) return;
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    for (auto ev : e->sync_pool) (void)hipEventDestroy(ev);
+    if (e->side) (void)hipStreamDestroy(e->side);
     delete e;
 }
 extern "C" long rpe_resnet50_workspace_bytes(const rpe_resnet50_t* e) { return e ? e->ws_bytes : 0; }
@@ -353,11 +363,73 @@ static int bn_back(rpe_resnet50* e, ConvL& c, const void* dA, int relu, void* dy
     return 0;
 }
 
+// data gradient of conv `c` with the BN-backward reduction of layer `bnl` (the layer producing c's input) fused in.
+// mask_mode 1: ReLU mask from bnl.a (residual block output); 2: mask recomputed from bnl.y, scale, shift.
+static int dgrad_fused(rpe_resnet50* e, ConvL& c, const void* dy, void* dz, const void* addend, ConvL* bnl, int mask_mode, void* stream) {
+    rpe_bn_bwd_epilogue ep;
+    ep.y = bnl->y;
+    ep.a_out = mask_mode == 1 ? bnl->a : nullptr;
+    ep.mean = bnl->mean; ep.invstd = bnl->invstd;
+    ep.scale = mask_mode == 2 ? bnl->scale : nullptr;
+    ep.shift = mask_mode == 2 ? bnl->shift : nullptr;
+    ep.stats_part = e->stats_part;
+    PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad_bn(&c.d, e->dtype, dy, c.wd, dz, addend, &ep, stream));
+    return 0;
+}
+
+// second half of the fused BN backward of layer c: partials (left in stats_part by dgrad_fused) -> dgamma, dbeta, dy
+static int bn_from_dz(rpe_resnet50* e, ConvL& c, const void* dz, void* dy, void* stream) {
+    PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_backward_from_dz(e->dtype, dz, c.y, c.mean, c.invstd, e->params[c.p_g], e->stats_part,
+                                                              (int)rpe_conv_stats_tiles(c.rows), e->grads[c.p_g], e->grads[c.p_b], dy, c.rows,
+                                                              c.d.out_c, e->c1c2, e->dpart, stream));
+    return 0;
+}
+
+#define HIPTRY(x) do { hipError_t he__ = (x); if (he__ != hipSuccess) return rpe_set_error_hip(he__, __FILE__, __LINE__); } while (0)
+
+static hipEvent_t sync_event(rpe_resnet50* e) {
+    if (e->sync_next == e->sync_pool.size()) {
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+        e->sync_pool.push_back(ev);
+    }
+    return e->sync_pool[e->sync_next++];
+}
+
+// the main stream is about to WRITE gradient buffer `buf`: wait for a side-stream weight-gradient still reading it
+static int writable(rpe_resnet50* e, const void* buf, void* stream) {
+    for (int i = 0; i < 4; ++i)
+        if (e->pend_buf[i] == buf && e->pend_ev[i]) {
+            HIPTRY(hipStreamWaitEvent((hipStream_t)stream, e->pend_ev[i], 0));
+            e->pend_ev[i] = nullptr;
+            e->pend_buf[i] = nullptr;
+        }
+    return 0;
+}
+
+// dW = x (*) dy.  Runs on the side stream once `dy` is complete on the main stream; `dy_buf` stays reserved until it is done.
 static int wgrad(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, void* stream) {
     float* dw = e->grads[c.p_w];
-    hipError_t he = hipMemsetAsync(dw, 0, (size_t)e->pnumel[c.p_w] * 4, (hipStream_t)stream);
-    if (he != hipSuccess) return rpe_set_error_hip(he, __FILE__, __LINE__);
-    PROF(e, RPE_PROF_CONV_WGRAD, stream, rpe_conv2d_wgrad(&c.d, e->dtype, x, dy, dw, stream));
+    hipStream_t run = (hipStream_t)stream;
+    if (e->overlap && e->side) {
+        hipEvent_t ready = sync_event(e);
+        if (!ready) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
+        HIPTRY(hipEventRecord(ready, (hipStream_t)stream));
+        HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
+        run = e->side;
+    }
+    HIPTRY(hipMemsetAsync(dw, 0, (size_t)e->pnumel[c.p_w] * 4, run));
+    PROF(e, RPE_PROF_CONV_WGRAD, run, rpe_conv2d_wgrad(&c.d, e->dtype, x, dy, dw, run));
+    if (run != (hipStream_t)stream) {
+        hipEvent_t done = sync_event(e);
+        if (!done) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
+        HIPTRY(hipEventRecord(done, run));
+        int slot = -1;
+        for (int i = 0; i < 4; ++i) if (e->pend_buf[i] == dy || (slot < 0 && !e->pend_ev[i])) { slot = i; if (e->pend_buf[i] == dy) break; }
+        if (slot < 0) slot = 0;
+        e->pend_buf[slot] = dy;
+        e->pend_ev[slot] = done;
+    }
     return 0;
 }
 
@@ -368,6 +440,12 @@ extern "C" int rpe_resnet50_backward(rpe_resnet50_t* e, const float* d_features,
     for (int i = 0; i < np; ++i)
         if (!e->grads[i]) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward: gradient tensors were not bound");
     hipStream_t s = (hipStream_t)stream;
+    if (e->overlap && !e->side) {
+        if (getenv("RPE_NO_OVERLAP")) e->overlap = false;
+        else HIPTRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    }
+    e->sync_next = 0;
+    for (int i = 0; i < 4; ++i) { e->pend_buf[i] = nullptr; e->pend_ev[i] = nullptr; }
     // fc
     float* dWfc = e->grads[np - 2];
     if (hipError_t he = hipMemsetAsync(dWfc, 0, (size_t)e->latent * 2048 * 4, s)) return rpe_set_error_hip(he, __FILE__, __LINE__);
@@ -380,40 +458,64 @@ extern "C" int rpe_resnet50_backward(rpe_resnet50_t* e, const float* d_features,
     TRY(rpe_linear_fwd(RPE_F32, d_features, (int)ld_d_features, e->fc_wt, e->latent_pad, nullptr, e->d_pooled, 2048, e->B, 2048, e->latent_pad, 0,
                        nullptr, 0, stream));
     ConvL& last = e->convs[e->blocks.back().c3];
-    void *g0 = e->G[0], *g1 = e->G[1], *g2 = e->G[2], *g3 = e->G[3];
-    TRY(rpe_avgpool_bwd(e->dtype, e->d_pooled, g0, e->B, last.Ho * last.Wo, 2048, stream));
-    // g0 holds the gradient wrt the current block's output
+    void *gA = e->G[0], *gB = e->G[1], *gC = e->G[2], *gD = e->G[3];
+    TRY(rpe_avgpool_bwd(e->dtype, e->d_pooled, gA, e->B, last.Ho * last.Wo, 2048, stream));
+    // Per block, entering with gA = dz3 (ReLU-masked gradient at the block output; for the last block: the raw dA).
+    // Every data-gradient GEMM also applies the ReLU mask of the layer it feeds and emits that layer's BN-backward
+    // partial sums (rpe_conv2d_dgrad_bn), so each BN costs one more pass (dz, y -> dy) instead of two full passes.
     for (int bi = (int)e->blocks.size() - 1; bi >= 0; --bi) {
         Block& b = e->blocks[bi];
         ConvL &c1 = e->convs[b.c1], &c2 = e->convs[b.c2], &c3 = e->convs[b.c3];
         const void* x_in = bi == 0 ? (const void*)e->pool : (const void*)e->convs[e->blocks[bi - 1].c3].a;
-        // bn3 (+ residual split): dy3 in place in g0, dz (identity-branch gradient) -> g2
-        TRY(bn_back(e, c3, g0, 1, g0, g2, stream));
-        TRY(wgrad(e, c3, c2.a, g0, stream));
-        PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&c3.d, e->dtype, g0, c3.wd, g1, nullptr, stream));  // dA2 -> g1
-        TRY(bn_back(e, c2, g1, 1, g1, nullptr, stream));
-        TRY(wgrad(e, c2, c1.a, g1, stream));
-        PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&c2.d, e->dtype, g1, c2.wd, g0, nullptr, stream));  // dA1 -> g0
-        TRY(bn_back(e, c1, g0, 1, g0, nullptr, stream));
-        TRY(wgrad(e, c1, x_in, g0, stream));
-        const void* shortcut = g2;
+        if (bi == (int)e->blocks.size() - 1) {
+            TRY(writable(e, gB, stream));
+            TRY(bn_back(e, c3, gA, 1, gB, gA, stream));  // unfused: dy3 -> gB, dz3 -> gA (in place)
+        } else {
+            TRY(writable(e, gB, stream));
+            TRY(bn_from_dz(e, c3, gA, gB, stream));       // dy3 -> gB (gA keeps dz3 = shortcut gradient)
+        }
+        TRY(wgrad(e, c3, c2.a, gB, stream));
+        TRY(writable(e, gC, stream));
+        TRY(dgrad_fused(e, c3, gB, gC, nullptr, &c2, 2, stream));   // dz2 -> gC
+        TRY(bn_from_dz(e, c2, gC, gC, stream));
+        TRY(wgrad(e, c2, c1.a, gC, stream));
+        TRY(writable(e, gB, stream));
+        TRY(dgrad_fused(e, c2, gC, gB, nullptr, &c1, 2, stream));   // dz1 -> gB
+        TRY(bn_from_dz(e, c1, gB, gB, stream));
+        TRY(wgrad(e, c1, x_in, gB, stream));
+        const void* shortcut = gA;
         if (b.cd >= 0) {
             ConvL& cd = e->convs[b.cd];
-            TRY(bn_back(e, cd, g2, 0, g2, nullptr, stream));
-            TRY(wgrad(e, cd, x_in, g2, stream));
-            PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&cd.d, e->dtype, g2, cd.wd, g1, nullptr, stream));  // -> g1
-            shortcut = g1;
+            TRY(bn_back(e, cd, gA, 0, gA, nullptr, stream));          // no ReLU on the projection shortcut
+            TRY(wgrad(e, cd, x_in, gA, stream));
+            TRY(writable(e, gC, stream));
+            PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&cd.d, e->dtype, gA, cd.wd, gC, nullptr, stream));
+            shortcut = gC;
         }
-        PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&c1.d, e->dtype, g0, c1.wd, g3, shortcut, stream));  // dX_in -> g3
-        void* t = g0; g0 = g3; g3 = t;
+        TRY(writable(e, gD, stream));
+        if (bi > 0) {
+            TRY(dgrad_fused(e, c1, gB, gD, shortcut, &e->convs[e->blocks[bi - 1].c3], 1, stream));  // dz3 of the previous block
+        } else {
+            PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&c1.d, e->dtype, gB, c1.wd, gD, shortcut, stream));
+        }
+        void* t = gA; gA = gD; gD = t;
     }
+    void *g0 = gA, *g1 = gB;
     // stem: g0 = gradient wrt maxpool output
     ConvL& st = e->convs[0];
+    TRY(writable(e, g1, stream));
     PROF(e, RPE_PROF_OTHER, stream, rpe_maxpool3x3s2_bwd(e->dtype, g0, e->pool_idx, use_d_early ? e->early_grad : nullptr, g1, e->B, st.Ho, st.Wo, 64, stream));
     TRY(bn_back(e, st, g1, 1, g1, nullptr, stream));
     if (hipError_t he = hipMemsetAsync(e->stem_dw, 0, 64 * 256 * 4, s)) return rpe_set_error_hip(he, __FILE__, __LINE__);
     PROF(e, RPE_PROF_CONV_WGRAD, stream, rpe_stem_conv_wgrad(e->dtype, e->x4, g1, e->stem_dw, e->B, e->H, e->W, stream));
     TRY(rpe_unpack_stem_grad(e->stem_dw, e->grads[st.p_w], stream));
+    // join: everything the side stream produced (weight gradients) is complete before the caller's next launch
+    if (e->overlap && e->side) {
+        hipEvent_t done = sync_event(e);
+        if (!done) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
+        HIPTRY(hipEventRecord(done, e->side));
+        HIPTRY(hipStreamWaitEvent(s, done, 0));
+    }
     return 0;
 }
 

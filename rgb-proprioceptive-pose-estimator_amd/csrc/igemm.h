@@ -34,7 +34,14 @@ template <typename T> struct NTArgs {
     const T* addend;     // [M][ld_add] or null : C = acc (+bias) + addend
     int ld_add;
     int relu;
-    float* stats_part;   // [tiles_m][2][N] per-tile column sum / sum of squares of acc, or null
+    float* stats_part;   // [tiles_m][2][N] per-tile column partial sums, or null:
+                         //   bn_mode == 0: (sum acc, sum acc^2)  -> forward batch statistics
+                         //   bn_mode != 0: (sum dz, sum dz*xhat) -> fused BatchNorm-backward reduction
+    // fused BN backward on the data-gradient output: C = dz = (acc + addend) * [relu mask]
+    int bn_mode;         // 0 off; 1 mask = bn_a > 0; 2 mask = bn_y*bn_scale + bn_shift > 0; 3 no mask
+    const T* bn_y;       // raw conv output the BN normalised, [M][ldc]
+    const T* bn_a;       // BN(+residual)+ReLU output, [M][ldc] (mode 1)
+    const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
     int tiles_m, tiles_n;
 };
 

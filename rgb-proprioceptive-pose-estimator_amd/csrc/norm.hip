@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
         if (res) chunk_to_f<T>(*(const u32x4*)(res + i * CE), r);
 #pragma unroll
         for (int e = 0; e < CE; ++e) {
-            float t = v[e] * scale[c0 + e] + shift[c0 + e];
+            float t = fmaf(v[e], scale[c0 + e], shift[c0 + e]);  // same expression as the fused dgrad epilogue's mask
             if (res) t += r[e];
             v[e] = relu ? fmaxf(t, 0.f) : t;
         }
@@ -174,6 +174,35 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         }
         *(u32x4*)(dy + i * CE) = f_to_chunk<T>(o);
         if (dz_out) *(u32x4*)(dz_out + i * CE) = f_to_chunk<T>(d);
+    }
+}
+
+// pass 3 when dz is already materialised (fused data-gradient epilogue): dy = gamma*invstd*(dz - c1 - xhat*c2)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_dz_kernel(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ c1, const float* __restrict__ c2, T* __restrict__ dy,
+                                                             long nchunks, int C) {
+    constexpr int CE = Elem<T>::kChunk;
+    const int cpr = C / CE;
+    // gridDim.x * 256 is a multiple of cpr (launcher), so a thread's channel chunk is fixed: coefficients live in registers
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c0 = (int)(i0 % cpr) * CE;
+    float k0[CE], k1[CE], k2[CE];  // dy = k0*dz + k1 + k2*y
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+        const float gi = gamma[c0 + e] * invstd[c0 + e];
+        k0[e] = gi;
+        k2[e] = -gi * invstd[c0 + e] * c2[c0 + e];
+        k1[e] = -gi * c1[c0 + e] - k2[e] * mean[c0 + e];
+    }
+    for (long i = i0; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+        float d[CE], yy[CE];
+        chunk_to_f<T>(*(const u32x4*)(dz + i * CE), d);
+        chunk_to_f<T>(*(const u32x4*)(y + i * CE), yy);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) d[e] = fmaf(k0[e], d[e], fmaf(k2[e], yy[e], k1[e]));
+        *(u32x4*)(dy + i * CE) = f_to_chunk<T>(d);
     }
 }
 
@@ -388,6 +417,30 @@ int bn_bwd_launch(const void* dA, const void* a_out, const void* y, const float*
     return 0;
 }
 
+template <typename T>
+int bn_bwd_from_dz_launch(const void* dz, const void* y, const float* mean, const float* invstd, const float* gamma, const float* stats_part,
+                          int tiles, float* dgamma, float* dbeta, void* dy, long M, int C, float* c1c2, double* dpart, hipStream_t s) {
+    constexpr int CE = Elem<T>::kChunk;
+    if (C % CE) return rpe_set_error(RPE_ERR_SHAPE, "bn_bwd_from_dz: C must be a multiple of the 16-byte chunk");
+    const int cpr = C / CE;
+    int ns = 0;
+    if (int e = reduce_partials(stats_part, tiles, C, dpart, &ns, s)) return e;
+    float* c1 = c1c2;
+    float* c2 = c1c2 + C;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)dpart, ns, C, (double)M, dgamma, dbeta, c1, c2);
+    RPE_CHECK_LAUNCH();
+    const long n = M * C / CE;
+    // grid * 256 must be a multiple of chunks-per-row (cpr is a power of two <= 512 for every ResNet width)
+    long g = ew_grid(n);
+    const long mult = cpr > 256 ? cpr / 256 : 1;
+    g = (g + mult - 1) / mult * mult;
+    if ((g * 256) % cpr) return rpe_set_error(RPE_ERR_SHAPE, "bn_bwd_from_dz: C/chunk must be a power of two");
+    hipLaunchKernelGGL((bn_bwd_apply_dz_kernel<T>), dim3((unsigned)g), dim3(256), 0, s, (const T*)dz, (const T*)y, mean, invstd, gamma,
+                       (const float*)c1, (const float*)c2, (T*)dy, n, C);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace rpe
 
 using namespace rpe;
@@ -429,6 +482,16 @@ int rpe_bn_backward(int dtype, const void* dA, const void* a_out, const void* y,
     if (dtype == RPE_BF16)
         return bn_bwd_launch<bf16>(dA, a_out, y, mean, invstd, gamma, dgamma, dbeta, dy, dz_out, rows, C, part, part_floats, c1c2, dpart, (hipStream_t)stream);
     return rpe_set_error(RPE_ERR_DTYPE, "bn_backward: unsupported dtype");
+}
+
+int rpe_bn_backward_from_dz(int dtype, const void* dz, const void* y, const float* mean, const float* invstd, const float* gamma,
+                            const float* stats_part, int tiles, float* dgamma, float* dbeta, void* dy, long rows, int C, float* c1c2,
+                            double* dpart, void* stream) {
+    if (dtype == RPE_F32)
+        return bn_bwd_from_dz_launch<float>(dz, y, mean, invstd, gamma, stats_part, tiles, dgamma, dbeta, dy, rows, C, c1c2, dpart, (hipStream_t)stream);
+    if (dtype == RPE_BF16)
+        return bn_bwd_from_dz_launch<bf16>(dz, y, mean, invstd, gamma, stats_part, tiles, dgamma, dbeta, dy, rows, C, c1c2, dpart, (hipStream_t)stream);
+    return rpe_set_error(RPE_ERR_DTYPE, "bn_backward_from_dz: unsupported dtype");
 }
 
 int rpe_maxpool3x3s2_fwd(int dtype, const void* x, void* out, unsigned char* idx, int B, int H, int W, int C, void* stream) {

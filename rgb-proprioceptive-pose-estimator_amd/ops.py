@@ -9,7 +9,7 @@ import ctypes
 
 import torch
 
-from ._lib import RPE_BF16, RPE_F32, ConvDesc, lib
+from ._lib import RPE_BF16, RPE_F32, BnBwdEpilogue, ConvDesc, lib
 
 _DT = {torch.float32: RPE_F32, torch.bfloat16: RPE_BF16}
 
@@ -78,6 +78,33 @@ def conv2d_dgrad(dy, w_crsk, x_shape, stride, pad, addend=None):
     dx = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device)
     lib.rpe_conv2d_dgrad(ctypes.byref(d), dtype_code(dy), _p(dy), _p(w_crsk), _p(dx), _p(addend), _stream())
     return dx
+
+
+def conv2d_dgrad_bn(dy, w_crsk, x_shape, stride, pad, y, mean, invstd, a_out=None, scale=None, shift=None, addend=None):
+    """Data gradient with the producing layer's ReLU mask and BN-backward partial sums fused into the epilogue.
+    Returns (dz [B,H,W,Ci], stats partials [tiles,2,Ci])."""
+    _chk(dy, "dy"), _chk(w_crsk, "w"), _chk(y, "y")
+    ci, k, co = w_crsk.shape[0], w_crsk.shape[1], w_crsk.shape[3]
+    d = conv_desc(x_shape, co, k, stride, pad)
+    dz = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device)
+    rows = x_shape[0] * x_shape[1] * x_shape[2]
+    st = torch.empty((stats_tiles(rows), 2, ci), dtype=torch.float32, device=dy.device)
+    ep = BnBwdEpilogue(*(None if t is None else t.data_ptr() for t in (y, a_out, mean, invstd, scale, shift, st)))
+    lib.rpe_conv2d_dgrad_bn(ctypes.byref(d), dtype_code(dy), _p(dy), _p(w_crsk), _p(dz), _p(addend), ctypes.byref(ep), _stream())
+    return dz, st
+
+
+def bn_backward_from_dz(dz, y, mean, invstd, gamma, stats_part):
+    c = y.shape[-1]
+    dev = y.device
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    dy = torch.empty_like(y)
+    c1c2 = torch.empty(2 * c, dtype=torch.float32, device=dev)
+    dpart = torch.empty(256 * 2 * c, dtype=torch.float64, device=dev)
+    lib.rpe_bn_backward_from_dz(dtype_code(y), _p(dz), _p(y), _p(mean), _p(invstd), _p(gamma), _p(stats_part), stats_part.shape[0], _p(dgamma),
+                                _p(dbeta), _p(dy), y.numel() // c, c, _p(c1c2), _p(dpart), _stream())
+    return dy, dgamma, dbeta
 
 
 def conv2d_wgrad(x, dy, k, stride, pad):

@@ -45,7 +45,7 @@ def nchw(t):
 
 # ------------------------------------------------------------------ dense GEMM (MFMA layout check)
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("m,n,k", [(200, 7, 36), (128, 128, 64), (300, 130, 200), (64, 70, 8), (1, 512, 2048)])
+@pytest.mark.parametrize("m,n,k", [(200, 7, 36), (128, 128, 64), (300, 130, 200), (64, 70, 8), (1, 512, 2048), (5000, 130, 1032), (4100, 40, 1024)])
 def test_linear_fwd_layout(dtype, m, n, k):
     g = torch.Generator().manual_seed(m * 1000 + n)
     kp = (k + 7) // 8 * 8
@@ -83,6 +83,10 @@ CONVS = [  # (B, H, Cin, Cout, k, stride, pad)
     (2, 14, 256, 512, 1, 2, 0),
     (1, 7, 512, 128, 3, 1, 1),
     (2, 10, 64, 128, 3, 2, 1),  # Ho*Wo not a multiple of anything convenient
+    # M >= 4096 rows and K >= 1024: the 256-row / 8-wave tile configuration
+    (8, 24, 128, 128, 3, 1, 1),
+    (8, 24, 1024, 64, 1, 1, 0),
+    (6, 30, 128, 256, 3, 2, 1),
 ]
 
 
@@ -134,6 +138,46 @@ def test_conv_wgrad(dtype, cfg):
     (ref,) = torch.autograd.grad(y, w, dy)
     dw = ops.conv2d_wgrad(nhwc(x).to(dtype).to(DEV), nhwc(dy).to(dtype).to(DEV), k, s, p)
     assert rel_err(dw.permute(0, 3, 1, 2), ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mask_mode", [1, 2])
+@pytest.mark.parametrize("cfg", [(2, 14, 64, 64, 3, 1, 1), (2, 14, 256, 512, 1, 2, 0), (3, 8, 128, 256, 1, 1, 0), (8, 24, 128, 128, 3, 1, 1),
+                                 (6, 30, 64, 1024, 1, 1, 0)])
+def test_dgrad_with_fused_bn_backward(dtype, mask_mode, cfg):
+    """conv data-gradient + ReLU mask + BN-backward reduction in one epilogue == torch's unfused composition."""
+    b, h, ci, co, k, s, p = cfg
+    g = torch.Generator().manual_seed(sum(cfg) + mask_mode)
+    # the producing layer: y_prev -> BN (+res) -> ReLU = a_prev, which is this conv's input
+    y_prev = q(torch.randn(b, ci, h, h, generator=g) * 1.5 + 0.3, dtype).requires_grad_(True)
+    res = q(torch.randn(b, ci, h, h, generator=g), dtype) if mask_mode == 1 else None
+    gamma = (0.5 + torch.rand(ci, generator=g)).requires_grad_(True)
+    beta = (torch.rand(ci, generator=g) - 0.5).requires_grad_(True)
+    z = F.batch_norm(y_prev, None, None, gamma, beta, True, 0.1, 1e-5)
+    a_prev = F.relu(z + res) if res is not None else F.relu(z)
+    w = q(torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5, dtype)
+    yc = F.conv2d(a_prev, w, None, s, p)
+    dyc = q(torch.randn(yc.shape, generator=g), dtype)
+    add = q(torch.randn(a_prev.shape, generator=g), dtype)
+    dy_ref, dg_ref, db_ref = torch.autograd.grad([yc, a_prev], (y_prev, gamma, beta), [dyc, add])
+    # GPU
+    yn = nhwc(y_prev.detach())
+    rows = yn.numel() // ci
+    mean = yn.reshape(rows, ci).mean(0)
+    var = yn.reshape(rows, ci).var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale = gamma.detach() * invstd
+    shift = beta.detach() - mean * scale
+    yd = yn.to(dtype).to(DEV)
+    a_d = ops.bn_apply(yd, scale.to(DEV), shift.to(DEV), None if res is None else nhwc(res).to(dtype).to(DEV), relu=True)
+    w_crsk = w.permute(1, 2, 3, 0).contiguous().to(dtype).to(DEV)
+    dz, st = ops.conv2d_dgrad_bn(nhwc(dyc).to(dtype).to(DEV), w_crsk, (b, h, h, ci), s, p, yd, mean.to(DEV), invstd.to(DEV),
+                                 a_out=a_d if mask_mode == 1 else None, scale=scale.to(DEV) if mask_mode == 2 else None,
+                                 shift=shift.to(DEV) if mask_mode == 2 else None, addend=nhwc(add).to(dtype).to(DEV))
+    dy, dg, db = ops.bn_backward_from_dz(dz, yd, mean.to(DEV), invstd.to(DEV), gamma.detach().to(DEV), st)
+    t = 1e-4 if dtype == torch.float32 else 3e-2
+    assert rel_err(nchw(dy), dy_ref) < t
+    assert rel_err(dg, dg_ref) < t and rel_err(db, db_ref) < t
 
 
 def test_pack_conv_weight():
