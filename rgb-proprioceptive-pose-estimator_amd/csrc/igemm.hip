@@ -591,7 +591,7 @@ template <typename T> int launch_nt(NTArgs<T>& a, int mode, hipStream_t s) {
     if ((a.ldb % CE) || (((uintptr_t)a.Bw) & 15) || (((uintptr_t)a.A) & 15))
         return rpe_set_error(RPE_ERR_ALIGN, "igemm_nt: operands must be 16-byte aligned with ld a multiple of the 16-byte chunk");
     if (mode == MODE_DENSE && ((a.lda % CE) || (a.K % CE))) return rpe_set_error(RPE_ERR_ALIGN, "igemm_nt: dense lda/K must be chunk multiples");
-    if (mode == MODE_CONV && (a.g.C % (8 * CE))) return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: conv channels must be a multiple of the K-step");
+    if (mode == MODE_CONV && (a.g.C % (8 * CE))) return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: conv channels must be a multiple of 8 chunks");
     const bool wide = a.N > 64;
     // BN partial sums are always indexed by 128-row tiles (rpe_conv_stats_tiles), whatever the M tile
     if (mode == MODE_STEM) return launch_nt_cfg<T, 2, 64, 4, MODE_STEM>(a, s);
@@ -605,7 +605,7 @@ template <typename T> int launch_nt(NTArgs<T>& a, int mode, hipStream_t s) {
         return wide ? launch_nt_cfg<T, 2, 128, 4, MODE_DENSE>(a, s) : launch_nt_cfg<T, 2, 64, 4, MODE_DENSE>(a, s);
     }
     if (big) return wide ? launch_nt_cfg<T, 4, 128, 8, MODE_CONV>(a, s) : launch_nt_cfg<T, 4, 64, 8, MODE_CONV>(a, s);
-    return wide ? launch_nt_cfg<T, 2, 128, 8, MODE_CONV>(a, s) : launch_nt_cfg<T, 2, 64, 8, MODE_CONV>(a, s);
+    return wide ? launch_nt_cfg<T, 2, 128, 4, MODE_CONV>(a, s) : launch_nt_cfg<T, 2, 64, 4, MODE_CONV>(a, s);
 }
 template int launch_nt<float>(NTArgs<float>&, int, hipStream_t);
 template int launch_nt<bf16>(NTArgs<bf16>&, int, hipStream_t);
@@ -615,8 +615,13 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
     a.tiles_i = ceil_div(a.I, BI);
     a.tiles_j = ceil_div(a.J, BJ);
     const long tiles = (long)a.tiles_i * a.tiles_j;
-    // enough workgroups to fill 256 CUs a few times over, but keep >= 16 m-steps per split
-    long want = (1536 + tiles - 1) / tiles;
+    // Every workgroup adds its whole BIxBJ fp32 tile with atomics (64 KB at 128x128), and float atomics run at ~1.3 TB/s
+    // chip-wide: 1536 workgroups = 100 MB = 77 us per launch, more than the GEMM itself.  ~2 workgroups per CU keeps the
+    // chip busy with a third of that traffic.
+    static const long target_wgs = getenv("RPE_TN_WGS") ? atol(getenv("RPE_TN_WGS")) : 512;
+    // (scaled so the atomic bytes, not the workgroup count, stay constant across tile sizes)
+    const long wgs = target_wgs * (128 * 128) / (BI * BJ);
+    long want = (wgs + tiles - 1) / tiles;
     long max_splits = a.M / (16 * BMK);
     if (max_splits < 1) max_splits = 1;
     if (want > max_splits) want = max_splits;
