@@ -77,6 +77,8 @@ typedef struct {
     const float *mean, *invstd, *scale, *shift;
     float* stats_part;
 } rpe_bn_bwd_epilogue;
+/* rows of bn->stats_part the fused data gradient writes (stride-2 layers enumerate rows per parity class) */
+long rpe_conv2d_dgrad_stats_tiles(const rpe_conv_desc* d);
 int rpe_conv2d_dgrad_bn(const rpe_conv_desc* d, int dtype, const void* dy, const void* w_crsk, void* dz, const void* addend,
                         const rpe_bn_bwd_epilogue* bn, void* stream);
 /* dw_krsc[out_c][kh][kw][in_c] (fp32) += x (*) dy.  Atomic accumulation: zero it first. */

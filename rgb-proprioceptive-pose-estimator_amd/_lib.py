@@ -42,6 +42,7 @@ _SPEC = {
     "rpe_conv_stats_tiles": (L, [L]),
     "rpe_conv2d_fwd": (I, [PD, I, P, P, P, P, P]),
     "rpe_conv2d_dgrad": (I, [PD, I, P, P, P, P, P]),
+    "rpe_conv2d_dgrad_stats_tiles": (L, [PD]),
     "rpe_conv2d_dgrad_bn": (I, [PD, I, P, P, P, P, POINTER(BnBwdEpilogue), P]),
     "rpe_bn_backward_from_dz": (I, [I, P, P, P, P, P, P, I, P, P, P, L, I, P, P, P]),
     "rpe_conv2d_wgrad": (I, [PD, I, P, P, P, P]),

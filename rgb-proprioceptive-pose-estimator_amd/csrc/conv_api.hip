@@ -1,6 +1,7 @@
 // C-ABI entry points for the MFMA implicit-GEMM kernels (conv forward / data-gradient /
 // weight-gradient, stem conv, Linear) and the library's error channel.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "igemm.h"
@@ -35,6 +36,11 @@ static int check_desc(const rpe_conv_desc* d) {
     return 0;
 }
 static inline int out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
+// stride-2 data gradients with even input dims run in parity-class order (see igemm.h Gather::parity)
+static inline bool dgrad_parity(const rpe_conv_desc* d) {
+    static const bool off = getenv("RPE_NO_PARITY") != nullptr;
+    return !off && d->stride == 2 && !(d->in_h & 1) && !(d->in_w & 1);
+}
 static inline bool is_dense(const rpe_conv_desc* d) { return d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0; }
 
 template <typename T>
@@ -78,6 +84,13 @@ static int conv_dgrad_t(const rpe_conv_desc* d, const void* dy, const void* w_cr
     g.sn = 1; g.sd_shift = ilog2(d->stride); g.base_h = d->pad; g.base_w = d->pad; g.tap_sign = -1;
     g.div_hw = make_fastdiv(d->in_h * d->in_w); g.div_w = make_fastdiv(d->in_w);
     g.img_stride = (long)Ho * Wo * d->out_c;
+    if (dgrad_parity(d)) {
+        // enumerate output pixels per parity class; Ho/Wo of the row space become the half dims
+        g.parity = 1;
+        g.Ho = d->in_h / 2; g.Wo = d->in_w / 2;
+        g.rows_q = d->batch * g.Ho * g.Wo;
+        g.div_hw = make_fastdiv(g.Ho * g.Wo); g.div_w = make_fastdiv(g.Wo);
+    }
     return launch_nt<T>(a, MODE_CONV, s);
 }
 
@@ -166,6 +179,13 @@ int rpe_conv_out_hw(const rpe_conv_desc* d, int* ho, int* wo) {
 }
 
 long rpe_conv_stats_tiles(long rows) { return (rows + 127) / 128; }
+
+long rpe_conv2d_dgrad_stats_tiles(const rpe_conv_desc* d) {
+    if (!d) return 0;
+    const long rows = (long)d->batch * d->in_h * d->in_w;
+    if (!is_dense(d) && dgrad_parity(d)) return 4 * ((rows / 4 + 127) / 128);
+    return (rows + 127) / 128;
+}
 
 int rpe_conv2d_fwd(const rpe_conv_desc* d, int dtype, const void* x, const void* w_krsc, void* y, float* stats_part, void* stream) {
     if (int e = check_desc(d)) return e;

@@ -80,6 +80,7 @@ struct rpe_resnet50 {
     float* stem_dw = nullptr;    // [64][8][8][4]
     std::vector<Named> named;
     int train_mode = 0;
+    int fused_tiles = 0;
     // optional per-category HIP-event timing (rpe_resnet50_profile)
     bool profiling = false;
     struct Span { int cat; hipEvent_t a, b; };
@@ -196,6 +197,8 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
         want(e, (void**)&c.invstd, c.d.out_c * 4L);
         const long sf = rpe_conv_stats_tiles(c.rows) * 2 * c.d.out_c;
         if (sf > e->stats_floats) e->stats_floats = sf;
+        const long sf2 = (rpe_conv2d_dgrad_stats_tiles(&c.d) + 4) * 2 * c.d.in_c;  // fused dgrad partials (parity classes round up)
+        if (sf2 > e->stats_floats) e->stats_floats = sf2;
     }
     const ConvL& st = e->convs[0];
     const long pool_n = (long)batch * (st.Ho / 2) * (st.Wo / 2) * 64;
@@ -373,6 +376,7 @@ static int dgrad_fused(rpe_resnet50* e, ConvL& c, const void* dy, void* dz, cons
     ep.scale = mask_mode == 2 ? bnl->scale : nullptr;
     ep.shift = mask_mode == 2 ? bnl->shift : nullptr;
     ep.stats_part = e->stats_part;
+    e->fused_tiles = (int)rpe_conv2d_dgrad_stats_tiles(&c.d);  // partial-sum rows this launch leaves behind
     PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad_bn(&c.d, e->dtype, dy, c.wd, dz, addend, &ep, stream));
     return 0;
 }
@@ -380,7 +384,7 @@ static int dgrad_fused(rpe_resnet50* e, ConvL& c, const void* dy, void* dz, cons
 // second half of the fused BN backward of layer c: partials (left in stats_part by dgrad_fused) -> dgamma, dbeta, dy
 static int bn_from_dz(rpe_resnet50* e, ConvL& c, const void* dz, void* dy, void* stream) {
     PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_backward_from_dz(e->dtype, dz, c.y, c.mean, c.invstd, e->params[c.p_g], e->stats_part,
-                                                              (int)rpe_conv_stats_tiles(c.rows), e->grads[c.p_g], e->grads[c.p_b], dy, c.rows,
+                                                              e->fused_tiles, e->grads[c.p_g], e->grads[c.p_b], dy, c.rows,
                                                               c.d.out_c, e->c1c2, e->dpart, stream));
     return 0;
 }

@@ -21,6 +21,11 @@ struct Gather {
     int tap_sign;
     FastDiv div_hw, div_w;
     long img_stride;
+    // stride-2 data gradient only: rows are enumerated per output-pixel parity class (h&1, w&1) so that a tile's K loop
+    // walks just the taps that can hit a non-zero of the zero-interleaved dy (1, 2, 2 or 4 of a 3x3; 1 or 0 of a 1x1)
+    // instead of multiplying 3/4 zeros.  parity = 1: Ho/Wo above are the HALF dims, rows_q = B*(H/2)*(W/2) rows per class.
+    int parity;
+    int rows_q;
 };
 
 template <typename T> struct NTArgs {

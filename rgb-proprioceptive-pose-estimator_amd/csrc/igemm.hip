@@ -102,8 +102,29 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
     const int wave_m = wave >> 1, wave_n = wave & 1;
     const int lb = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     const int tile_n = lb % p.tiles_n, tile_m = lb / p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int n0 = tile_n * BN;
     const Gather& g = p.g;
+    // Row space.  Normal: row m = m0 + local.  Parity mode (stride-2 dgrad): tile_m = tq * 4 + cls (classes interleaved:
+    // they cost 1 : 2 : 2 : 4 taps, and the XCD remap hands each XCD a contiguous tile range -- class-major order left two
+    // XCDs with all the work); local rows index the class-local pixel list (b, h', w') -> output pixel (b, 2h'+ph, 2w'+pw).
+    int cls = 0, ph = 0, pw = 0, m0 = tile_m * BM, row_lim = p.M;
+    if (MODE == MODE_CONV && g.parity) {
+        cls = tile_m & 3;
+        m0 = (tile_m >> 2) * BM;
+        ph = cls >> 1; pw = cls & 1;
+        row_lim = g.rows_q;
+    }
+    // output row (for C / addend / BN operands) of tile-local row index `lr`, or -1 when outside the problem
+    auto out_row = [&](int lr) -> long {
+        const int m = m0 + lr;
+        if (m >= row_lim) return -1;
+        if (!(MODE == MODE_CONV && g.parity)) return m;
+        const unsigned b = fd_div((unsigned)m, g.div_hw);
+        const unsigned rem = (unsigned)m - b * g.div_hw.d;
+        const unsigned hh = fd_div(rem, g.div_w);
+        const unsigned ww = rem - hh * g.div_w.d;
+        return ((long)b * (2 * g.Ho) + (2 * hh + ph)) * (2 * g.Wo) + (2 * ww + pw);
+    };
     // Staging.  DMA path (dense / conv): global_load_lds_dwordx4 writes 64 lanes x 16 B = RPI rows x KCH slots straight
     // into LDS (no VGPR round trip, no ds_write).  The LDS image is lane-linear, so the slot swizzle is applied on the
     // SOURCE side: the lane that fills slot s of row r fetches logical chunk s ^ f(r).  Padding taps / tails fetch from a
@@ -126,7 +147,7 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         const int m = m0 + a_row[i];
-        a_ok[i] = m < p.M;
+        a_ok[i] = m < row_lim;
         a_hb[i] = a_wb[i] = 0;
         if (MODE == MODE_DENSE) {
             a_base[i] = (long)m * p.lda + a_chunk[i] * CE;
@@ -134,8 +155,9 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
             const unsigned mm = a_ok[i] ? (unsigned)m : 0u;
             const unsigned b = fd_div(mm, g.div_hw);
             const unsigned rem = mm - b * g.div_hw.d;
-            const unsigned oh = fd_div(rem, g.div_w);
-            const unsigned ow = rem - oh * g.div_w.d;
+            unsigned oh = fd_div(rem, g.div_w);
+            unsigned ow = rem - oh * g.div_w.d;
+            if (MODE == MODE_CONV && g.parity) { oh = 2 * oh + ph; ow = 2 * ow + pw; }
             a_base[i] = (long)b * g.img_stride;
             a_hb[i] = (int)oh * g.sn + g.base_h;
             a_wb[i] = (int)ow * g.sn + g.base_w;
@@ -150,8 +172,16 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
         b_off[i] = (long)n * p.ldb + b_chunk[i] * CE;
     }
 
-    // uniform K-walk state for MODE_CONV: k = (r*S + s)*C + c0
-    int kbase = 0, c0 = 0, tr = 0, ts = 0;
+    // uniform K-walk state for MODE_CONV: k = (r*S + s)*C + c0.  Parity mode visits taps r0, r0+2, .. x s0, s0+2, ..
+    int kbase = 0, c0 = 0, tr = 0, ts = 0, tstep = 1, s_first = 0;
+    int nk = (p.K + BK - 1) / BK;
+    if (MODE == MODE_CONV && g.parity) {
+        const int r0 = (ph + g.base_h) & 1, s0 = (pw + g.base_w) & 1;
+        const int nr = r0 < g.R ? (g.R - r0 + 1) / 2 : 0, ns = s0 < g.S ? (g.S - s0 + 1) / 2 : 0;
+        tr = r0; ts = s0; s_first = s0; tstep = 2;
+        kbase = (tr * g.S + ts) * g.C;
+        nk = nr * ns * (g.C / BK);
+    }
 
     // source address of A chunk i for the current K-step, or nullptr for zero fill
     auto a_src = [&](int i) -> const T* {
@@ -171,7 +201,12 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
         kbase += BK;
         if (MODE == MODE_CONV) {
             c0 += BK;
-            if (c0 >= g.C) { c0 = 0; if (++ts >= g.S) { ts = 0; ++tr; } }
+            if (c0 >= g.C) {
+                c0 = 0;
+                ts += tstep;
+                if (ts >= g.S) { ts = s_first; tr += tstep; }
+                if (tstep != 1) kbase = (tr * g.S + ts) * g.C;
+            }
         }
     };
     typedef __attribute__((address_space(3))) char lds_char;
@@ -215,7 +250,6 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
 #pragma unroll
         for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.K + BK - 1) / BK;
     const int fr = lane & 15, fc = lane >> 4;
     auto compute = [&](int st) {
         const u32x4* base = lds + st * STAGE;
@@ -238,7 +272,7 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
         // s_barrier (not __syncthreads, which would drain vmcnt to 0) then publishes it to the other waves; slot (kt+2)%3
         // was last read in iteration kt-1, i.e. before the barrier every wave has already passed.
         constexpr int NI = AR + BR;
-        dma_tile(0);
+        if (nk > 0) dma_tile(0);
         if (nk > 1) { advance_k(); dma_tile(1); wait_vmcnt<NI>(); } else { wait_vmcnt<0>(); }
         __builtin_amdgcn_s_barrier();
         int st = 0;
@@ -309,14 +343,14 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int r = ps * RPP + erow;
-            const int m = m0 + wave_m * WM + qf * 16 + r;
+            const long m = out_row(wave_m * WM + qf * 16 + r);
             float v[8];
             {
                 const f32x4 t0 = *(const f32x4*)(stg + r * LDW + echk * 8);
                 const f32x4 t1 = *(const f32x4*)(stg + r * LDW + echk * 8 + 4);
                 v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
             }
-            if (m >= p.M || !ncol_ok) continue;
+            if (m < 0 || !ncol_ok) continue;
             if (p.stats_part && !bn_mode) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { cs[j] += v[j]; cq[j] += v[j] * v[j]; }
@@ -327,15 +361,15 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
             }
             if (p.addend) {
                 float ad[8];
-                load8(p.addend, (long)m * p.ld_add + n, vec_add, ad);
+                load8(p.addend, m * p.ld_add + n, vec_add, ad);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] += ad[j];
             }
             if (bn_mode) {
                 // v = dA (gradient wrt the BN output after ReLU).  dz = dA * [a_out > 0]; partial sums of dz and dz*xhat.
                 float yy[8], aa[8];
-                load8(p.bn_y, (long)m * p.ldc + n, vec_c, yy);
-                if (bn_mode == 1) load8(p.bn_a, (long)m * p.ldc + n, vec_c, aa);
+                load8(p.bn_y, m * p.ldc + n, vec_c, yy);
+                if (bn_mode == 1) load8(p.bn_a, m * p.ldc + n, vec_c, aa);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const bool on = bn_mode == 1 ? (aa[j] > 0.f) : (bn_mode == 2 ? (fmaf(yy[j], csc[j], csh[j]) > 0.f) : true);
@@ -349,7 +383,7 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
             }
-            T* cp = p.C + (long)m * p.ldc + n;
+            T* cp = p.C + m * p.ldc + n;
             if (vec_c) {
                 if (CE == 8) { *(u32x4*)cp = f_to_chunk<T>(v); }
                 else { *(u32x4*)cp = f_to_chunk<T>(v); *(u32x4*)(cp + 4) = f_to_chunk<T>(v + 4); }
@@ -379,8 +413,9 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
         __syncthreads();
         for (int i = tid; i < (WAVES_M / 2) * BN; i += NTHR) {
             const int h = i / BN, c = i - h * BN;
-            const long t128 = (long)tile_m * (WAVES_M / 2) + h;
-            if (n0 + c < p.N && t128 * 128 < p.M) {
+            long t128 = (long)tile_m * (WAVES_M / 2) + h;
+            if (MODE == MODE_CONV && g.parity) t128 = (long)cls * ((g.rows_q + 127) / 128) + m0 / 128 + h;
+            if (n0 + c < p.N && m0 + h * 128 < row_lim) {
                 const float s_ = red[((2 * h) * BN + c) * 2] + red[((2 * h + 1) * BN + c) * 2];
                 const float q_ = red[((2 * h) * BN + c) * 2 + 1] + red[((2 * h + 1) * BN + c) * 2 + 1];
                 p.stats_part[(t128 * 2 + 0) * p.N + n0 + c] = s_;
@@ -576,7 +611,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
 // -----------------------------------------------------------------------------------------------
 template <typename T, int WAVES_M, int BN, int KCH, int MODE> static int launch_nt_cfg(NTArgs<T>& a, hipStream_t s) {
     constexpr int BM = 64 * WAVES_M;
-    a.tiles_m = ceil_div(a.M, BM);
+    a.tiles_m = (MODE == MODE_CONV && a.g.parity) ? 4 * ceil_div(a.g.rows_q, BM) : ceil_div(a.M, BM);
     a.tiles_n = ceil_div(a.N, BN);
     const long nwg = (long)a.tiles_m * a.tiles_n;
     if (nwg <= 0 || nwg > 0x7fffffffL) return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: bad grid");

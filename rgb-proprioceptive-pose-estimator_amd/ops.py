@@ -87,8 +87,7 @@ def conv2d_dgrad_bn(dy, w_crsk, x_shape, stride, pad, y, mean, invstd, a_out=Non
     ci, k, co = w_crsk.shape[0], w_crsk.shape[1], w_crsk.shape[3]
     d = conv_desc(x_shape, co, k, stride, pad)
     dz = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device)
-    rows = x_shape[0] * x_shape[1] * x_shape[2]
-    st = torch.empty((stats_tiles(rows), 2, ci), dtype=torch.float32, device=dy.device)
+    st = torch.empty((lib.rpe_conv2d_dgrad_stats_tiles(ctypes.byref(d)), 2, ci), dtype=torch.float32, device=dy.device)
     ep = BnBwdEpilogue(*(None if t is None else t.data_ptr() for t in (y, a_out, mean, invstd, scale, shift, st)))
     lib.rpe_conv2d_dgrad_bn(ctypes.byref(d), dtype_code(dy), _p(dy), _p(w_crsk), _p(dz), _p(addend), ctypes.byref(ep), _stream())
     return dz, st

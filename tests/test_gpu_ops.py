@@ -83,6 +83,8 @@ CONVS = [  # (B, H, Cin, Cout, k, stride, pad)
     (2, 14, 256, 512, 1, 2, 0),
     (1, 7, 512, 128, 3, 1, 1),
     (2, 10, 64, 128, 3, 2, 1),  # Ho*Wo not a multiple of anything convenient
+    (2, 9, 64, 64, 3, 2, 1),    # odd input size: stride-2 data gradient without the parity-class decomposition
+    (3, 12, 64, 128, 1, 2, 0),
     # M >= 4096 rows and K >= 1024: the 256-row / 8-wave tile configuration
     (8, 24, 128, 128, 3, 1, 1),
     (8, 24, 1024, 64, 1, 1, 0),
