@@ -91,6 +91,16 @@ int rpe_stem_conv_wgrad(int dtype, const void* x4, const void* dy, float* dw_pac
 
 /* weight layouts.  w_krsc_f32 is the fp32 master in channels_last storage. */
 int rpe_pack_conv_weight(int dtype, const float* w_krsc, void* w_fwd, void* w_dgrad, int Co, int R, int S, int Ci, void* stream);
+/* the same for many layers in one launch; the descriptor table lives in device memory */
+typedef struct {
+    const float* src; /* [Co][RS][Ci] fp32 */
+    void* wf;         /* forward copy or NULL */
+    void* wd;         /* dgrad copy [Ci][RS][Co] or NULL */
+    int Co, RS, Ci;
+    int pad_;
+    long start;       /* first flat element index of this layer */
+} rpe_pack_desc;
+int rpe_pack_conv_weights_multi(int dtype, const rpe_pack_desc* table_dev, int nlayers, long total, void* stream);
 int rpe_pack_stem_weight(int dtype, const float* w_oihw, void* out, void* stream);
 int rpe_unpack_stem_grad(const float* d_packed, float* dw_oihw, void* stream);
 

@@ -49,6 +49,7 @@ _SPEC = {
     "rpe_stem_conv_fwd": (I, [I, P, P, P, P, I, I, I, P]),
     "rpe_stem_conv_wgrad": (I, [I, P, P, P, I, I, I, P]),
     "rpe_pack_conv_weight": (I, [I, P, P, P, I, I, I, I, P]),
+    "rpe_pack_conv_weights_multi": (I, [I, P, I, L, P]),
     "rpe_pack_stem_weight": (I, [I, P, P, P]),
     "rpe_unpack_stem_grad": (I, [P, P, P]),
     "rpe_stage_image_nhwc4": (I, [I, P, P, I, I, I, P]),

@@ -81,6 +81,12 @@ struct rpe_resnet50 {
     std::vector<Named> named;
     int train_mode = 0;
     int fused_tiles = 0;
+    // conv/fc weight gradients are accumulated with atomics: when the bound gradient tensors form one contiguous block
+    // (they do in the flat arena) it is zeroed by ONE memset per backward instead of 54 (15 us each)
+    rpe_pack_desc* pack_tab = nullptr;   // device table for the one-launch weight packing
+    long pack_total = 0;
+    char* gspan_lo = nullptr;
+    size_t gspan_bytes = 0;
     // optional per-category HIP-event timing (rpe_resnet50_profile)
     bool profiling = false;
     struct Span { int cat; hipEvent_t a, b; };
@@ -215,6 +221,7 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
     want(e, (void**)&e->c1c2, 2 * 2048 * 4L);
     want(e, (void**)&e->dpart, (long)RPE_BN_MAX_SLICES * 2 * 2048 * 8);
     want(e, (void**)&e->stem_dw, 64L * 256 * 4);
+    want(e, (void**)&e->pack_tab, 64L * sizeof(rpe_pack_desc));
     for (auto& c : e->convs) {
         const double mnk = 2.0 * (double)c.rows * c.d.out_c * (double)(c.d.kh * c.d.kw * c.d.in_c);
         const double in_b = (double)batch * c.d.in_h * c.d.in_w * c.d.in_c * es, out_b = (double)c.rows * c.d.out_c * es;
@@ -290,6 +297,40 @@ extern "C" int rpe_resnet50_bind(rpe_resnet50_t* e, void* workspace, long worksp
     e->named.push_back({"pool", e->pool, (long)e->B * (e->convs[0].Ho / 2) * (e->convs[0].Wo / 2), 64});
     e->named.push_back({"x4", e->x4, (long)e->B * e->H * e->W, 4});
     for (int i = 0; i < 4; ++i) e->named.push_back({"G" + std::to_string(i), e->G[i], 0, 0});
+    {   // descriptor table of the per-step weight packing (bind is a setup call: one small synchronous upload)
+        std::vector<rpe_pack_desc> tab;
+        long start = 0;
+        for (size_t i = 1; i < e->convs.size(); ++i) {
+            ConvL& c = e->convs[i];
+            rpe_pack_desc d;
+            d.src = e->params[c.p_w];
+            d.wf = e->dtype == RPE_F32 ? nullptr : c.wf;
+            d.wd = c.wd;
+            d.Co = c.d.out_c; d.RS = c.d.kh * c.d.kw; d.Ci = c.d.in_c; d.pad_ = 0;
+            d.start = start;
+            start += (long)d.Co * d.RS * d.Ci;
+            tab.push_back(d);
+        }
+        e->pack_total = start;
+        if (hipError_t he = hipMemcpy(e->pack_tab, tab.data(), tab.size() * sizeof(rpe_pack_desc), hipMemcpyHostToDevice))
+            return rpe_set_error_hip(he, __FILE__, __LINE__);
+    }
+    e->gspan_lo = nullptr; e->gspan_bytes = 0;
+    if (grads_host) {
+        char *lo = nullptr, *hi = nullptr;
+        size_t sum = 0;
+        bool ok = true;
+        for (int i = 0; i < np; ++i) {
+            if (!e->grads[i]) { ok = false; break; }
+            char* a = (char*)e->grads[i];
+            char* b = a + (size_t)e->pnumel[i] * 4;
+            if (!lo || a < lo) lo = a;
+            if (!hi || b > hi) hi = b;
+            sum += (size_t)e->pnumel[i] * 4;
+        }
+        // contiguous up to the arena's 16-byte segment padding
+        if (ok && (size_t)(hi - lo) <= sum + (size_t)np * 16) { e->gspan_lo = lo; e->gspan_bytes = (size_t)(hi - lo); }
+    }
     e->bound = true;
     e->fwd_done = false;
     return 0;
@@ -300,10 +341,7 @@ extern "C" int rpe_resnet50_bind(rpe_resnet50_t* e, void* workspace, long worksp
 extern "C" int rpe_resnet50_pack_weights(rpe_resnet50_t* e, void* stream) {
     if (!e || !e->bound) return rpe_set_error(RPE_ERR_STATE, "resnet50_pack_weights: engine not bound");
     PROF(e, RPE_PROF_OTHER, stream, rpe_pack_stem_weight(e->dtype, e->params[e->convs[0].p_w], e->convs[0].wf, stream));
-    for (size_t i = 1; i < e->convs.size(); ++i) {
-        ConvL& c = e->convs[i];
-        PROF(e, RPE_PROF_OTHER, stream, rpe_pack_conv_weight(e->dtype, e->params[c.p_w], e->dtype == RPE_F32 ? nullptr : c.wf, c.wd, c.d.out_c, c.d.kh, c.d.kw, c.d.in_c, stream));
-    }
+    PROF(e, RPE_PROF_OTHER, stream, rpe_pack_conv_weights_multi(e->dtype, e->pack_tab, (int)e->convs.size() - 1, e->pack_total, stream));
     const int np = (int)e->pnames.size();
     TRY(rpe_transpose_f32(e->params[np - 2], e->fc_wt, e->latent, 2048, 2048, e->latent_pad, stream));
     return 0;
@@ -422,7 +460,7 @@ static int wgrad(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, void*
         HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
         run = e->side;
     }
-    HIPTRY(hipMemsetAsync(dw, 0, (size_t)e->pnumel[c.p_w] * 4, run));
+    if (!e->gspan_lo) HIPTRY(hipMemsetAsync(dw, 0, (size_t)e->pnumel[c.p_w] * 4, run));
     PROF(e, RPE_PROF_CONV_WGRAD, run, rpe_conv2d_wgrad(&c.d, e->dtype, x, dy, dw, run));
     if (run != (hipStream_t)stream) {
         hipEvent_t done = sync_event(e);
@@ -450,9 +488,10 @@ extern "C" int rpe_resnet50_backward(rpe_resnet50_t* e, const float* d_features,
     }
     e->sync_next = 0;
     for (int i = 0; i < 4; ++i) { e->pend_buf[i] = nullptr; e->pend_ev[i] = nullptr; }
+    if (e->gspan_lo) HIPTRY(hipMemsetAsync(e->gspan_lo, 0, e->gspan_bytes, s));
     // fc
     float* dWfc = e->grads[np - 2];
-    if (hipError_t he = hipMemsetAsync(dWfc, 0, (size_t)e->latent * 2048 * 4, s)) return rpe_set_error_hip(he, __FILE__, __LINE__);
+    if (!e->gspan_lo) HIPTRY(hipMemsetAsync(dWfc, 0, (size_t)e->latent * 2048 * 4, s));
     TRY(rpe_linear_wgrad(RPE_F32, d_features, (int)ld_d_features, e->pooled, 2048, dWfc, 2048, e->B, e->latent, 2048, stream));
     TRY(rpe_colsum(d_features, e->B, e->latent, (int)ld_d_features, e->grads[np - 1], 0, stream));
     // d_pooled[B][2048] = d_features[B][latent] * Wfc[latent][2048]  ==  NT with weight fc_wt [2048][latent_pad].

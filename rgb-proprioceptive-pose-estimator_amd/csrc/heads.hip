@@ -346,6 +346,30 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __re
     }
 }
 
+// all conv layers of a trunk in ONE launch: a table of per-layer descriptors, flat element index space
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv_weights_multi_kernel(const rpe_pack_desc* __restrict__ tab, int nlayers, long total) {
+    __shared__ long starts[128];
+    for (int i = threadIdx.x; i <= nlayers && i < 128; i += blockDim.x) starts[i] = i < nlayers ? tab[i].start : total;
+    __syncthreads();
+    const long chunk = 2048;
+    for (long base = (long)blockIdx.x * chunk; base < total; base += (long)gridDim.x * chunk) {
+        int l = 0;
+        while (l + 1 < nlayers && starts[l + 1] <= base) ++l;
+        for (long i = base + threadIdx.x; i < base + chunk && i < total; i += blockDim.x) {
+            while (l + 1 < nlayers && starts[l + 1] <= i) ++l;
+            const rpe_pack_desc d = tab[l];
+            const long j = i - d.start;
+            const int ci = (int)(j % d.Ci);
+            const long t = j / d.Ci;
+            const int rs = (int)(t % d.RS), co = (int)(t / d.RS);
+            const float v = d.src[j];
+            if (d.wf) ((T*)d.wf)[j] = Elem<T>::from_f(v);
+            if (d.wd) ((T*)d.wd)[((long)ci * d.RS + rs) * d.Co + co] = Elem<T>::from_f(v);
+        }
+    }
+}
+
 // stem: OIHW [64][3][7][7] fp32 -> [64][8][8][4] T (taps and channel zero padded)
 template <typename T>
 __global__ void pack_stem_weight_kernel(const float* __restrict__ w, T* __restrict__ out) {
@@ -499,6 +523,16 @@ int rpe_pack_conv_weight(int dtype, const float* w_krsc, void* w_fwd, void* w_dg
     if (dtype == RPE_F32) hipLaunchKernelGGL((pack_conv_weight_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, w_krsc, (float*)w_fwd, (float*)w_dgrad, Co, R * S, Ci);
     else if (dtype == RPE_BF16) hipLaunchKernelGGL((pack_conv_weight_kernel<bf16>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, w_krsc, (bf16*)w_fwd, (bf16*)w_dgrad, Co, R * S, Ci);
     else return rpe_set_error(RPE_ERR_DTYPE, "pack_conv_weight: unsupported dtype");
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_pack_conv_weights_multi(int dtype, const rpe_pack_desc* table_dev, int nlayers, long total, void* stream) {
+    if (nlayers <= 0 || nlayers > 127 || total <= 0) return rpe_set_error(RPE_ERR_SHAPE, "pack_conv_weights_multi: bad table");
+    const int grid = (int)((total + 2047) / 2048 < 4096 ? (total + 2047) / 2048 : 4096);
+    if (dtype == RPE_F32) hipLaunchKernelGGL((pack_conv_weights_multi_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, table_dev, nlayers, total);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((pack_conv_weights_multi_kernel<bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, table_dev, nlayers, total);
+    else return rpe_set_error(RPE_ERR_DTYPE, "pack_conv_weights_multi: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;
 }

@@ -83,7 +83,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 //   large config  <4, 128|64, 8>: 256-row tile, 128-B rows  (conv trunk): 2x the FLOPs per byte pulled from L2 into LDS
 //   and every DMA instruction moves whole 128-B lines -- at 128x128x32 the kernel sat at ~16 B/clk/CU of L2->LDS traffic.
 // -----------------------------------------------------------------------------------------------
-template <typename T, int WAVES_M, int BN, int KCH, int MODE>
+template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST = 3>
 __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
     constexpr int CE = Elem<T>::kChunk, BK = KCH * CE;
     constexpr int NW = 2 * WAVES_M, NTHR = 64 * NW;
@@ -94,8 +94,9 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
     constexpr int STAGE = (BM + BN) * KCH;             // 16-byte units
     constexpr int EPI16 = NW * 16 * (WN + 4) / 4;      // epilogue staging (NW waves x 16 rows x (WN+4) floats)
     constexpr bool DMA = MODE != MODE_STEM;
-    constexpr int NSTAGE = DMA ? 3 : 2;                // DMA path: ring of 3, two tiles in flight
+    constexpr int NSTAGE = DMA ? NST : 2;              // DMA path: ring of NST slots, NST-1 tiles in flight
     static_assert(DMA || (WAVES_M == 2 && KCH == 4), "register staging is only wired for the 128-row / 64-B-row config");
+    static_assert(NST >= 2 && NST <= 3, "ring depth 2 or 3");
     __shared__ u32x4 lds[(NSTAGE * STAGE > EPI16) ? NSTAGE * STAGE : EPI16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -272,17 +273,29 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
         // s_barrier (not __syncthreads, which would drain vmcnt to 0) then publishes it to the other waves; slot (kt+2)%3
         // was last read in iteration kt-1, i.e. before the barrier every wave has already passed.
         constexpr int NI = AR + BR;
-        if (nk > 0) dma_tile(0);
-        if (nk > 1) { advance_k(); dma_tile(1); wait_vmcnt<NI>(); } else { wait_vmcnt<0>(); }
+        constexpr int PF = NSTAGE - 1;  // tiles kept in flight ahead of the one being multiplied
+        // prologue: tiles 0 .. PF-1
+#pragma unroll
+        for (int t = 0; t < PF; ++t) {
+            if (t < nk) { if (t > 0) advance_k(); dma_tile(t); }
+        }
+        // tile 0 must have landed: allow the (min(PF, nk) - 1) newer tiles to stay in flight
+        {
+            const int newer = (nk < PF ? nk : PF) - 1;
+            if (newer >= 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
+        }
         __builtin_amdgcn_s_barrier();
         int st = 0;
         for (int kt = 0; kt < nk; ++kt) {
-            const bool pre = kt + 2 < nk;
-            if (pre) { advance_k(); int s2 = st + 2; if (s2 >= 3) s2 -= 3; dma_tile(s2); }
+            const bool pre = kt + PF < nk;
+            if (pre) { advance_k(); int s2 = st + PF; if (s2 >= NSTAGE) s2 -= NSTAGE; dma_tile(s2); }
             compute(st);
-            if (pre) wait_vmcnt<NI>(); else wait_vmcnt<0>();
+            // tile kt+1 must be complete; tiles kt+2 .. may still be in flight
+            int newer = nk - 2 - kt;               // tiles issued after kt+1
+            if (newer > PF - 1) newer = PF - 1;
+            if (newer >= 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
-            if (++st == 3) st = 0;
+            if (++st == NSTAGE) st = 0;
         }
     } else {
         load_tile();
@@ -609,13 +622,13 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
 // -----------------------------------------------------------------------------------------------
 // host launchers
 // -----------------------------------------------------------------------------------------------
-template <typename T, int WAVES_M, int BN, int KCH, int MODE> static int launch_nt_cfg(NTArgs<T>& a, hipStream_t s) {
+template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST = 3> static int launch_nt_cfg(NTArgs<T>& a, hipStream_t s) {
     constexpr int BM = 64 * WAVES_M;
     a.tiles_m = (MODE == MODE_CONV && a.g.parity) ? 4 * ceil_div(a.g.rows_q, BM) : ceil_div(a.M, BM);
     a.tiles_n = ceil_div(a.N, BN);
     const long nwg = (long)a.tiles_m * a.tiles_n;
     if (nwg <= 0 || nwg > 0x7fffffffL) return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: bad grid");
-    hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE>), dim3((unsigned)nwg), dim3(128 * WAVES_M), 0, s, a);
+    hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST>), dim3((unsigned)nwg), dim3(128 * WAVES_M), 0, s, a);
     RPE_CHECK_LAUNCH();
     return 0;
 }
@@ -635,6 +648,13 @@ template <typename T> int launch_nt(NTArgs<T>& a, int mode, hipStream_t s) {
     // in lockstep): 34.4 vs 32.9 ms/step.  Kept selectable for experiments (RPE_NT_BIG=1), off by default.
     static const bool big_enabled = getenv("RPE_NT_BIG") != nullptr;
     const bool big = big_enabled && a.M >= 4096 && a.K >= 1024;
+    // Long reductions (K >= 1024: the 3x3 convs from layer2 on and the deep 1x1s): 128-B K rows (BK 64) with a 2-slot ring
+    // (64 KB LDS, 2 workgroups per CU) -- half the barriers per FLOP; measured +10..15 % there, -5..15 % on short K.
+    static const bool bk64_all = getenv("RPE_NT_BK64") != nullptr, bk64_off = getenv("RPE_NT_NOBK64") != nullptr;
+    if (!big && !bk64_off && a.M >= 1024 && (bk64_all ? a.K >= 16 * CE : a.K >= 1024)) {
+        if (mode == MODE_DENSE) return wide ? launch_nt_cfg<T, 2, 128, 8, MODE_DENSE, 2>(a, s) : launch_nt_cfg<T, 2, 64, 8, MODE_DENSE, 2>(a, s);
+        return wide ? launch_nt_cfg<T, 2, 128, 8, MODE_CONV, 2>(a, s) : launch_nt_cfg<T, 2, 64, 8, MODE_CONV, 2>(a, s);
+    }
     if (mode == MODE_DENSE) {
         if (big) return wide ? launch_nt_cfg<T, 4, 128, 8, MODE_DENSE>(a, s) : launch_nt_cfg<T, 4, 64, 8, MODE_DENSE>(a, s);
         return wide ? launch_nt_cfg<T, 2, 128, 4, MODE_DENSE>(a, s) : launch_nt_cfg<T, 2, 64, 4, MODE_DENSE>(a, s);
