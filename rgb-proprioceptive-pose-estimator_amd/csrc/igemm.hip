@@ -450,7 +450,7 @@ template <typename T, int CPR> __device__ __forceinline__ int tn_swz(int row) {
     return (((row >> 1) & 1) | ((row >> 2) & 2)) << 1;                          // 128-B rows (parity picks the half)
 }
 
-template <typename T, int BI, int BJ, int MODE>
+template <typename T, int BI, int BJ, int MODE, bool USE_DMA = true>
 __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
     constexpr int CE = Elem<T>::kChunk, BMK = 4 * CE;
     constexpr int WI = BI / 2, WJ = BJ / 2, FI = WI / 16, FJ = WJ / 16;
@@ -459,7 +459,10 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
     constexpr int NPI = (BMK + RPI - 1) / RPI, NPJ = (BMK + RPJ - 1) / RPJ;
     constexpr int PT = BMK * CPI, QT = BMK * CPJ;      // tile sizes in 16-byte units
     constexpr int STAGE = PT + QT;
-    __shared__ u32x4 lds[2 * STAGE];
+    constexpr bool DMA = USE_DMA && MODE != MODE_STEM;  // LDS-DMA staging, 3-slot ring (see nt_kernel); stem: registers
+    constexpr int NSTAGE = DMA ? 3 : 2;
+    static_assert(BMK % RPI == 0 && BMK % RPJ == 0, "tile rows must split evenly over the passes");
+    __shared__ u32x4 lds[NSTAGE * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_i = wave >> 1, wave_j = wave & 1;
@@ -473,54 +476,77 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
     if (m_begin >= m_end) return;
     const Gather& g = p.g;
 
-    const int p_cc = tid % CPI, p_r = tid / CPI;
-    const int q_cc = tid % CPJ, q_r = tid / CPJ;
-    const bool p_col_ok = (i0 + p_cc * CE) < p.I;
-    const bool q_col_ok = (j0 + q_cc * CE) < p.J;
+    // thread -> (row, LDS slot) of pass i: row = tid / CP + i * RP, slot = tid % CP (64 consecutive chunks per wave: the
+    // lane-linear image one DMA instruction writes).  The slot holds logical chunk slot ^ swz(row).
+    const int p_slot = tid % CPI, p_r = tid / CPI;
+    const int q_slot = tid % CPJ, q_r = tid / CPJ;
     // conv: the BJ-wide column tile lies inside one tap (BJ divides C)
     int tap_r = 0, tap_s = 0, tap_c = 0;
     if (MODE == MODE_CONV) { const int rs = j0 / g.C; tap_c = j0 - rs * g.C; tap_r = rs / g.S; tap_s = rs - tap_r * g.S; }
 
-    u32x4 rp[NPI], rq[NPJ];
-    auto load_tile = [&](int mb) {
+    auto p_src = [&](int mb, int i) -> const T* {
+        const int row = p_r + i * RPI;
+        const int cc = p_slot ^ tn_swz<T, CPI>(row);
+        const int m = mb + row;
+        return (m < m_end && (i0 + cc * CE) < p.I) ? p.P + (long)m * p.ldp + i0 + cc * CE : nullptr;
+    };
+    auto q_src = [&](int mb, int i) -> const T* {   // dense / conv only
+        const int row = q_r + i * RPJ;
+        const int cc = q_slot ^ tn_swz<T, CPJ>(row);
+        const int m = mb + row;
+        const bool ok = m < m_end && (j0 + cc * CE) < p.J;
+        if (MODE == MODE_DENSE) return ok ? p.Q + (long)m * p.ldq + j0 + cc * CE : nullptr;
+        const unsigned mm = ok ? (unsigned)m : 0u;
+        const unsigned b = fd_div(mm, g.div_hw);
+        const unsigned rem = mm - b * g.div_hw.d;
+        const unsigned oh = fd_div(rem, g.div_w);
+        const unsigned ow = rem - oh * g.div_w.d;
+        const int ih = (int)oh * g.sn + g.base_h + tap_r, iw = (int)ow * g.sn + g.base_w + tap_s;
+        return (ok && ih >= 0 && iw >= 0 && ih < g.H && iw < g.W)
+                   ? p.Q + (long)b * g.img_stride + ((long)ih * g.W + iw) * g.C + tap_c + cc * CE : nullptr;
+    };
+    typedef __attribute__((address_space(3))) char lds_char;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    auto dma_tile = [&](int st, int mb) {
+        lds_char* base = (lds_char*)lds + st * (STAGE * 16);
 #pragma unroll
         for (int i = 0; i < NPI; ++i) {
-            const int row = p_r + i * RPI;
-            const int m = mb + row;
-            rp[i] = (row < BMK && m < m_end && p_col_ok) ? ld16(p.P + (long)m * p.ldp + i0 + p_cc * CE) : zero16();
+            const T* src = p_src(mb, i);
+            const void* sp = src ? (const void*)src : (const void*)rpe_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)sp, (__attribute__((address_space(3))) void*)(base + (i * 4 + wave) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NPJ; ++i) {
+            const T* src = q_src(mb, i);
+            const void* sp = src ? (const void*)src : (const void*)rpe_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)sp, (__attribute__((address_space(3))) void*)(base + PT * 16 + (i * 4 + wave) * 1024), 16, 0, 0);
+        }
+    };
+    u32x4 rp[NPI], rq[NPJ];
+    auto load_tile = [&](int mb) {  // register staging (stem)
+#pragma unroll
+        for (int i = 0; i < NPI; ++i) { const T* src = p_src(mb, i); rp[i] = src ? ld16(src) : zero16(); }
+#pragma unroll
+        for (int i = 0; i < NPJ; ++i) {
             const int row = q_r + i * RPJ;
+            const int cc = q_slot ^ tn_swz<T, CPJ>(row);
             const int m = mb + row;
-            u32x4 v = zero16();
-            const bool ok = row < BMK && m < m_end && q_col_ok;
-            if (MODE == MODE_DENSE) {
-                if (ok) v = ld16(p.Q + (long)m * p.ldq + j0 + q_cc * CE);
-            } else {
-                const unsigned mm = ok ? (unsigned)m : 0u;
-                const unsigned b = fd_div(mm, g.div_hw);
-                const unsigned rem = mm - b * g.div_hw.d;
-                const unsigned oh = fd_div(rem, g.div_w);
-                const unsigned ow = rem - oh * g.div_w.d;
-                const int hb = (int)oh * g.sn + g.base_h, wb = (int)ow * g.sn + g.base_w;
-                if (MODE == MODE_CONV) {
-                    const int ih = hb + tap_r, iw = wb + tap_s;
-                    if (ok && ih >= 0 && iw >= 0 && ih < g.H && iw < g.W)
-                        v = ld16(p.Q + (long)b * g.img_stride + ((long)ih * g.W + iw) * g.C + tap_c + q_cc * CE);
-                } else {
-                    v = stem_chunk<T>(p.Q, (long)b * g.img_stride, hb, wb, g.H, g.W, j0 + q_cc * CE, ok);
-                }
-            }
-            rq[i] = v;
+            const bool ok = m < m_end && (j0 + cc * CE) < p.J;
+            const unsigned mm = ok ? (unsigned)m : 0u;
+            const unsigned b = fd_div(mm, g.div_hw);
+            const unsigned rem = mm - b * g.div_hw.d;
+            const unsigned oh = fd_div(rem, g.div_w);
+            const unsigned ow = rem - oh * g.div_w.d;
+            if (MODE == MODE_STEM) rq[i] = stem_chunk<T>(p.Q, (long)b * g.img_stride, (int)oh * g.sn + g.base_h, (int)ow * g.sn + g.base_w, g.H, g.W, j0 + cc * CE, ok);
+            else { const T* src = q_src(mb, i); rq[i] = src ? ld16(src) : zero16(); }
         }
     };
     auto store_tile = [&](int st) {
         u32x4* base = lds + st * STAGE;
 #pragma unroll
-        for (int i = 0; i < NPI; ++i) { const int row = p_r + i * RPI; if (row < BMK) base[row * CPI + (p_cc ^ tn_swz<T, CPI>(row))] = rp[i]; }
+        for (int i = 0; i < NPI; ++i) base[(p_r + i * RPI) * CPI + p_slot] = rp[i];
 #pragma unroll
-        for (int i = 0; i < NPJ; ++i) { const int row = q_r + i * RPJ; if (row < BMK) base[PT + row * CPJ + (q_cc ^ tn_swz<T, CPJ>(row))] = rq[i]; }
+        for (int i = 0; i < NPJ; ++i) base[PT + (q_r + i * RPJ) * CPJ + q_slot] = rq[i];
     };
 
     f32x4 acc[FI][FJ];
@@ -530,14 +556,8 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
         for (int b = 0; b < FJ; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nsteps = (m_end - m_begin + BMK - 1) / BMK;
-    load_tile(m_begin);
-    store_tile(0);
-    __syncthreads();
     const int fg = lane >> 4, fl = lane & 15;
-    for (int st = 0; st < nsteps; ++st) {
-        const int cur = st & 1;
-        const bool more = st + 1 < nsteps;
-        if (more) load_tile(m_begin + (st + 1) * BMK);
+    auto compute = [&](int cur) {
         const char* pb = (const char*)(lds + cur * STAGE);
         const char* qb = (const char*)(lds + cur * STAGE + PT);
         if (sizeof(T) == 2) {
@@ -601,8 +621,40 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
                     for (int b = 0; b < FJ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[a], qf[b], acc[a][b], 0, 0, 0);
             }
         }
-        if (more) store_tile(cur ^ 1);
+    };
+    if (DMA) {
+        constexpr int NI = NPI + NPJ;
+        constexpr int PF = NSTAGE - 1;
+#pragma unroll
+        for (int t = 0; t < PF; ++t)
+            if (t < nsteps) dma_tile(t, m_begin + t * BMK);
+        {
+            const int newer = (nsteps < PF ? nsteps : PF) - 1;
+            if (newer >= 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        int slot = 0;
+        for (int st = 0; st < nsteps; ++st) {
+            if (st + PF < nsteps) { int s2 = slot + PF; if (s2 >= NSTAGE) s2 -= NSTAGE; dma_tile(s2, m_begin + (st + PF) * BMK); }
+            compute(slot);
+            int newer = nsteps - 2 - st;
+            if (newer > PF - 1) newer = PF - 1;
+            if (newer >= 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (++slot == NSTAGE) slot = 0;
+        }
+    } else {
+        load_tile(m_begin);
+        store_tile(0);
         __syncthreads();
+        for (int st = 0; st < nsteps; ++st) {
+            const int cur = st & 1;
+            const bool more = st + 1 < nsteps;
+            if (more) load_tile(m_begin + (st + 1) * BMK);
+            compute(cur);
+            if (more) store_tile(cur ^ 1);
+            __syncthreads();
+        }
     }
     // D[i = ..+4*fg+reg][j = ..+fl]: for a fixed register 16 lanes add 64 contiguous bytes of one row
 #pragma unroll
@@ -686,7 +738,12 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
     a.rows_per_split = (int)rps;
     a.splits = (int)((a.M + rps - 1) / rps);
     const long nwg = tiles * a.splits;
-    hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE>), dim3((unsigned)nwg), dim3(256), 0, s, a);
+    // A/B on one MI355X (bs256 ResNet shapes): the LDS-DMA 3-slot ring is 8 % SLOWER here than 2-stage register staging
+    // (5.67 vs 5.22 ms per step; 48 KB LDS costs occupancy and the transposed reads, not the staging, bound this kernel).
+    // Register staging is the default; RPE_TN_DMA=1 selects the ring.
+    static const bool dma = getenv("RPE_TN_DMA") != nullptr;
+    if (dma) hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, false>), dim3((unsigned)nwg), dim3(256), 0, s, a);
     RPE_CHECK_LAUNCH();
     return 0;
 }
