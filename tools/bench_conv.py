@@ -22,7 +22,7 @@ def timeit(fn, n=5):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
 
-tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0, "dgrad+bn(y)": 0.0, "dgrad+bn(a)": 0.0}
 print("%-28s %8s | %8s %7s | %8s %7s | %8s %7s" % ("shape (Cin->Cout k s H)", "GFLOP", "fwd ms", "TF/s", "dgrad ms", "TF/s", "wgrad ms", "TF/s"))
 for ci, co, k, s, h, cnt in SHAPES:
     p = k // 2
@@ -35,6 +35,12 @@ for ci, co, k, s, h, cnt in SHAPES:
     tf = timeit(lambda: ops.conv2d_fwd(x, w, s, p, want_stats=True))
     td = timeit(lambda: ops.conv2d_dgrad(dy, wd, (B, h, h, ci), s, p))
     tw = timeit(lambda: ops.conv2d_wgrad(x, dy, k, s, p))
-    for key, t in (("fwd", tf), ("dgrad", td), ("wgrad", tw)): tot[key] += t * cnt
-    print("%4d->%4d k%d s%d H%-3d x%d %12.1f | %8.3f %7.1f | %8.3f %7.1f | %8.3f %7.1f" % (ci, co, k, s, h, cnt, fl / 1e9, tf, fl / tf / 1e9, td, fl / td / 1e9, tw, fl / tw / 1e9))
+    # data gradient with the producing layer's BN-backward reduction fused (mask from y / from a_out + addend)
+    yprev = torch.randn(B, h, h, ci, device="cuda").to(dtype)
+    aprev = torch.relu(yprev)
+    mean = torch.zeros(ci, device="cuda"); invstd = torch.ones(ci, device="cuda"); sc = torch.ones(ci, device="cuda"); sh = torch.zeros(ci, device="cuda")
+    t2 = timeit(lambda: ops.conv2d_dgrad_bn(dy, wd, (B, h, h, ci), s, p, yprev, mean, invstd, scale=sc, shift=sh))
+    t1 = timeit(lambda: ops.conv2d_dgrad_bn(dy, wd, (B, h, h, ci), s, p, yprev, mean, invstd, a_out=aprev, addend=aprev))
+    for key, t in (("fwd", tf), ("dgrad", td), ("wgrad", tw), ("dgrad+bn(y)", t2), ("dgrad+bn(a)", t1)): tot[key] += t * cnt
+    print("%4d->%4d k%d s%d H%-3d x%d %7.1f | %6.3f %6.1f | %6.3f %6.1f | %6.3f %6.1f | bn(y) %6.3f bn(a) %6.3f" % (ci, co, k, s, h, cnt, fl / 1e9, tf, fl / tf / 1e9, td, fl / td / 1e9, tw, fl / tw / 1e9, t2, t1))
 print("weighted totals per step (ms):", {k: round(v, 2) for k, v in tot.items()})
