@@ -338,49 +338,32 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
             if (bn_mode == 2) { csc[j] = p.bn_scale[n + j]; csh[j] = p.bn_shift[n + j]; }
         }
     }
-    // Epilogue operands of one 16-row fragment (NPASS rows per lane), fetched as raw 16-byte chunks one fragment AHEAD of
-    // their use so their latency hides under the LDS staging / math of the previous fragment.
-    constexpr int OPC = (CE == 8) ? 1 : 2;   // 16-byte chunks per 8 channels
-    struct Pre { u32x4 ad[NPASS][OPC], yy[NPASS][OPC], aa[NPASS][OPC]; long m[NPASS]; };
-    auto fetch8 = [&](const T* base, long off, bool vec, u32x4* out) {
+    auto load8 = [&](const T* base, long off, bool vec, float* out) {
         if (vec) {
+            if (CE == 8) { chunk_to_f<T>(ld16(base + off), out); }
+            else { chunk_to_f<T>(ld16(base + off), out); chunk_to_f<T>(ld16(base + off + 4), out + 4); }
+        } else {
 #pragma unroll
-            for (int c = 0; c < OPC; ++c) out[c] = ld16(base + off + c * CE);
-        } else {  // ragged / unaligned rows: element loads, re-packed so the consumer code is the same
-            float t[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = (n + j < p.N) ? Elem<T>::to_f(base[off + j]) : 0.f;
-#pragma unroll
-            for (int c = 0; c < OPC; ++c) out[c] = f_to_chunk<T>(t + c * CE);
+            for (int j = 0; j < 8; ++j) out[j] = (n + j < p.N) ? Elem<T>::to_f(base[off + j]) : 0.f;
         }
     };
-    auto unpack8 = [&](const u32x4* in, float* out) {
 #pragma unroll
-        for (int c = 0; c < OPC; ++c) chunk_to_f<T>(in[c], out + c * CE);
-    };
-    auto prefetch = [&](int qf, Pre& pre) {
+    for (int qf = 0; qf < FM; ++qf) {
+        __syncthreads();
 #pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const long m = out_row(wave_m * WM + qf * 16 + ps * RPP + erow);
-            pre.m[ps] = (m >= 0 && ncol_ok) ? m : -1;
-            if (pre.m[ps] < 0) continue;
-            if (p.addend) fetch8(p.addend, m * p.ld_add + n, vec_add, pre.ad[ps]);
-            if (bn_mode) fetch8(p.bn_y, m * p.ldc + n, vec_c, pre.yy[ps]);
-            if (bn_mode == 1) fetch8(p.bn_a, m * p.ldc + n, vec_c, pre.aa[ps]);
-        }
-    };
-    auto finish = [&](const Pre& pre) {
+        for (int a = 0; a < FN; ++a) *(f32x4*)(stg + fr * LDW + a * 16 + fc * 4) = acc[a][qf];
+        __syncthreads();
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int r = ps * RPP + erow;
+            const long m = out_row(wave_m * WM + qf * 16 + r);
             float v[8];
             {
                 const f32x4 t0 = *(const f32x4*)(stg + r * LDW + echk * 8);
                 const f32x4 t1 = *(const f32x4*)(stg + r * LDW + echk * 8 + 4);
                 v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
             }
-            const long m = pre.m[ps];
-            if (m < 0) continue;
+            if (m < 0 || !ncol_ok) continue;
             if (p.stats_part && !bn_mode) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { cs[j] += v[j]; cq[j] += v[j] * v[j]; }
@@ -391,15 +374,15 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
             }
             if (p.addend) {
                 float ad[8];
-                unpack8(pre.ad[ps], ad);
+                load8(p.addend, m * p.ld_add + n, vec_add, ad);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] += ad[j];
             }
             if (bn_mode) {
                 // v = dA (gradient wrt the BN output after ReLU).  dz = dA * [a_out > 0]; partial sums of dz and dz*xhat.
                 float yy[8], aa[8];
-                unpack8(pre.yy[ps], yy);
-                if (bn_mode == 1) unpack8(pre.aa[ps], aa);
+                load8(p.bn_y, m * p.ldc + n, vec_c, yy);
+                if (bn_mode == 1) load8(p.bn_a, m * p.ldc + n, vec_c, aa);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const bool on = bn_mode == 1 ? (aa[j] > 0.f) : (bn_mode == 2 ? (fmaf(yy[j], csc[j], csh[j]) > 0.f) : true);
@@ -415,32 +398,13 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
             }
             T* cp = p.C + m * p.ldc + n;
             if (vec_c) {
-#pragma unroll
-                for (int c = 0; c < OPC; ++c) *(u32x4*)(cp + c * CE) = f_to_chunk<T>(v + c * CE);
+                if (CE == 8) { *(u32x4*)cp = f_to_chunk<T>(v); }
+                else { *(u32x4*)cp = f_to_chunk<T>(v); *(u32x4*)(cp + 4) = f_to_chunk<T>(v + 4); }
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) if (n + j < p.N) cp[j] = Elem<T>::from_f(v[j]);
             }
         }
-    };
-    // the staging rows are private to a wave: LDS executes a wave's accesses in order, so a wave-level fence between its
-    // writes and its (cross-lane) reads is enough -- the workgroup barrier is only needed once, after the K loop.
-    auto wave_sync = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-    Pre preA, preB;
-    prefetch(0, preA);
-    __syncthreads();   // every wave is done with the K loop's LDS tiles
-#pragma unroll
-    for (int qf = 0; qf < FM; ++qf) {
-        wave_sync();   // this wave's reads of the previous fragment are done
-#pragma unroll
-        for (int a = 0; a < FN; ++a) *(f32x4*)(stg + fr * LDW + a * 16 + fc * 4) = acc[a][qf];
-        wave_sync();
-        if (qf & 1) { if (qf + 1 < FM) prefetch(qf + 1, preA); finish(preB); }
-        else { if (qf + 1 < FM) prefetch(qf + 1, preB); finish(preA); }
     }
     if (p.stats_part) {
         // column partials: lanes with the same chunk differ in erow -> butterfly over the row bits, then pairs of 64-row
