@@ -98,13 +98,13 @@ def main():
     b = synthetic_batch((args.batch,), 1234 + rank, device=dev)
     batch = (b["img"], None, b["x0bar"], b["x0"], None, b["obj"])
 
-    # first step materialises the arena; then make replicas identical and set up the gradient reduction
-    train_step(model, batch, criterion, opt, True, "train", None)
+    # build the parameter arena, make replicas identical, attach the staged gradient reduction -- all before the first step
+    model._materialize(dev)
     sync = None
     if world > 1:
         broadcast_parameters(model._arena.flat, list(model.buffers()))
-        sync = GradSync(model._arena.grad)
-    for _ in range(max(0, args.warmup - 1)):
+        sync = GradSync(model._arena.grad).attach(model)   # slices are all-reduced under the backward
+    for _ in range(args.warmup):
         train_step(model, batch, criterion, opt, True, "train", sync)
 
     def fence():

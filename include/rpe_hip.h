@@ -231,6 +231,12 @@ enum { RPE_PROF_CONV_FWD = 0, RPE_PROF_CONV_DGRAD = 1, RPE_PROF_CONV_WGRAD = 2, 
        RPE_PROF_OTHER = 5, RPE_PROF_NUM = 6 };
 int rpe_resnet50_profile(rpe_resnet50_t* e, int enable);
 int rpe_resnet50_profile_read(rpe_resnet50_t* e, float* ms, int* launches, double* flops, double* bytes);
+/* The same backward in stages, so a data-parallel caller can all-reduce finished gradients while the rest is computed:
+ * begin (fc + avgpool) -> blocks(count, join=1) ... until all 16 blocks are done -> end (stem).  After blocks(.., join=1)
+ * every gradient of the blocks processed so far is complete in stream order on `stream`. */
+int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_features, long ld_d_features, void* stream);
+int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int join, void* stream);
+int rpe_resnet50_backward_end(rpe_resnet50_t* e, int use_d_early, void* stream);
 /* debugging / parity: device pointer, rows and channels of a named intermediate (e.g. "layer1.0.y1") */
 int rpe_resnet50_tensor(const rpe_resnet50_t* e, const char* name, const void** ptr, long* rows, int* channels);
 

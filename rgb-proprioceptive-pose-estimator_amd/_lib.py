@@ -88,6 +88,9 @@ _SPEC = {
     "rpe_resnet50_backward": (I, [P, P, L, I, P]),
     "rpe_resnet50_profile": (I, [P, I]),
     "rpe_resnet50_profile_read": (I, [P, POINTER(c_float), POINTER(c_int), POINTER(c_double), POINTER(c_double)]),
+    "rpe_resnet50_backward_begin": (I, [P, P, L, P]),
+    "rpe_resnet50_backward_blocks": (I, [P, I, I, P]),
+    "rpe_resnet50_backward_end": (I, [P, I, P]),
     "rpe_resnet50_tensor": (I, [P, c_char_p, POINTER(c_void_p), POINTER(c_long), POINTER(c_int)]),
 }
 # entry points whose int return value is data, not a status

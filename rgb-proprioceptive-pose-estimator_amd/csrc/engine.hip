@@ -81,6 +81,8 @@ struct rpe_resnet50 {
     std::vector<Named> named;
     int train_mode = 0;
     int fused_tiles = 0;
+    void* cur[4] = {nullptr, nullptr, nullptr, nullptr};  // rotating gradient buffers of a backward in progress
+    int bwd_next = -2;                                     // next block of a staged backward (-1: blocks done, -2: idle)
     // conv/fc weight gradients are accumulated with atomics: when the bound gradient tensors form one contiguous block
     // (they do in the flat arena) it is zeroed by ONE memset per backward instead of 54 (15 us each)
     rpe_pack_desc* pack_tab = nullptr;   // device table for the one-launch weight packing
@@ -475,7 +477,18 @@ static int wgrad(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, void*
     return 0;
 }
 
-extern "C" int rpe_resnet50_backward(rpe_resnet50_t* e, const float* d_features, long ld_d_features, int use_d_early, void* stream) {
+static int join_side(rpe_resnet50* e, hipStream_t s) {
+    // everything the side stream produced so far (weight gradients) is complete before the caller's next launch on s
+    if (e->overlap && e->side) {
+        hipEvent_t done = sync_event(e);
+        if (!done) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
+        HIPTRY(hipEventRecord(done, e->side));
+        HIPTRY(hipStreamWaitEvent(s, done, 0));
+    }
+    return 0;
+}
+
+extern "C" int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_features, long ld_d_features, void* stream) {
     if (!e || !e->bound) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward: engine not bound");
     if (!e->fwd_done) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward: no training-mode forward to differentiate");
     const int np = (int)e->pnames.size();
@@ -501,12 +514,22 @@ extern "C" int rpe_resnet50_backward(rpe_resnet50_t* e, const float* d_features,
     TRY(rpe_linear_fwd(RPE_F32, d_features, (int)ld_d_features, e->fc_wt, e->latent_pad, nullptr, e->d_pooled, 2048, e->B, 2048, e->latent_pad, 0,
                        nullptr, 0, stream));
     ConvL& last = e->convs[e->blocks.back().c3];
-    void *gA = e->G[0], *gB = e->G[1], *gC = e->G[2], *gD = e->G[3];
-    TRY(rpe_avgpool_bwd(e->dtype, e->d_pooled, gA, e->B, last.Ho * last.Wo, 2048, stream));
-    // Per block, entering with gA = dz3 (ReLU-masked gradient at the block output; for the last block: the raw dA).
-    // Every data-gradient GEMM also applies the ReLU mask of the layer it feeds and emits that layer's BN-backward
-    // partial sums (rpe_conv2d_dgrad_bn), so each BN costs one more pass (dz, y -> dy) instead of two full passes.
-    for (int bi = (int)e->blocks.size() - 1; bi >= 0; --bi) {
+    for (int i = 0; i < 4; ++i) e->cur[i] = e->G[i];
+    TRY(rpe_avgpool_bwd(e->dtype, e->d_pooled, e->cur[0], e->B, last.Ho * last.Wo, 2048, stream));
+    e->bwd_next = (int)e->blocks.size() - 1;
+    return 0;
+}
+
+// Backward through the next `count` bottleneck blocks (descending).  On return every gradient of those blocks is complete
+// in stream order on `stream` (the side stream is joined), so the caller may start reducing them across replicas.
+// Per block, entering with gA = dz3 (ReLU-masked gradient at the block output; for the last block: the raw dA).
+// Every data-gradient GEMM also applies the ReLU mask of the layer it feeds and emits that layer's BN-backward
+// partial sums (rpe_conv2d_dgrad_bn), so each BN costs one more pass (dz, y -> dy) instead of two full passes.
+extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int join, void* stream) {
+    if (!e || !e->bound || e->bwd_next < -1) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward_blocks: call rpe_resnet50_backward_begin first");
+    void *gA = e->cur[0], *gB = e->cur[1], *gC = e->cur[2], *gD = e->cur[3];
+    int bi = e->bwd_next;
+    for (; bi >= 0 && count > 0; --bi, --count) {
         Block& b = e->blocks[bi];
         ConvL &c1 = e->convs[b.c1], &c2 = e->convs[b.c2], &c3 = e->convs[b.c3];
         const void* x_in = bi == 0 ? (const void*)e->pool : (const void*)e->convs[e->blocks[bi - 1].c3].a;
@@ -543,7 +566,16 @@ extern "C" int rpe_resnet50_backward(rpe_resnet50_t* e, const float* d_features,
         }
         void* t = gA; gA = gD; gD = t;
     }
-    void *g0 = gA, *g1 = gB;
+    e->cur[0] = gA; e->cur[1] = gB; e->cur[2] = gC; e->cur[3] = gD;
+    e->bwd_next = bi;
+    if (join) TRY(join_side(e, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int rpe_resnet50_backward_end(rpe_resnet50_t* e, int use_d_early, void* stream) {
+    if (!e || !e->bound || e->bwd_next != -1) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward_end: blocks not finished");
+    hipStream_t s = (hipStream_t)stream;
+    void *g0 = e->cur[0], *g1 = e->cur[1];
     // stem: g0 = gradient wrt maxpool output
     ConvL& st = e->convs[0];
     TRY(writable(e, g1, stream));
@@ -552,14 +584,15 @@ extern "C" int rpe_resnet50_backward(rpe_resnet50_t* e, const float* d_features,
     if (hipError_t he = hipMemsetAsync(e->stem_dw, 0, 64 * 256 * 4, s)) return rpe_set_error_hip(he, __FILE__, __LINE__);
     PROF(e, RPE_PROF_CONV_WGRAD, stream, rpe_stem_conv_wgrad(e->dtype, e->x4, g1, e->stem_dw, e->B, e->H, e->W, stream));
     TRY(rpe_unpack_stem_grad(e->stem_dw, e->grads[st.p_w], stream));
-    // join: everything the side stream produced (weight gradients) is complete before the caller's next launch
-    if (e->overlap && e->side) {
-        hipEvent_t done = sync_event(e);
-        if (!done) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
-        HIPTRY(hipEventRecord(done, e->side));
-        HIPTRY(hipStreamWaitEvent(s, done, 0));
-    }
+    TRY(join_side(e, s));
+    e->bwd_next = -2;
     return 0;
+}
+
+extern "C" int rpe_resnet50_backward(rpe_resnet50_t* e, const float* d_features, long ld_d_features, int use_d_early, void* stream) {
+    TRY(rpe_resnet50_backward_begin(e, d_features, ld_d_features, stream));
+    TRY(rpe_resnet50_backward_blocks(e, 1 << 20, 0, stream));
+    return rpe_resnet50_backward_end(e, use_d_early, stream);
 }
 
 extern "C" int rpe_resnet50_tensor(const rpe_resnet50_t* e, const char* name, const void** ptr, long* rows, int* channels) {

@@ -21,10 +21,13 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+            # RPE_DIST_BACKEND=gloo lets several ranks share one GPU for a functional rehearsal (RCCL wants one GPU per rank)
+            backend = os.environ.get("RPE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend, rank=rank, world_size=world)
+    if torch.cuda.is_available():
+        local = local % torch.cuda.device_count()
     return rank, world, local
 
 
@@ -41,6 +44,12 @@ class GradSync:
     xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of M bytes moves 2*(P-1)/P*M
     through one link, so a few large buckets (default 32 MiB) keep per-call latency negligible while letting
     the first buckets start before the last ones are queued.
+
+    Two ways to use it:
+      * all_reduce(): one shot after backward (what the reference's DataParallel gather amounts to);
+      * attach(model): the model's backward then calls stage_done(name) as the gradients of "fc" (trunk fc + all head
+        layers), "layer4" .. "layer1", "stem" become final, and each stage's contiguous arena slice is reduced
+        asynchronously while the earlier layers are still being differentiated; finish() waits for all of them.
     """
 
     def __init__(self, flat_grad, bucket_bytes=32 << 20, group=None):
@@ -48,17 +57,75 @@ class GradSync:
         self.group = group
         self.bucket = max(1, bucket_bytes // flat_grad.element_size())
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._works = []
+        self._slices = None
+        self._seen = None
 
-    def buckets(self):
-        n = self.flat.numel()
-        return [(lo, min(n, lo + self.bucket)) for lo in range(0, n, self.bucket)]
+    def buckets(self, lo=0, hi=None):
+        hi = self.flat.numel() if hi is None else hi
+        return [(a, min(hi, a + self.bucket)) for a in range(lo, hi, self.bucket)]
+
+    def reduce_range(self, lo, hi):
+        if self.world == 1 or hi <= lo:
+            return
+        for a, b in self.buckets(lo, hi):
+            self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self._slices is not None and self._seen is not None:
+            if self.world > 1 and self._seen != set(self._slices):
+                raise RuntimeError("GradSync: stages %s were never reduced" % sorted(set(self._slices) - self._seen))
+            self._seen = set()
 
     def all_reduce(self):
-        if self.world == 1:
-            return
-        works = [dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for lo, hi in self.buckets()]
-        for w in works:
-            w.wait()
+        self.reduce_range(0, self.flat.numel())
+        self.finish()
+
+    # -- staged mode --------------------------------------------------------------------------------
+    def attach(self, model):
+        """Derive the arena slice of every backward stage of `model` and register with it."""
+        self._slices = stage_slices(model)
+        self._seen = set()
+        model._grad_sync = self
+        return self
+
+    @property
+    def staged(self):
+        return self._slices is not None
+
+    def stage_done(self, name):
+        lo, hi = self._slices[name]
+        self._seen.add(name)
+        self.reduce_range(lo, hi)
+
+
+def stage_slices(model):
+    """name -> [lo, hi) element range of the flat gradient arena, in backward completion order.
+
+    The arena lays parameters out in registration order: trunk (conv1/bn1, layer1..layer4, fc) first, then the heads, so
+    every stage is one contiguous range: "fc" = trunk fc + every head layer (their gradients exist before the trunk's
+    backward starts), then layer4, layer3, layer2, and finally layer1 + the stem."""
+    arena = model._arena
+    if arena is None:
+        raise RuntimeError("stage_slices: the model has no parameter arena yet (run one forward on the device)")
+    trunk = model.trunk
+    off = {id(p): o for p, o in zip(arena.params, arena.offsets)}
+
+    def first(mod):
+        return min(off[id(p)] for p in mod.parameters())
+
+    marks = [("stem", 0), ("layer2", first(trunk.layer2)), ("layer3", first(trunk.layer3)), ("layer4", first(trunk.layer4)),
+             ("fc", first(trunk.fc)), ("end", arena.numel)]
+    if first(trunk.conv1) != 0 or [m[1] for m in marks] != sorted(m[1] for m in marks):
+        raise RuntimeError("stage_slices: trunk parameters are not laid out first and in order in the arena")
+    s = {"stem": (0, marks[1][1]), "layer2": (marks[1][1], marks[2][1]), "layer3": (marks[2][1], marks[3][1]),
+         "layer4": (marks[3][1], marks[4][1]), "fc": (marks[4][1], marks[5][1])}
+    # layer1 finishes before the stem but shares its slice: reduce the slice once, when the stem is done
+    s["layer1"] = (0, 0)
+    return s
 
 
 def broadcast_parameters(flat_params, buffers=(), src=0, group=None):

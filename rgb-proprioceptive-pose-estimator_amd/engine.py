@@ -203,5 +203,19 @@ class _Plan:
         lib.rpe_resnet50_tensor(self.handle, name.encode(), ctypes.byref(ptr), ctypes.byref(rows), ctypes.byref(ch))
         return self._alias(ptr.value, (rows.value, ch.value))
 
-    def backward(self, d_features, use_d_early):
-        lib.rpe_resnet50_backward(self.handle, ops._p(d_features), d_features.stride(0), int(use_d_early), ops._stream())
+    STAGES = (("layer4", 3), ("layer3", 6), ("layer2", 4), ("layer1", 3))  # bottleneck blocks per stage, in backward order
+
+    def backward(self, d_features, use_d_early, stage_done=None):
+        """stage_done(name): optional callback fired when the gradients of a stage ("fc", "layer4" .. "layer1", "stem") are
+        complete in stream order -- the data-parallel path starts their all-reduce there, under the rest of the backward."""
+        s = ops._stream()
+        if stage_done is None:
+            lib.rpe_resnet50_backward(self.handle, ops._p(d_features), d_features.stride(0), int(use_d_early), s)
+            return
+        lib.rpe_resnet50_backward_begin(self.handle, ops._p(d_features), d_features.stride(0), s)
+        stage_done("fc")
+        for name, nblocks in self.STAGES:
+            lib.rpe_resnet50_backward_blocks(self.handle, nblocks, 1, s)
+            stage_done(name)
+        lib.rpe_resnet50_backward_end(self.handle, int(use_d_early), s)
+        stage_done("stem")

@@ -121,6 +121,7 @@ class PoseModelBase(nn.Module):
         self._heads_registered = register_heads
         self._arena = None
         self._aux_op = None
+        self._grad_sync = None   # dist.GradSync attached by the data-parallel loop (staged all-reduce under backward)
         self.rollout = False
 
     # -- helpers --------------------------------------------------------------------------------
@@ -185,7 +186,8 @@ class PoseModelBase(nn.Module):
         if use_early:
             L = self.latent_dim
             self._aux_op.bwd(d_rows[:, L:L + self.aux_latent_dim])
-        self._plan.backward(d_rows, use_early)
+        sync = getattr(self, "_grad_sync", None)
+        self._plan.backward(d_rows, use_early, None if sync is None else sync.stage_done)
 
     @staticmethod
     def _pad_rows(t, cols):

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from ..dist import GradSync, shard_bounds
+from ..dist import GradSync, broadcast_parameters, shard_bounds
 
 
 def _writer(logging):
@@ -49,7 +49,10 @@ def train_step(model, batch, criterion, optimizer, train_obj_pose, phase="train"
         if phase == "train":
             loss.backward()
             if grad_sync is not None:
-                grad_sync.all_reduce()
+                if grad_sync.staged:   # slices were launched under the backward (dist.GradSync.attach): just wait
+                    grad_sync.finish()
+                else:
+                    grad_sync.all_reduce()
             optimizer.step()
     return loss.detach(), pos_err, ori_err
 
@@ -68,12 +71,18 @@ def train(model, dataset, criterion, optimizer, num_epochs, num_train_episodes_p
     if device == "cpu":
         raise RuntimeError("train(): the pose train step runs on the MI355X HIP path only (device='cuda:N'); there is no CPU fallback")
     model.cuda()
+    # Build the flat parameter arena now, so replicas can be made identical and the gradient reduction attached BEFORE the
+    # first optimizer step (Adam moments would otherwise diverge between ranks).
+    model._materialize(torch.device("cuda", torch.cuda.current_device()))
+    grad_sync = None
+    if world > 1:
+        broadcast_parameters(model._arena.flat, list(model.buffers()))
+        grad_sync = GradSync(model._arena.grad).attach(model)
     seq = model.sequence_length if model.requires_sequence else 1
     fname = "{}_{}_{}hzn_{}ep_{}.pth".format(type(model).__name__, type(dataset.env).__name__, dataset.env.horizon,
                                              num_epochs * num_train_episodes_per_epoch, dt_string)
     if save_model and rank == 0:
         print("\nFile name saved:\n{}\n".format(fname))
-    grad_sync = None
     for epoch in range(num_epochs):
         if logging and rank == 0:
             print("\n" + "-" * 10 + "\nEpoch {}/{}\n".format(epoch, num_epochs - 1) + "-" * 10)
@@ -92,11 +101,7 @@ def train(model, dataset, criterion, optimizer, num_epochs, num_train_episodes_p
                     depth = None if depth is None else depth[0]
                     x1 = None if x1 is None else x1[0]
                     obj = None if obj is None else obj[0]
-                if phase == "train" and world > 1 and grad_sync is None and getattr(model, "_arena", None) is not None:
-                    grad_sync = GradSync(model._arena.grad)
                 loss, pe, oe = train_step(model, (img, depth, x0bar, x0, x1, obj), criterion, optimizer, train_obj_pose, phase, grad_sync)
-                if phase == "train" and world > 1 and grad_sync is None:  # arena exists only after the first forward
-                    grad_sync = GradSync(model._arena.grad)
                 sums += torch.stack([loss.double(), pe.double(), oe.double()])
             if world > 1:
                 dist.all_reduce(sums)
