@@ -138,7 +138,6 @@ def main():
     flops = (ctypes.c_double * 6)()
     byts = (ctypes.c_double * 6)()
     lib.rpe_resnet50_profile_read(plan.handle, ms, launches, flops, byts)
-    lib.rpe_resnet50_profile(plan.handle, 0)
     log("[bench] profiled pass read back")
     fam = {}
     for i, c in enumerate(CATS):
@@ -146,13 +145,41 @@ def main():
             fam[c] = {"ms_per_step": ms[i] / n_prof, "launches_per_step": launches[i] // n_prof,
                       "tflops": (flops[i] / 1e12) / (ms[i] / n_prof / 1e3) if flops[i] else None,
                       "gbs": (byts[i] / 1e9) / (ms[i] / n_prof / 1e3) if byts[i] else None}
-    dom = max((c for c in fam if c.startswith("conv")), key=lambda c: fam[c]["ms_per_step"])
-    di = CATS.index(dom)
-    dom_ms = ms[di] / launches[di]
-    achieved = (flops[di] / (launches[di] / n_prof)) / 1e12 / (dom_ms / 1e3)   # algorithmic FLOPs per launch / avg launch duration
-    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
-                "avg_launch_ms": round(dom_ms, 4), "launches_per_step": launches[di] // n_prof,
+    # the same spans per kernel SYMBOL (names as rocprofv3 lists them, short form): the roofline line is for the symbol with
+    # the largest summed time; achieved = its algorithmic FLOPs per launch / its average launch duration
+    buf = ctypes.create_string_buffer(1 << 16)
+    nbytes = lib.rpe_resnet50_profile_kernels(plan.handle, buf, len(buf))
+    syms = []
+    for line in buf.raw[:max(0, nbytes)].decode().splitlines():
+        name, cnt, tms, fl, by = line.split(";")
+        syms.append({"kernel": name, "launches": int(cnt), "ms": float(tms), "flops": float(fl), "bytes": float(by)})
+    lib.rpe_resnet50_profile(plan.handle, 0)
+    gemm = [k for k in syms if k["flops"] > 0]
+    dom = max(gemm, key=lambda k: k["ms"])
+    avg_ms = dom["ms"] / dom["launches"]
+    tflops = dom["flops"] / dom["launches"] / 1e12 / (avg_ms / 1e3)
+    gbs = dom["bytes"] / dom["launches"] / 1e9 / (avg_ms / 1e3)
+    # which roof bounds this kernel: arithmetic intensity against the ridge peak_flops / peak_bytes
+    ai = dom["flops"] / max(dom["bytes"], 1.0)
+    hbm_bound = ai < PEAK_TFLOPS[args.dtype] * 1e12 / (PEAK_HBM_GBS * 1e9)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic_pmc.json")
+    if os.path.exists(tpath):  # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) of this same command, committed per round
+        for k in json.load(open(tpath)).get("kernels", []):
+            if k["kernel"] == dom["kernel"]:
+                traffic = round(k["per_launch_MB"] * 1e6)
+    roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": dom["kernel"],
+                "achieved": round(gbs if hbm_bound else tflops, 2), "peak": PEAK_HBM_GBS if hbm_bound else PEAK_TFLOPS[args.dtype],
+                "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": round((gbs / PEAK_HBM_GBS) if hbm_bound else (tflops / PEAK_TFLOPS[args.dtype]), 4), "traffic": traffic,
+                "avg_launch_ms": round(avg_ms, 4), "launches_per_step": dom["launches"] // n_prof,
+                "algorithmic_mb_per_launch": round(dom["bytes"] / dom["launches"] / 1e6, 2),
+                "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 2),
+                "arithmetic_intensity": round(ai, 1), "tflops": round(tflops, 1), "gbs": round(gbs, 1),
+                "kernels": sorted(({"kernel": k["kernel"], "launches_per_step": k["launches"] // n_prof, "ms_per_step": round(k["ms"] / n_prof, 3),
+                                    "tflops": round(k["flops"] / 1e12 / (k["ms"] / 1e3), 1) if k["flops"] else None,
+                                    "gbs": round(k["bytes"] / 1e9 / (k["ms"] / 1e3), 1) if k["bytes"] else None} for k in syms),
+                                  key=lambda k: -k["ms_per_step"])[:8],
                 "families": {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in fam.items()}}
 
     if rank == 0:

@@ -231,6 +231,11 @@ enum { RPE_PROF_CONV_FWD = 0, RPE_PROF_CONV_DGRAD = 1, RPE_PROF_CONV_WGRAD = 2, 
        RPE_PROF_OTHER = 5, RPE_PROF_NUM = 6 };
 int rpe_resnet50_profile(rpe_resnet50_t* e, int enable);
 int rpe_resnet50_profile_read(rpe_resnet50_t* e, float* ms, int* launches, double* flops, double* bytes);
+/* the same spans aggregated per kernel symbol: text lines "name;launches;ms;flops;bytes" (algorithmic work) written to buf; returns bytes written */
+long rpe_resnet50_profile_kernels(rpe_resnet50_t* e, char* buf, long buflen);
+/* short name of the implicit-GEMM kernel instance the last conv / Linear call on this thread launched,
+ * e.g. "nt_kernel<bf16,2,128,4,0,3,1>" = <dtype, waves_m, BN, chunks per K-row, mode, ring depth, role> */
+const char* rpe_last_kernel_name(void);
 /* The same backward in stages, so a data-parallel caller can all-reduce finished gradients while the rest is computed:
  * begin (fc + avgpool) -> blocks(count, join=1) ... until all 16 blocks are done -> end (stem).  After blocks(.., join=1)
  * every gradient of the blocks processed so far is complete in stream order on `stream`. */

@@ -91,6 +91,8 @@ _SPEC = {
     "rpe_resnet50_backward_begin": (I, [P, P, L, P]),
     "rpe_resnet50_backward_blocks": (I, [P, I, I, P]),
     "rpe_resnet50_backward_end": (I, [P, I, P]),
+    "rpe_resnet50_profile_kernels": (L, [P, P, L]),
+    "rpe_last_kernel_name": (c_char_p, []),
     "rpe_resnet50_tensor": (I, [P, c_char_p, POINTER(c_void_p), POINTER(c_long), POINTER(c_int)]),
 }
 # entry points whose int return value is data, not a status

@@ -71,6 +71,7 @@ static int conv_dgrad_t(const rpe_conv_desc* d, const void* dy, const void* w_cr
     a.M = d->batch * d->in_h * d->in_w; a.N = d->in_c; a.K = d->kh * d->kw * d->out_c;
     a.lda = d->out_c; a.ldb = a.K; a.ldc = d->in_c;
     a.addend = (const T*)addend; a.ld_add = d->in_c;
+    a.role = 1;
     if (bn) {
         if (!bn->y || !bn->mean || !bn->invstd || !bn->stats_part) return rpe_set_error(RPE_ERR_SHAPE, "conv2d_dgrad_bn: y, mean, invstd, stats_part are required");
         a.bn_mode = bn->a_out ? 1 : (bn->scale && bn->shift ? 2 : 3);
@@ -150,6 +151,7 @@ static int linear_fwd_t(const void* x, int ldx, const void* w, int ldw, const fl
     a.A = (const T*)x; a.Bw = (const T*)w; a.C = (T*)y;
     a.M = M; a.N = N; a.K = K; a.lda = ldx; a.ldb = ldw; a.ldc = ldy;
     a.bias = bias; a.addend = (const T*)addend; a.ld_add = ld_add; a.relu = relu;
+    a.role = 2;
     return launch_nt<T>(a, MODE_DENSE, s);
 }
 

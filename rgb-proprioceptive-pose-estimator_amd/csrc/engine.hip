@@ -91,7 +91,9 @@ struct rpe_resnet50 {
     size_t gspan_bytes = 0;
     // optional per-category HIP-event timing (rpe_resnet50_profile)
     bool profiling = false;
-    struct Span { int cat; hipEvent_t a, b; };
+    struct Span { int cat; hipEvent_t a, b; int name_id; double flops, bytes; };
+    std::vector<std::string> kernel_names;   // distinct kernel symbols seen while profiling (rpe_last_kernel_name)
+    double pending_flops = 0, pending_bytes = 0;  // algorithmic FLOPs / HBM bytes of the launch being bracketed
     std::vector<Span> spans;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_next = 0;
@@ -105,6 +107,15 @@ struct rpe_resnet50 {
     double flops[RPE_PROF_NUM] = {0};   // algorithmic FLOPs per pass, per category
     double bytes[RPE_PROF_NUM] = {0};   // algorithmic bytes per pass, per category
 };
+
+extern "C" const char* rpe_last_kernel_name(void);
+static int kernel_id(rpe_resnet50* e) {
+    const char* n = rpe_last_kernel_name();
+    for (size_t i = 0; i < e->kernel_names.size(); ++i)
+        if (e->kernel_names[i] == n) return (int)i;
+    e->kernel_names.push_back(n);
+    return (int)e->kernel_names.size() - 1;
+}
 
 static hipEvent_t next_event(rpe_resnet50* e) {
     if (e->ev_next == e->ev_pool.size()) {
@@ -123,7 +134,7 @@ static hipEvent_t next_event(rpe_resnet50* e) {
             if (pa__) (void)hipEventRecord(pa__, (hipStream_t)(stream)); }                 \
         if (int err__ = (call)) return err__;                                        \
         if ((e)->profiling && pa__ && pb__) { (void)hipEventRecord(pb__, (hipStream_t)(stream)); \
-            (e)->spans.push_back({(cat), pa__, pb__}); }                             \
+            (e)->spans.push_back({(cat), pa__, pb__, (cat) <= RPE_PROF_CONV_WGRAD ? kernel_id(e) : -1, (e)->pending_flops, (e)->pending_bytes}); (e)->pending_flops = 0; (e)->pending_bytes = 0; } \
     } while (0)
 
 static int add_conv(rpe_resnet50* e, const std::string& name, const std::string& bn, int in_h, int in_w, int in_c, int out_c, int k,
@@ -260,6 +271,30 @@ extern "C" int rpe_resnet50_profile_read(rpe_resnet50_t* e, float* ms, int* laun
     return 0;
 }
 
+// Per kernel SYMBOL (the names rocprofv3 lists, in the short form of rpe_last_kernel_name): launches, summed HIP-event
+// time and summed algorithmic FLOPs since rpe_resnet50_profile(e, 1).  Text lines "name;launches;ms;flops;bytes\n".
+extern "C" long rpe_resnet50_profile_kernels(rpe_resnet50_t* e, char* buf, long buflen) {
+    if (!e || !buf || buflen <= 0) return -1;
+    const size_t nk = e->kernel_names.size();
+    std::vector<double> ms(nk, 0.0), fl(nk, 0.0), by(nk, 0.0);
+    std::vector<int> cnt(nk, 0);
+    for (auto& sp : e->spans) {
+        if (sp.name_id < 0 || (size_t)sp.name_id >= nk) continue;
+        if (hipEventSynchronize(sp.b) != hipSuccess) return -1;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, sp.a, sp.b) != hipSuccess) return -1;
+        ms[sp.name_id] += t; fl[sp.name_id] += sp.flops; by[sp.name_id] += sp.bytes; cnt[sp.name_id] += 1;
+    }
+    long off = 0;
+    for (size_t i = 0; i < nk; ++i) {
+        if (!cnt[i]) continue;
+        const int w = snprintf(buf + off, (size_t)(buflen - off), "%s;%d;%.6f;%.0f;%.0f\n", e->kernel_names[i].c_str(), cnt[i], ms[i], fl[i], by[i]);
+        if (w < 0 || off + w >= buflen) break;
+        off += w;
+    }
+    return off;
+}
+
 extern "C" void rpe_resnet50_destroy(rpe_resnet50_t* e) {
     if (!e) return;
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
@@ -349,11 +384,18 @@ extern "C" int rpe_resnet50_pack_weights(rpe_resnet50_t* e, void* stream) {
     return 0;
 }
 
+// algorithmic HBM bytes: every operand tensor read or written exactly once (weights amortised over the batch)
+static double conv_in_bytes(const rpe_resnet50* e, const ConvL& c) { return (double)c.d.batch * c.d.in_h * c.d.in_w * c.d.in_c * e->esz; }
+static double conv_out_bytes(const rpe_resnet50* e, const ConvL& c) { return (double)c.rows * c.d.out_c * e->esz; }
+static double conv_flops(const ConvL& c) { return 2.0 * (double)c.rows * c.d.out_c * (double)(c.d.kh * c.d.kw * c.d.in_c); }
+
 static const void* fwd_weight(rpe_resnet50* e, ConvL& c) { return (e->dtype == RPE_F32 && &c != &e->convs[0]) ? (const void*)e->params[c.p_w] : c.wf; }
 
 // conv -> batch statistics -> BN apply (+residual) (+relu)
 static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residual, int relu, void* stream) {
     const bool train = e->train_mode != 0;
+    e->pending_flops = conv_flops(c);
+    e->pending_bytes = conv_in_bytes(e, c) + conv_out_bytes(e, c);
     if (&c == &e->convs[0]) PROF(e, RPE_PROF_CONV_FWD, stream, rpe_stem_conv_fwd(e->dtype, x, c.wf, c.y, train ? e->stats_part : nullptr, e->B, e->H, e->W, stream));
     else PROF(e, RPE_PROF_CONV_FWD, stream, rpe_conv2d_fwd(&c.d, e->dtype, x, fwd_weight(e, c), c.y, train ? e->stats_part : nullptr, stream));
     float* rm = e->running[2 * c.bn_i];
@@ -416,6 +458,9 @@ static int dgrad_fused(rpe_resnet50* e, ConvL& c, const void* dy, void* dz, cons
     ep.scale = mask_mode == 2 ? bnl->scale : nullptr;
     ep.shift = mask_mode == 2 ? bnl->shift : nullptr;
     ep.stats_part = e->stats_part;
+    e->pending_flops = conv_flops(c);
+    // reads dy; writes dz; the fused epilogue also reads y (and a_out for residual outputs) and the shortcut addend
+    e->pending_bytes = conv_out_bytes(e, c) + conv_in_bytes(e, c) * (2.0 + (mask_mode == 1 ? 1.0 : 0.0) + (addend ? 1.0 : 0.0));
     e->fused_tiles = (int)rpe_conv2d_dgrad_stats_tiles(&c.d);  // partial-sum rows this launch leaves behind
     PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad_bn(&c.d, e->dtype, dy, c.wd, dz, addend, &ep, stream));
     return 0;
@@ -463,6 +508,8 @@ static int wgrad(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, void*
         run = e->side;
     }
     if (!e->gspan_lo) HIPTRY(hipMemsetAsync(dw, 0, (size_t)e->pnumel[c.p_w] * 4, run));
+    e->pending_flops = conv_flops(c);
+    e->pending_bytes = conv_in_bytes(e, c) + conv_out_bytes(e, c);
     PROF(e, RPE_PROF_CONV_WGRAD, run, rpe_conv2d_wgrad(&c.d, e->dtype, x, dy, dw, run));
     if (run != (hipStream_t)stream) {
         hipEvent_t done = sync_event(e);

@@ -48,6 +48,7 @@ template <typename T> struct NTArgs {
     const T* bn_a;       // BN(+residual)+ReLU output, [M][ldc] (mode 1)
     const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
     int tiles_m, tiles_n;
+    int role;            // 0 conv forward, 1 conv data-gradient, 2 Linear (kernel symbol tag for profiles)
 };
 
 template <typename T> struct TNArgs {

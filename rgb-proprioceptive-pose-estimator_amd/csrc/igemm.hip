@@ -11,6 +11,7 @@
 // The weight tile is the MFMA "A" operand and the activation tile the "B" operand, so the
 // accumulator registers of a lane run along N (channels): the epilogue stores 4 consecutive
 // channels per lane straight to NHWC memory (8 B bf16 / 16 B f32) without an LDS transpose.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "igemm.h"
@@ -83,7 +84,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 //   large config  <4, 128|64, 8>: 256-row tile, 128-B rows  (conv trunk): 2x the FLOPs per byte pulled from L2 into LDS
 //   and every DMA instruction moves whole 128-B lines -- at 128x128x32 the kernel sat at ~16 B/clk/CU of L2->LDS traffic.
 // -----------------------------------------------------------------------------------------------
-template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST = 3>
+// ROLE only tells the symbols apart in profiles: 0 conv forward, 1 conv data-gradient, 2 Linear.
+template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE>
 __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
     constexpr int CE = Elem<T>::kChunk, BK = KCH * CE;
     constexpr int NW = 2 * WAVES_M, NTHR = 64 * NW;
@@ -674,15 +676,25 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
 // -----------------------------------------------------------------------------------------------
 // host launchers
 // -----------------------------------------------------------------------------------------------
+static thread_local char g_last_kernel[96] = "";
+extern "C" const char* rpe_last_kernel_name(void) { return g_last_kernel; }
+
+template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE> static int launch_nt_role(NTArgs<T>& a, hipStream_t s, long nwg) {
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "nt_kernel<%s,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", WAVES_M, BN, KCH, MODE, NST, ROLE);
+    hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE>), dim3((unsigned)nwg), dim3(128 * WAVES_M), 0, s, a);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
 template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST = 3> static int launch_nt_cfg(NTArgs<T>& a, hipStream_t s) {
     constexpr int BM = 64 * WAVES_M;
     a.tiles_m = (MODE == MODE_CONV && a.g.parity) ? 4 * ceil_div(a.g.rows_q, BM) : ceil_div(a.M, BM);
     a.tiles_n = ceil_div(a.N, BN);
     const long nwg = (long)a.tiles_m * a.tiles_n;
     if (nwg <= 0 || nwg > 0x7fffffffL) return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: bad grid");
-    hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST>), dim3((unsigned)nwg), dim3(128 * WAVES_M), 0, s, a);
-    RPE_CHECK_LAUNCH();
-    return 0;
+    if (a.role == 1) return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 1>(a, s, nwg);
+    if (a.role == 2) return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 2>(a, s, nwg);
+    return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 0>(a, s, nwg);
 }
 
 template <typename T> int launch_nt(NTArgs<T>& a, int mode, hipStream_t s) {
@@ -742,6 +754,7 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
     // (5.67 vs 5.22 ms per step; 48 KB LDS costs occupancy and the transposed reads, not the staging, bound this kernel).
     // Register staging is the default; RPE_TN_DMA=1 selects the ring.
     static const bool dma = getenv("RPE_TN_DMA") != nullptr;
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "tn_kernel<%s,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", BI, BJ, MODE, dma ? 1 : 0);
     if (dma) hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, false>), dim3((unsigned)nwg), dim3(256), 0, s, a);
     RPE_CHECK_LAUNCH();
