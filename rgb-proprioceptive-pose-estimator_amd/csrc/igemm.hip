@@ -349,12 +349,20 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
             for (int j = 0; j < 8; ++j) out[j] = (n + j < p.N) ? Elem<T>::to_f(base[off + j]) : 0.f;
         }
     };
+    // the staging rows are private to a wave and LDS executes a wave's accesses in order: a wave-level fence between its
+    // writes and its cross-lane reads is enough; the workgroup barrier is only needed once, after the K loop
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    __syncthreads();   // every wave is done with the K loop's LDS tiles
 #pragma unroll
     for (int qf = 0; qf < FM; ++qf) {
-        __syncthreads();
+        wave_sync();   // this wave's reads of the previous fragment have been issued (LDS is in order per wave)
 #pragma unroll
         for (int a = 0; a < FN; ++a) *(f32x4*)(stg + fr * LDW + a * 16 + fc * 4) = acc[a][qf];
-        __syncthreads();
+        wave_sync();
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int r = ps * RPP + erow;
@@ -718,6 +726,12 @@ template <typename T> int launch_nt(NTArgs<T>& a, int mode, hipStream_t s) {
     if (!big && !bk64_off && a.M >= 1024 && (bk64_all ? a.K >= 16 * CE : a.K >= 1024)) {
         if (mode == MODE_DENSE) return wide ? launch_nt_cfg<T, 2, 128, 8, MODE_DENSE, 2>(a, s) : launch_nt_cfg<T, 2, 64, 8, MODE_DENSE, 2>(a, s);
         return wide ? launch_nt_cfg<T, 2, 128, 8, MODE_CONV, 2>(a, s) : launch_nt_cfg<T, 2, 64, 8, MODE_CONV, 2>(a, s);
+    }
+    // experiment: 2-slot ring (32 KB LDS -> more resident workgroups) for the short-K, epilogue-dominated launches
+    static const bool nst2 = getenv("RPE_NT_NST2") != nullptr;
+    if (nst2 && !big && a.K <= 512) {
+        if (mode == MODE_DENSE) return wide ? launch_nt_cfg<T, 2, 128, 4, MODE_DENSE, 2>(a, s) : launch_nt_cfg<T, 2, 64, 4, MODE_DENSE, 2>(a, s);
+        return wide ? launch_nt_cfg<T, 2, 128, 4, MODE_CONV, 2>(a, s) : launch_nt_cfg<T, 2, 64, 4, MODE_CONV, 2>(a, s);
     }
     if (mode == MODE_DENSE) {
         if (big) return wide ? launch_nt_cfg<T, 4, 128, 8, MODE_DENSE>(a, s) : launch_nt_cfg<T, 4, 64, 8, MODE_DENSE>(a, s);
