@@ -108,6 +108,12 @@ int rpe_unpack_stem_grad(const float* d_packed, float* dw_oihw, void* stream);
  * ((B,3,H,W) fp32 NCHW, util/data_utils.py:62-73) -> NHWC4 in the compute dtype. */
 int rpe_stage_image_nhwc4(int dtype, const float* img_nchw, void* out, int B, int H, int W, void* stream);
 
+/* replaces: the CPU image transform ToPILImage -> Resize(256) -> CenterCrop(224) -> ToTensor -> Normalize
+ * (util/data_utils.py:48-54) for frames whose shorter side already equals the resize target: uint8 [B][Hs][Ws][3] frames are
+ * centre-cropped to (H, W), normalised with the HOST arrays mean3/std3 and written as NHWC4 in the compute dtype. */
+int rpe_stage_frames_u8(int dtype, const unsigned char* frames, void* out, int B, int Hs, int Ws, int H, int W, const float* mean3_host,
+                        const float* std3_host, void* stream);
+
 /* ------------------------------------------------------------------ batch norm */
 /* replaces: nn.BatchNorm2d (train mode: biased batch variance, eps, momentum with
  * unbiased running variance) + the in-place nn.ReLU and `out += identity` of the
@@ -219,6 +225,9 @@ int rpe_resnet50_pack_weights(rpe_resnet50_t* e, void* stream);
 /* img: (B,3,H,W) fp32 NCHW.  features: fp32 [B][ld_features] (first latent_dim columns written).
  * training != 0: batch statistics + running-stat update and everything backward needs is kept. */
 int rpe_resnet50_forward(rpe_resnet50_t* e, const float* img_nchw, float* features, long ld_features, int training, void* stream);
+/* the same from raw simulator frames (uint8 [B][Hs][Ws][3]): crop + normalise + stage in one kernel (rpe_stage_frames_u8) */
+int rpe_resnet50_forward_u8(rpe_resnet50_t* e, const unsigned char* frames, int Hs, int Ws, const float* mean3_host, const float* std3_host,
+                            float* features, long ld_features, int training, void* stream);
 /* the hooked early feature relu(bn1(conv1 x)): NHWC [B][H/2][W/2][64] in the compute dtype (inside the workspace) */
 const void* rpe_resnet50_early_feature(const rpe_resnet50_t* e);
 /* gradient buffer of the early feature; the caller writes d(loss)/d(early) there (or passes use_d_early = 0) */

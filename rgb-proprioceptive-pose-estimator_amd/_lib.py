@@ -53,6 +53,7 @@ _SPEC = {
     "rpe_pack_stem_weight": (I, [I, P, P, P]),
     "rpe_unpack_stem_grad": (I, [P, P, P]),
     "rpe_stage_image_nhwc4": (I, [I, P, P, I, I, I, P]),
+    "rpe_stage_frames_u8": (I, [I, P, P, I, I, I, I, I, POINTER(c_float), POINTER(c_float), P]),
     "rpe_bn_finalize": (I, [P, I, I, L, P, P, P, P, P, F, F, P, P, P, P, P, P]),
     "rpe_bn_eval_affine": (I, [I, P, P, P, P, F, P, P, P]),
     "rpe_bn_apply": (I, [I, P, P, P, P, P, L, I, I, P]),
@@ -83,6 +84,7 @@ _SPEC = {
     "rpe_resnet50_bind": (I, [P, P, L, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
     "rpe_resnet50_pack_weights": (I, [P, P]),
     "rpe_resnet50_forward": (I, [P, P, P, L, I, P]),
+    "rpe_resnet50_forward_u8": (I, [P, P, I, I, POINTER(c_float), POINTER(c_float), P, L, I, P]),
     "rpe_resnet50_early_feature": (c_void_p, [P]),
     "rpe_resnet50_early_grad": (c_void_p, [P]),
     "rpe_resnet50_backward": (I, [P, P, L, I, P]),

@@ -411,11 +411,13 @@ static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residua
     return 0;
 }
 
-extern "C" int rpe_resnet50_forward(rpe_resnet50_t* e, const float* img_nchw, float* features, long ld_features, int training, void* stream) {
+static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned char* frames, int Hs, int Ws, const float* mean3, const float* std3,
+                        float* features, long ld_features, int training, void* stream) {
     if (!e || !e->bound) return rpe_set_error(RPE_ERR_STATE, "resnet50_forward: engine not bound");
-    if (!img_nchw || !features || ld_features < e->latent) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_forward: bad img/features");
+    if ((!img_nchw && !frames) || !features || ld_features < e->latent) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_forward: bad img/features");
     e->train_mode = training;
-    PROF(e, RPE_PROF_OTHER, stream, rpe_stage_image_nhwc4(e->dtype, img_nchw, e->x4, e->B, e->H, e->W, stream));
+    if (frames) PROF(e, RPE_PROF_OTHER, stream, rpe_stage_frames_u8(e->dtype, frames, e->x4, e->B, Hs, Ws, e->H, e->W, mean3, std3, stream));
+    else PROF(e, RPE_PROF_OTHER, stream, rpe_stage_image_nhwc4(e->dtype, img_nchw, e->x4, e->B, e->H, e->W, stream));
     ConvL& st = e->convs[0];
     TRY(conv_bn(e, st, e->x4, nullptr, 1, stream));
     PROF(e, RPE_PROF_OTHER, stream, rpe_maxpool3x3s2_fwd(e->dtype, st.a, e->pool, e->pool_idx, e->B, st.Ho, st.Wo, 64, stream));
@@ -436,6 +438,16 @@ extern "C" int rpe_resnet50_forward(rpe_resnet50_t* e, const float* img_nchw, fl
                        nullptr, 0, stream));
     e->fwd_done = training != 0;
     return 0;
+}
+
+extern "C" int rpe_resnet50_forward(rpe_resnet50_t* e, const float* img_nchw, float* features, long ld_features, int training, void* stream) {
+    return forward_impl(e, img_nchw, nullptr, 0, 0, nullptr, nullptr, features, ld_features, training, stream);
+}
+
+extern "C" int rpe_resnet50_forward_u8(rpe_resnet50_t* e, const unsigned char* frames, int Hs, int Ws, const float* mean3_host,
+                                       const float* std3_host, float* features, long ld_features, int training, void* stream) {
+    if (!frames) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_forward_u8: null frames");
+    return forward_impl(e, nullptr, frames, Hs, Ws, mean3_host, std3_host, features, ld_features, training, stream);
 }
 
 extern "C" const void* rpe_resnet50_early_feature(const rpe_resnet50_t* e) { return e ? e->convs[0].a : nullptr; }

@@ -365,6 +365,30 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restr
     }
 }
 
+// Simulator frames: uint8 [B][Hs][Ws][3] -> centre crop (H, W) -> (x/255 - mean)/std -> NHWC4 compute type.
+// replaces ToPILImage -> Resize(256) -> CenterCrop(224) -> ToTensor -> Normalize (util/data_utils.py:48-54) for frames whose
+// shorter side already is the resize target (robosuite's 256x256 default), and the .cuda() copy of the fp32 result.
+template <typename T>
+__global__ __launch_bounds__(256) void frames_u8_to_nhwc4_kernel(const unsigned char* __restrict__ fr, T* __restrict__ out, int B, int Hs, int Ws,
+                                                                int H, int W, float m0, float m1, float m2, float i0, float i1, float i2) {
+    const int top = (Hs - H) / 2, left = (Ws - W) / 2;
+    const long total = (long)B * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        const long t = i / W;
+        const int h = (int)(t % H);
+        const long b = t / H;
+        const unsigned char* p = fr + ((b * Hs + (top + h)) * Ws + (left + w)) * 3;
+        const float r = ((float)p[0] * (1.f / 255.f) - m0) * i0, g = ((float)p[1] * (1.f / 255.f) - m1) * i1, bl = ((float)p[2] * (1.f / 255.f) - m2) * i2;
+        if (sizeof(T) == 4) {
+            *(f32x4*)(out + i * 4) = f32x4{r, g, bl, 0.f};
+        } else {
+            u32x2 v; v.x = pack_bf16x2(r, g); v.y = pack_bf16x2(bl, 0.f);
+            *(u32x2*)(out + i * 4) = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -555,6 +579,18 @@ int rpe_stage_image_nhwc4(int dtype, const float* img_nchw, void* out, int B, in
     if (dtype == RPE_F32) hipLaunchKernelGGL((nchw_to_nhwc4_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, img_nchw, (float*)out, B, H * W);
     else if (dtype == RPE_BF16) hipLaunchKernelGGL((nchw_to_nhwc4_kernel<bf16>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, img_nchw, (bf16*)out, B, H * W);
     else return rpe_set_error(RPE_ERR_DTYPE, "stage_image: unsupported dtype");
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_stage_frames_u8(int dtype, const unsigned char* frames, void* out, int B, int Hs, int Ws, int H, int W, const float* mean3_host,
+                        const float* std3_host, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || Hs < H || Ws < W || !mean3_host || !std3_host) return rpe_set_error(RPE_ERR_SHAPE, "stage_frames_u8: bad shape");
+    const long n = (long)B * H * W;
+    const float i0 = 1.f / std3_host[0], i1 = 1.f / std3_host[1], i2 = 1.f / std3_host[2];
+    if (dtype == RPE_F32) hipLaunchKernelGGL((frames_u8_to_nhwc4_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, frames, (float*)out, B, Hs, Ws, H, W, mean3_host[0], mean3_host[1], mean3_host[2], i0, i1, i2);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((frames_u8_to_nhwc4_kernel<bf16>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, frames, (bf16*)out, B, Hs, Ws, H, W, mean3_host[0], mean3_host[1], mean3_host[2], i0, i1, i2);
+    else return rpe_set_error(RPE_ERR_DTYPE, "stage_frames_u8: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;
 }

@@ -58,6 +58,10 @@ class ResNet50Trunk(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
         self.compute_dtype = compute_dtype
+        # device-side preprocessing of uint8 frames (the reference's transform, util/data_utils.py:48-54)
+        self.crop_hw = (224, 224)
+        self.norm_mean = (0.485, 0.456, 0.406)
+        self.norm_std = (0.229, 0.224, 0.225)
         self._plans = {}      # (B, H, W, dtype, latent) -> _Plan
         self._active = None
 
@@ -112,8 +116,14 @@ class ResNet50Trunk(nn.Module):
         columns receive the ResNet output.  Returns the plan (early feature / backward handle)."""
         if not img.is_cuda:
             raise RuntimeError("ResNet50Trunk needs device tensors: the HIP path has no CPU fallback")
-        b, c, h, w = img.shape
-        assert c == 3 and img.dtype == torch.float32 and img.is_contiguous()
+        frames = img.dtype == torch.uint8  # raw simulator frames (B, Hs, Ws, 3): cropped + normalised on the device
+        if frames:
+            b, hs, ws, c = img.shape
+            h, w = self.crop_hw
+            assert c == 3 and img.is_contiguous() and hs >= h and ws >= w
+        else:
+            b, c, h, w = img.shape
+            assert c == 3 and img.dtype == torch.float32 and img.is_contiguous()
         plan = self._plan(b, h, w)
         s = ops._stream()
         if training or not plan.packed:
@@ -121,7 +131,12 @@ class ResNet50Trunk(nn.Module):
             # compute-dtype / transposed copies (53 tiny kernels, ~0.2 GB of traffic)
             lib.rpe_resnet50_pack_weights(plan.handle, s)
             plan.packed = True
-        lib.rpe_resnet50_forward(plan.handle, ops._p(img), ops._p(features), features.stride(0), int(training), s)
+        if frames:
+            F3 = ctypes.c_float * 3
+            lib.rpe_resnet50_forward_u8(plan.handle, ops._p(img), hs, ws, F3(*self.norm_mean), F3(*self.norm_std), ops._p(features),
+                                        features.stride(0), int(training), s)
+        else:
+            lib.rpe_resnet50_forward(plan.handle, ops._p(img), ops._p(features), features.stride(0), int(training), s)
         self._active = plan
         return plan
 

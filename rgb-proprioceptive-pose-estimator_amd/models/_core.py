@@ -162,7 +162,9 @@ class PoseModelBase(nn.Module):
 
     def _call(self, img, depth, self_measurement):
         self._materialize(img.device)
-        img = img.contiguous().float()
+        # float images are the reference's (…, 3, H, W) tensors; uint8 images are raw (…, Hs, Ws, 3) frames that the trunk
+        # crops and normalises on the device
+        img = img.contiguous() if img.dtype == torch.uint8 else img.contiguous().float()
         x0bar = None if self_measurement is None else self_measurement.contiguous().float()
         anchor = self._anchor()
         if torch.is_grad_enabled() and self.training and anchor is not None:

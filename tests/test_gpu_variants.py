@@ -1,0 +1,34 @@
+"""The kernel configurations that are selectable by environment switch (measured, rejected as defaults, kept
+for experiments) must stay CORRECT: each switch is read once per process, so every variant gets one child process that runs
+the conv / Linear parity cases of test_gpu_ops.py under it.  Children run one after the other (one GPU process at a time)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SUBSET = "conv_fwd_and_stats or conv_dgrad or conv_wgrad or dgrad_with_fused_bn_backward or linear_fwd_layout or linear_wgrad"
+
+VARIANTS = [
+    {"RPE_NT_BIG": "1"},      # 256-row / 8-wave NT tiles for M >= 4096, K >= 1024
+    {"RPE_NT_BK64": "1"},     # 128-byte K rows + 2-slot ring for every K
+    {"RPE_NT_NOBK64": "1"},   # ... and for none
+    {"RPE_NT_NST2": "1"},     # 2-slot ring for short K
+    {"RPE_TN_DMA": "1"},      # LDS-DMA ring in the weight-gradient kernel
+    {"RPE_NO_PARITY": "1"},   # stride-2 data gradient without the parity-class decomposition
+    {"RPE_TN_WGS": "64"},     # few, long split-M slices in the weight gradient
+]
+
+
+@pytest.mark.parametrize("env", VARIANTS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_kernel_variant_parity(env):
+    child_env = dict(os.environ)
+    child_env.update(env)
+    cmd = [sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_ops.py"), "-q", "-x", "-p", "no:cacheprovider", "-k", SUBSET]
+    r = subprocess.run(cmd, env=child_env, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=900)
+    tail = (r.stdout or "")[-3000:] + (r.stderr or "")[-1000:]
+    assert r.returncode == 0, "variant %r failed:\n%s" % (env, tail)
+    assert " passed" in r.stdout
