@@ -1,0 +1,65 @@
+"""Reduce two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) to per-kernel-symbol HBM bytes -> profiles/hbm_traffic_pmc.json.
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc -o fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc -o write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    python tools/pmc_reduce.py gpurun_out/pmc/fetch_counter_collection.csv gpurun_out/pmc/write_counter_collection.csv 6 > profiles/hbm_traffic_pmc.json
+
+Corrections (MI355X_MICROARCH.md, HBM / rocprofv3 section): both counters are in KB; on gfx950 FETCH_SIZE tallies 128-byte
+requests as 64 bytes, so the fetch side is doubled.  The third argument is the number of train steps the profiled command ran
+(bench.py: warm-up + timed + 3 profiled).  Kernel symbols are normalised to the names bench.py reports
+(`nt_kernel<bf16,2,128,4,0,3,1>`)."""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+csv.field_size_limit(1 << 30)
+
+
+def symbol(name):
+    name = name.replace("void ", "").replace("rpe::", "").replace("(anonymous namespace)::", "")
+    m = re.match(r"([A-Za-z_0-9]+)(<.*?>)?\(", name)
+    if not m:
+        m = re.match(r"([A-Za-z_0-9:]+)", name)
+        return m.group(1) if m else name[:60]
+    base, targs = m.group(1), m.group(2) or ""
+    if base in ("nt_kernel", "tn_kernel"):
+        targs = targs.replace("__hip_bfloat16", "bf16").replace("float", "f32").replace(" ", "").replace("true", "1").replace("false", "0")
+        targs = re.sub(r"\(rpe::[A-Za-z]+\)", "", targs)
+        return base + targs
+    return base
+
+
+def totals(path, counter):
+    kb, launches = defaultdict(float), defaultdict(set)
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            s = symbol(row["Kernel_Name"])
+            kb[s] += float(row["Counter_Value"])
+            launches[s].add(row["Dispatch_Id"])
+    return kb, {k: len(v) for k, v in launches.items()}
+
+
+def main():
+    fetch_csv, write_csv, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    fkb, fl = totals(fetch_csv, "FETCH_SIZE")
+    wkb, _ = totals(write_csv, "WRITE_SIZE")
+    rows = []
+    for s in fkb:
+        fetch_gb = 2.0 * fkb[s] * 1024 / 1e9
+        write_gb = wkb.get(s, 0.0) * 1024 / 1e9
+        rows.append({"kernel": s, "launches": fl[s], "fetch_GB_corrected": round(fetch_gb, 3), "write_GB": round(write_gb, 3),
+                     "per_launch_MB": round((fetch_gb + write_gb) * 1e3 / fl[s], 2)})
+    rows.sort(key=lambda r: -(r["fetch_GB_corrected"] + r["write_GB"]))
+    total = sum(r["fetch_GB_corrected"] + r["write_GB"] for r in rows)
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 2 --warmup 1 "
+                       "--no-cpu-baseline`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); counter "
+                       "unit KB; per_launch_MB = (corrected fetch + write) / launches",
+               "train_steps_in_run": steps, "per_step_GB": round(total / steps, 1), "kernels": rows}, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
