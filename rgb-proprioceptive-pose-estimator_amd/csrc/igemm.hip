@@ -85,7 +85,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 //   and every DMA instruction moves whole 128-B lines -- at 128x128x32 the kernel sat at ~16 B/clk/CU of L2->LDS traffic.
 // -----------------------------------------------------------------------------------------------
 // ROLE only tells the symbols apart in profiles: 0 conv forward, 1 conv data-gradient, 2 Linear.
-template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE>
+template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE, bool EPI_PIPE = true>
 __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
     constexpr int CE = Elem<T>::kChunk, BK = KCH * CE;
     constexpr int NW = 2 * WAVES_M, NTHR = 64 * NW;
@@ -247,6 +247,44 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
         for (int i = 0; i < BR; ++i) base[BM * KCH + b_row[i] * KCH + nt_swz<KCH>(b_row[i], b_chunk[i])] = rb[i];
     };
 
+    // ---- epilogue lane geometry (needed early: the data-gradient form prefetches its epilogue operands) ----
+    constexpr int LDW = WN + 4;     // staged row pitch in floats (+4: conflict-free float4 writes)
+    constexpr int CPW = WN / 8;     // 8-channel chunks per staged row
+    constexpr int RPP = 64 / CPW;   // rows per pass
+    constexpr int NPASS = 16 / RPP;
+    constexpr int NSTEP = FM * NPASS;   // epilogue steps of a wave: (fragment, pass) pairs, 8 channels of one row per lane each
+    const int erow = lane / CPW, echk = lane % CPW;
+    const int nl = wave_n * WN + echk * 8;
+    const int n = n0 + nl;
+    const bool ncol_ok = n < p.N;
+    const bool nfull = n + 7 < p.N;
+    const bool vec_c = nfull && (p.ldc % CE == 0) && (((uintptr_t)p.C) & 15) == 0;
+    const bool vec_add = nfull && p.addend && (p.ld_add % CE == 0) && (((uintptr_t)p.addend) & 15) == 0;
+    const int bn_mode = p.bn_mode;
+    // Data-gradient launches with short K are bound by the epilogue's operand stream (residual gradient, y, a_out: up to
+    // three reads and one write per output element against K/N-th of that for the GEMM operands).  One step at a time
+    // keeps ~1-3 KB per wave in flight; here the operands of the next DEPTH steps are requested ahead (the first DEPTH
+    // before the K loop even starts), 16 B per lane and operand, into registers that are recycled step by step.
+    constexpr bool PIPE = (ROLE == 1) && (CE == 8) && EPI_PIPE;
+    constexpr int DEPTH = PIPE ? (NSTEP < 4 ? NSTEP : 4) : 1;
+    u32x4 qd[DEPTH], qy[DEPTH], qa[DEPTH];
+    auto step_row = [&](int t) -> long { return out_row(wave_m * WM + (t / NPASS) * 16 + (t % NPASS) * RPP + erow); };
+    auto issue = [&](int t) {
+        if (!PIPE) return;
+        const long m = step_row(t);
+        const int sl = t % DEPTH;
+        if (m < 0 || !ncol_ok) return;
+        if (vec_add) qd[sl] = ld16(p.addend + m * p.ld_add + n);
+        if (bn_mode && vec_c) {
+            qy[sl] = ld16(p.bn_y + m * p.ldc + n);
+            if (bn_mode == 1) qa[sl] = ld16(p.bn_a + m * p.ldc + n);
+        }
+    };
+    if (PIPE) {
+#pragma unroll
+        for (int t = 0; t < DEPTH; ++t) issue(t);
+    }
+
     f32x4 acc[FN][FM];
 #pragma unroll
     for (int a = 0; a < FN; ++a)
@@ -317,19 +355,7 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
     // A lane's accumulators hold 4 channels of 16 scattered rows.  They go through LDS once so that every lane
     // ends up with 8 consecutive channels of ONE row: epilogue operands (addend, and for the fused BN-backward
     // form y / a_out) are then read, and the result written, as 16 bytes per lane = whole 128-B lines per 8 lanes.
-    constexpr int LDW = WN + 4;     // staged row pitch in floats (+4: conflict-free float4 writes)
-    constexpr int CPW = WN / 8;     // 8-channel chunks per staged row
-    constexpr int RPP = 64 / CPW;   // rows per pass
-    constexpr int NPASS = 16 / RPP;
     float* stg = (float*)lds + wave * (16 * LDW);  // 16 staged rows (one 16-row fragment) per wave at a time
-    const int erow = lane / CPW, echk = lane % CPW;
-    const int nl = wave_n * WN + echk * 8;
-    const int n = n0 + nl;
-    const bool ncol_ok = n < p.N;
-    const bool nfull = n + 7 < p.N;
-    const bool vec_c = nfull && (p.ldc % CE == 0) && (((uintptr_t)p.C) & 15) == 0;
-    const bool vec_add = nfull && p.addend && (p.ld_add % CE == 0) && (((uintptr_t)p.addend) & 15) == 0;
-    const int bn_mode = p.bn_mode;
     float cs[8], cq[8], cmean[8], cinv[8], csc[8], csh[8], cbias[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -366,6 +392,7 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int r = ps * RPP + erow;
+            const int t = qf * NPASS + ps, sl = t % DEPTH;
             const long m = out_row(wave_m * WM + qf * 16 + r);
             float v[8];
             {
@@ -373,47 +400,55 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
                 const f32x4 t1 = *(const f32x4*)(stg + r * LDW + echk * 8 + 4);
                 v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
             }
-            if (m < 0 || !ncol_ok) continue;
-            if (p.stats_part && !bn_mode) {
+            if (m >= 0 && ncol_ok) {
+                if (p.stats_part && !bn_mode) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { cs[j] += v[j]; cq[j] += v[j] * v[j]; }
-            }
-            if (p.bias) {
+                    for (int j = 0; j < 8; ++j) { cs[j] += v[j]; cq[j] += v[j] * v[j]; }
+                }
+                if (p.bias) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += cbias[j];
-            }
-            if (p.addend) {
-                float ad[8];
-                load8(p.addend, m * p.ld_add + n, vec_add, ad);
+                    for (int j = 0; j < 8; ++j) v[j] += cbias[j];
+                }
+                if (p.addend) {
+                    float ad[8];
+                    if (PIPE && vec_add) chunk_to_f<T>(qd[sl], ad);
+                    else load8(p.addend, m * p.ld_add + n, vec_add, ad);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += ad[j];
-            }
-            if (bn_mode) {
-                // v = dA (gradient wrt the BN output after ReLU).  dz = dA * [a_out > 0]; partial sums of dz and dz*xhat.
-                float yy[8], aa[8];
-                load8(p.bn_y, m * p.ldc + n, vec_c, yy);
-                if (bn_mode == 1) load8(p.bn_a, m * p.ldc + n, vec_c, aa);
+                    for (int j = 0; j < 8; ++j) v[j] += ad[j];
+                }
+                if (bn_mode) {
+                    // v = dA (gradient wrt the BN output after ReLU).  dz = dA * [a_out > 0]; partial sums of dz and dz*xhat.
+                    float yy[8], aa[8];
+                    if (PIPE && vec_c) {
+                        chunk_to_f<T>(qy[sl], yy);
+                        if (bn_mode == 1) chunk_to_f<T>(qa[sl], aa);
+                    } else {
+                        load8(p.bn_y, m * p.ldc + n, vec_c, yy);
+                        if (bn_mode == 1) load8(p.bn_a, m * p.ldc + n, vec_c, aa);
+                    }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const bool on = bn_mode == 1 ? (aa[j] > 0.f) : (bn_mode == 2 ? (fmaf(yy[j], csc[j], csh[j]) > 0.f) : true);
-                    const float dz = on ? v[j] : 0.f;
-                    cs[j] += dz;
-                    cq[j] += dz * (yy[j] - cmean[j]) * cinv[j];
-                    v[j] = dz;
+                    for (int j = 0; j < 8; ++j) {
+                        const bool on = bn_mode == 1 ? (aa[j] > 0.f) : (bn_mode == 2 ? (fmaf(yy[j], csc[j], csh[j]) > 0.f) : true);
+                        const float dz = on ? v[j] : 0.f;
+                        cs[j] += dz;
+                        cq[j] += dz * (yy[j] - cmean[j]) * cinv[j];
+                        v[j] = dz;
+                    }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                T* cp = p.C + m * p.ldc + n;
+                if (vec_c) {
+                    if (CE == 8) { *(u32x4*)cp = f_to_chunk<T>(v); }
+                    else { *(u32x4*)cp = f_to_chunk<T>(v); *(u32x4*)(cp + 4) = f_to_chunk<T>(v + 4); }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (n + j < p.N) cp[j] = Elem<T>::from_f(v[j]);
                 }
             }
-            if (p.relu) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-            }
-            T* cp = p.C + m * p.ldc + n;
-            if (vec_c) {
-                if (CE == 8) { *(u32x4*)cp = f_to_chunk<T>(v); }
-                else { *(u32x4*)cp = f_to_chunk<T>(v); *(u32x4*)(cp + 4) = f_to_chunk<T>(v + 4); }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) if (n + j < p.N) cp[j] = Elem<T>::from_f(v[j]);
-            }
+            if (PIPE && t + DEPTH < NSTEP) issue(t + DEPTH);   // recycle this step's operand registers
         }
     }
     if (p.stats_part) {
@@ -689,7 +724,10 @@ extern "C" const char* rpe_last_kernel_name(void) { return g_last_kernel; }
 
 template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE> static int launch_nt_role(NTArgs<T>& a, hipStream_t s, long nwg) {
     snprintf(g_last_kernel, sizeof(g_last_kernel), "nt_kernel<%s,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", WAVES_M, BN, KCH, MODE, NST, ROLE);
-    hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE>), dim3((unsigned)nwg), dim3(128 * WAVES_M), 0, s, a);
+    // RPE_NO_EPI_PIPE=1: data-gradient epilogue without the operand prefetch (A/B experiments)
+    static const bool no_pipe = getenv("RPE_NO_EPI_PIPE") != nullptr;
+    if (ROLE == 1 && no_pipe) hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, false>), dim3((unsigned)nwg), dim3(128 * WAVES_M), 0, s, a);
+    else hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, true>), dim3((unsigned)nwg), dim3(128 * WAVES_M), 0, s, a);
     RPE_CHECK_LAUNCH();
     return 0;
 }

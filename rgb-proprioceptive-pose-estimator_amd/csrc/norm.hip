@@ -1,6 +1,7 @@
 // BatchNorm (train / eval), ReLU, residual add, pooling, layout staging: HBM-bound NHWC kernels.
 // All tensors are [rows][C] with C contiguous; every thread moves 16-byte chunks.
 #include "common.h"
+#include <cstdlib>
 
 namespace rpe {
 
@@ -86,24 +87,55 @@ __global__ void bn_eval_affine_kernel(int C, const float* gamma, const float* be
 // ---------------------------------------------------------------------------------------------
 // BN apply (+ residual) (+ ReLU):  a = relu(y*scale + shift + res)
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+// streaming-kernel load/store helpers: NT = non-temporal (the operand is not read again before it would be evicted anyway)
+template <bool NT> __device__ inline u32x4 ld16(const void* p) {
+    if (NT) return __builtin_nontemporal_load((const u32x4*)p);
+    return *(const u32x4*)p;
+}
+template <bool NT> __device__ inline void st16(void* p, const u32x4& v) {
+    if (NT) __builtin_nontemporal_store(v, (u32x4*)p);
+    else *(u32x4*)p = v;
+}
+
+// gridDim.x * 256 is a multiple of C/CE (launcher), so a thread's channel chunk is fixed and scale/shift live in registers;
+// UNR independent 16-byte loads per operand are issued before any of them is consumed.
+template <typename T, int UNR, bool NT>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ out,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
                                                       long nchunks, int C, int relu) {
     constexpr int CE = Elem<T>::kChunk;
     const int cpr = C / CE;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % cpr) * CE;
-        float v[CE], r[CE];
-        chunk_to_f<T>(*(const u32x4*)(y + i * CE), v);
-        if (res) chunk_to_f<T>(*(const u32x4*)(res + i * CE), r);
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const int c0 = (int)(i0 % cpr) * CE;
+    float sc[CE], sh[CE];
 #pragma unroll
-        for (int e = 0; e < CE; ++e) {
-            float t = fmaf(v[e], scale[c0 + e], shift[c0 + e]);  // same expression as the fused dgrad epilogue's mask
-            if (res) t += r[e];
-            v[e] = relu ? fmaxf(t, 0.f) : t;
+    for (int e = 0; e < CE; ++e) { sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e]; }
+    for (long i = i0; i < nchunks; i += stride * UNR) {
+        u32x4 vy[UNR], vr[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long j = i + u * stride;
+            if (j < nchunks) {
+                vy[u] = ld16<NT>(y + j * CE);
+                if (res) vr[u] = ld16<NT>(res + j * CE);
+            }
         }
-        *(u32x4*)(out + i * CE) = f_to_chunk<T>(v);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long j = i + u * stride;
+            if (j >= nchunks) break;
+            float v[CE], r[CE];
+            chunk_to_f<T>(vy[u], v);
+            if (res) chunk_to_f<T>(vr[u], r);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                float t = fmaf(v[e], sc[e], sh[e]);  // same expression as the fused dgrad epilogue's mask
+                if (res) t += r[e];
+                v[e] = relu ? fmaxf(t, 0.f) : t;
+            }
+            *(u32x4*)(out + j * CE) = f_to_chunk<T>(v);
+        }
     }
 }
 
@@ -195,7 +227,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 }
 
 // pass 3 when dz is already materialised (fused data-gradient epilogue): dy = gamma*invstd*(dz - c1 - xhat*c2)
-template <typename T>
+template <typename T, int UNR, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_dz_kernel(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                              const float* __restrict__ c1, const float* __restrict__ c2, T* __restrict__ dy,
@@ -204,6 +236,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_dz_kernel(const T* __restric
     const int cpr = C / CE;
     // gridDim.x * 256 is a multiple of cpr (launcher), so a thread's channel chunk is fixed: coefficients live in registers
     const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
     const int c0 = (int)(i0 % cpr) * CE;
     float k0[CE], k1[CE], k2[CE];  // dy = k0*dz + k1 + k2*y
 #pragma unroll
@@ -213,13 +246,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_dz_kernel(const T* __restric
         k2[e] = -gi * invstd[c0 + e] * c2[c0 + e];
         k1[e] = -gi * c1[c0 + e] - k2[e] * mean[c0 + e];
     }
-    for (long i = i0; i < nchunks; i += (long)gridDim.x * blockDim.x) {
-        float d[CE], yy[CE];
-        chunk_to_f<T>(*(const u32x4*)(dz + i * CE), d);
-        chunk_to_f<T>(*(const u32x4*)(y + i * CE), yy);
+    for (long i = i0; i < nchunks; i += stride * UNR) {
+        u32x4 vd[UNR], vy[UNR];
 #pragma unroll
-        for (int e = 0; e < CE; ++e) d[e] = fmaf(k0[e], d[e], fmaf(k2[e], yy[e], k1[e]));
-        *(u32x4*)(dy + i * CE) = f_to_chunk<T>(d);
+        for (int u = 0; u < UNR; ++u) {
+            const long j = i + u * stride;
+            if (j < nchunks) { vd[u] = ld16<NT>(dz + j * CE); vy[u] = ld16<NT>(y + j * CE); }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long j = i + u * stride;
+            if (j >= nchunks) break;
+            float d[CE], yy[CE];
+            chunk_to_f<T>(vd[u], d);
+            chunk_to_f<T>(vy[u], yy);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) d[e] = fmaf(k0[e], d[e], fmaf(k2[e], yy[e], k1[e]));
+            *(u32x4*)(dy + j * CE) = f_to_chunk<T>(d);
+        }
     }
 }
 
@@ -399,6 +443,29 @@ static inline int ew_grid(long n, int per_block = 256) {
     return (int)g;
 }
 
+// streaming BN kernels: unroll / grid cap / non-temporal loads (RPE_EW_UNR, RPE_EW_GRID, RPE_EW_NT for experiments)
+struct EwCfg { int unr; long cap; bool nt; };
+static inline EwCfg ew_cfg() {
+    static const EwCfg c = [] {
+        EwCfg v{4, 8192, false};
+        if (const char* e = getenv("RPE_EW_UNR")) v.unr = atoi(e);
+        if (const char* e = getenv("RPE_EW_GRID")) v.cap = atol(e);
+        if (const char* e = getenv("RPE_EW_NT")) v.nt = atoi(e) != 0;
+        return v;
+    }();
+    return c;
+}
+// grid for `n` 16-byte chunks of rows with `cpr` chunks each: grid*256 a multiple of cpr, one thread covers >= unr chunks
+static inline long ew_grid_rows(long n, int cpr, const EwCfg& cfg) {
+    long g = (n + 256L * cfg.unr - 1) / (256L * cfg.unr);
+    if (g > cfg.cap) g = cfg.cap;
+    if (g < 1) g = 1;
+    long a = cpr, b = 256;
+    while (b) { const long t = a % b; a = b; b = t; }
+    const long mult = cpr / a;  // cpr / gcd(cpr, 256)
+    return (g + mult - 1) / mult * mult;
+}
+
 // slices for the staged partial reduction: enough blocks to cover the chip, >= 8 tiles per slice
 static inline int reduce_slices(int tiles, int C) {
     const int colblocks = (C + 31) / 32;
@@ -422,7 +489,14 @@ int bn_apply_launch(const void* y, const void* res, void* out, const float* scal
     constexpr int CE = Elem<T>::kChunk;
     if (C % CE) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply: C must be a multiple of the 16-byte chunk");
     const long n = M * C / CE;
-    hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, s, (const T*)y, (const T*)res, (T*)out, scale, shift, n, C, relu);
+    const int cpr = C / CE;
+    const EwCfg cfg = ew_cfg();
+    const long g = ew_grid_rows(n, cpr, cfg);
+    if ((g * 256) % cpr) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply: C/chunk must divide grid*256 (power-of-two channel counts)");
+#define RPE_BN_APPLY(U, N) hipLaunchKernelGGL((bn_apply_kernel<T, U, N>), dim3((unsigned)g), dim3(256), 0, s, (const T*)y, (const T*)res, (T*)out, scale, shift, n, C, relu)
+    if (cfg.nt) { if (cfg.unr == 1) RPE_BN_APPLY(1, true); else if (cfg.unr == 2) RPE_BN_APPLY(2, true); else RPE_BN_APPLY(4, true); }
+    else { if (cfg.unr == 1) RPE_BN_APPLY(1, false); else if (cfg.unr == 2) RPE_BN_APPLY(2, false); else RPE_BN_APPLY(4, false); }
+#undef RPE_BN_APPLY
     RPE_CHECK_LAUNCH();
     return 0;
 }
@@ -473,12 +547,13 @@ int bn_bwd_from_dz_launch(const void* dz, const void* y, const float* mean, cons
     RPE_CHECK_LAUNCH();
     const long n = M * C / CE;
     // grid * 256 must be a multiple of chunks-per-row (cpr is a power of two <= 512 for every ResNet width)
-    long g = ew_grid(n);
-    const long mult = cpr > 256 ? cpr / 256 : 1;
-    g = (g + mult - 1) / mult * mult;
+    const EwCfg cfg = ew_cfg();
+    const long g = ew_grid_rows(n, cpr, cfg);
     if ((g * 256) % cpr) return rpe_set_error(RPE_ERR_SHAPE, "bn_bwd_from_dz: C/chunk must be a power of two");
-    hipLaunchKernelGGL((bn_bwd_apply_dz_kernel<T>), dim3((unsigned)g), dim3(256), 0, s, (const T*)dz, (const T*)y, mean, invstd, gamma,
-                       (const float*)c1, (const float*)c2, (T*)dy, n, C);
+#define RPE_BN_DZ(U, N) hipLaunchKernelGGL((bn_bwd_apply_dz_kernel<T, U, N>), dim3((unsigned)g), dim3(256), 0, s, (const T*)dz, (const T*)y, mean, invstd, gamma, (const float*)c1, (const float*)c2, (T*)dy, n, C)
+    if (cfg.nt) { if (cfg.unr == 1) RPE_BN_DZ(1, true); else if (cfg.unr == 2) RPE_BN_DZ(2, true); else RPE_BN_DZ(4, true); }
+    else { if (cfg.unr == 1) RPE_BN_DZ(1, false); else if (cfg.unr == 2) RPE_BN_DZ(2, false); else RPE_BN_DZ(4, false); }
+#undef RPE_BN_DZ
     RPE_CHECK_LAUNCH();
     return 0;
 }
