@@ -118,7 +118,10 @@ int rpe_stage_frames_u8(int dtype, const unsigned char* frames, void* out, int B
 /* replaces: nn.BatchNorm2d (train mode: biased batch variance, eps, momentum with
  * unbiased running variance) + the in-place nn.ReLU and `out += identity` of the
  * torchvision Bottleneck. */
-/* dpart: RPE_BN_MAX_SLICES*2*C doubles of scratch for the staged (deterministic) partial-sum reduction */
+/* dpart: RPE_BN_DPART_DOUBLES(C) doubles of scratch for the staged (deterministic) partial-sum reduction: 64 doubles that hold
+ * the arrival counters of the fused reduce+finalize launch, then the slice sums.  The first 64 doubles must be ZERO before the
+ * first use (the kernels leave them zero again); two launches that may run concurrently need separate dpart buffers. */
+#define RPE_BN_DPART_DOUBLES(C) ((long)RPE_BN_MAX_SLICES * 2 * (C) + 64)
 #define RPE_BN_MAX_SLICES 256
 int rpe_bn_finalize(const float* part, int tiles, int C, long count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, long long* num_batches, float momentum, float eps, float* scale, float* shift,

@@ -232,7 +232,7 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
     e->bwd_part_floats = 1024L * 2 * 2048;
     want(e, (void**)&e->bwd_part, e->bwd_part_floats * 4);
     want(e, (void**)&e->c1c2, 2 * 2048 * 4L);
-    want(e, (void**)&e->dpart, (long)RPE_BN_MAX_SLICES * 2 * 2048 * 8);
+    want(e, (void**)&e->dpart, RPE_BN_DPART_DOUBLES(2048) * 8);
     want(e, (void**)&e->stem_dw, 64L * 256 * 4);
     want(e, (void**)&e->pack_tab, 64L * sizeof(rpe_pack_desc));
     for (auto& c : e->convs) {
@@ -351,6 +351,8 @@ extern "C" int rpe_resnet50_bind(rpe_resnet50_t* e, void* workspace, long worksp
         e->pack_total = start;
         if (hipError_t he = hipMemcpy(e->pack_tab, tab.data(), tab.size() * sizeof(rpe_pack_desc), hipMemcpyHostToDevice))
             return rpe_set_error_hip(he, __FILE__, __LINE__);
+        // arrival counters of the fused BN reduce+finalize launches start at zero (and are left at zero by every launch)
+        if (hipError_t he = hipMemset(e->dpart, 0, 64 * sizeof(double))) return rpe_set_error_hip(he, __FILE__, __LINE__);
     }
     e->gspan_lo = nullptr; e->gspan_bytes = 0;
     if (grads_host) {
@@ -556,7 +558,16 @@ extern "C" int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_fea
     hipStream_t s = (hipStream_t)stream;
     if (e->overlap && !e->side) {
         if (getenv("RPE_NO_OVERLAP")) e->overlap = false;
-        else HIPTRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+        else {
+            // weight gradients are off the critical path (the data-gradient chain is): RPE_SIDE_PRIO=low|high asks for a
+            // lower / higher dispatch priority than the caller's stream (experiment switch; default: same priority)
+            int least = 0, greatest = 0;
+            HIPTRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            const char* pr = getenv("RPE_SIDE_PRIO");
+            if (pr && pr[0] == 'l') HIPTRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, least));
+            else if (pr && pr[0] == 'h') HIPTRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, greatest));
+            else HIPTRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+        }
     }
     e->sync_next = 0;
     for (int i = 0; i < 4; ++i) { e->pend_buf[i] = nullptr; e->pend_ev[i] = nullptr; }

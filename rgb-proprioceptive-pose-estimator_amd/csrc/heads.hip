@@ -346,26 +346,67 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __re
     }
 }
 
-// all conv layers of a trunk in ONE launch: a table of per-layer descriptors, flat element index space
+template <typename T> __device__ inline void store4(T* o, float a, float b, float c, float d);
+template <> __device__ inline void store4<float>(float* o, float a, float b, float c, float d) { *(f32x4*)o = f32x4{a, b, c, d}; }
+template <> __device__ inline void store4<bf16>(bf16* o, float a, float b, float c, float d) {
+    u32x2 v; v.x = pack_bf16x2(a, b); v.y = pack_bf16x2(c, d);
+    *(u32x2*)o = v;
+}
+
+// all conv layers of a trunk in ONE launch: a table of per-layer descriptors, flat element index space.
+// Layers whose Co and Ci are multiples of 64 (every trunk conv) go 64x64 tile by tile through LDS, so both the source read
+// and the two destination writes (forward layout = source order; data-gradient layout = [Ci][RS][Co], a transpose) move
+// whole 128/256-byte rows; other layers fall back to element-wise scatter.
 template <typename T>
 __global__ __launch_bounds__(256) void pack_conv_weights_multi_kernel(const rpe_pack_desc* __restrict__ tab, int nlayers, long total) {
     __shared__ long starts[128];
+    __shared__ float tile[64][65];
     for (int i = threadIdx.x; i <= nlayers && i < 128; i += blockDim.x) starts[i] = i < nlayers ? tab[i].start : total;
     __syncthreads();
-    const long chunk = 2048;
+    const long chunk = 4096;   // one 64x64 tile; layer starts are multiples of it whenever Co, Ci are multiples of 64
+    const int tr = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 4;
     for (long base = (long)blockIdx.x * chunk; base < total; base += (long)gridDim.x * chunk) {
         int l = 0;
         while (l + 1 < nlayers && starts[l + 1] <= base) ++l;
+        const rpe_pack_desc d = tab[l];
+        const bool tiled = (d.Co % 64 == 0) && (d.Ci % 64 == 0) && (d.start % chunk == 0) && starts[l + 1] >= base + chunk;
+        if (tiled) {
+            const long t = (base - d.start) / chunk;
+            const int cit = d.Ci / 64;
+            const int ci0 = (int)(t % cit) * 64;
+            const int rs = (int)((t / cit) % d.RS);
+            const int co0 = (int)(t / ((long)cit * d.RS)) * 64;
+            __syncthreads();   // previous tile fully consumed
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int co = tr + 16 * it;
+                const long j = ((long)(co0 + co) * d.RS + rs) * d.Ci + ci0 + tc;
+                const f32x4 v = *(const f32x4*)(d.src + j);
+                tile[co][tc] = v.x; tile[co][tc + 1] = v.y; tile[co][tc + 2] = v.z; tile[co][tc + 3] = v.w;
+                if (d.wf) store4<T>((T*)d.wf + j, v.x, v.y, v.z, v.w);
+            }
+            __syncthreads();
+            if (d.wd) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int ci = tr + 16 * it;
+                    store4<T>((T*)d.wd + ((long)(ci0 + ci) * d.RS + rs) * d.Co + co0 + tc, tile[tc][ci], tile[tc + 1][ci], tile[tc + 2][ci],
+                              tile[tc + 3][ci]);
+                }
+            }
+            continue;
+        }
         for (long i = base + threadIdx.x; i < base + chunk && i < total; i += blockDim.x) {
-            while (l + 1 < nlayers && starts[l + 1] <= i) ++l;
-            const rpe_pack_desc d = tab[l];
-            const long j = i - d.start;
-            const int ci = (int)(j % d.Ci);
-            const long t = j / d.Ci;
-            const int rs = (int)(t % d.RS), co = (int)(t / d.RS);
-            const float v = d.src[j];
-            if (d.wf) ((T*)d.wf)[j] = Elem<T>::from_f(v);
-            if (d.wd) ((T*)d.wd)[((long)ci * d.RS + rs) * d.Co + co] = Elem<T>::from_f(v);
+            int ll = l;
+            while (ll + 1 < nlayers && starts[ll + 1] <= i) ++ll;
+            const rpe_pack_desc e = tab[ll];
+            const long j = i - e.start;
+            const int ci = (int)(j % e.Ci);
+            const long t = j / e.Ci;
+            const int rs = (int)(t % e.RS), co = (int)(t / e.RS);
+            const float v = e.src[j];
+            if (e.wf) ((T*)e.wf)[j] = Elem<T>::from_f(v);
+            if (e.wd) ((T*)e.wd)[((long)ci * e.RS + rs) * e.Co + co] = Elem<T>::from_f(v);
         }
     }
 }
@@ -529,7 +570,7 @@ int rpe_pack_conv_weight(int dtype, const float* w_krsc, void* w_fwd, void* w_dg
 
 int rpe_pack_conv_weights_multi(int dtype, const rpe_pack_desc* table_dev, int nlayers, long total, void* stream) {
     if (nlayers <= 0 || nlayers > 127 || total <= 0) return rpe_set_error(RPE_ERR_SHAPE, "pack_conv_weights_multi: bad table");
-    const int grid = (int)((total + 2047) / 2048 < 4096 ? (total + 2047) / 2048 : 4096);
+    const int grid = (int)((total + 4095) / 4096 < 8192 ? (total + 4095) / 4096 : 8192);
     if (dtype == RPE_F32) hipLaunchKernelGGL((pack_conv_weights_multi_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, table_dev, nlayers, total);
     else if (dtype == RPE_BF16) hipLaunchKernelGGL((pack_conv_weights_multi_kernel<bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, table_dev, nlayers, total);
     else return rpe_set_error(RPE_ERR_DTYPE, "pack_conv_weights_multi: unsupported dtype");

@@ -773,6 +773,9 @@ template <typename T> int launch_nt(NTArgs<T>& a, int mode, hipStream_t s) {
     }
     if (mode == MODE_DENSE) {
         if (big) return wide ? launch_nt_cfg<T, 4, 128, 8, MODE_DENSE>(a, s) : launch_nt_cfg<T, 4, 64, 8, MODE_DENSE>(a, s);
+        // few-row Linear layers (the 256-row fusion MLP and ResNet fc: 4..16 tiles of 128x128 on 256 CUs, each walking K alone
+        // at the fp32 MFMA rate -- 277 us for 256x1024x3655): 64x64 tiles / 2 waves put 4..8x as many workgroups on the chip
+        if (!a.stats_part && (long)ceil_div(a.M, 128) * ceil_div(a.N, wide ? 128 : 64) < 96) return launch_nt_cfg<T, 1, 64, 4, MODE_DENSE>(a, s);
         return wide ? launch_nt_cfg<T, 2, 128, 4, MODE_DENSE>(a, s) : launch_nt_cfg<T, 2, 64, 4, MODE_DENSE>(a, s);
     }
     if (big) return wide ? launch_nt_cfg<T, 4, 128, 8, MODE_CONV>(a, s) : launch_nt_cfg<T, 4, 64, 8, MODE_CONV>(a, s);

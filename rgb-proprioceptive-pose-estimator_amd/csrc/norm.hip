@@ -8,55 +8,19 @@ namespace rpe {
 // ---------------------------------------------------------------------------------------------
 // BN forward: finalize batch statistics from the conv epilogue's per-tile partial sums
 // ---------------------------------------------------------------------------------------------
-// part: [tiles][2][C] fp32 partial sums.  Stage 1 (grid = (C/32, NS)): slice s sums tiles s, s+NS, ... in double
-// -> dpart [NS][2][C].  Stage 2 finishes per channel.  Two small launches keep >= 256 blocks busy even for C = 64
-// (one block per 32 channels alone took 1.1 ms on the stem's 25088 tiles).
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int tiles, int C, int NS, double* __restrict__ dpart) {
-    __shared__ double sh[2][8][32];
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double s = 0.0, q = 0.0;
-    if (c < C) {
-        for (int t = blockIdx.y + rl * NS; t < tiles; t += 8 * NS) {
-            s += (double)part[((long)t * 2 + 0) * C + c];
-            q += (double)part[((long)t * 2 + 1) * C + c];
-        }
-    }
-    sh[0][rl][cl] = s;
-    sh[1][rl][cl] = q;
-    __syncthreads();
-    if (rl == 0 && c < C) {
-        for (int i = 1; i < 8; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
-        dpart[((long)blockIdx.y * 2 + 0) * C + c] = s;
-        dpart[((long)blockIdx.y * 2 + 1) * C + c] = q;
-    }
-}
-
-// Sum the NS double slices of channel c with 8 lanes per channel (block = 32 channels x 8 lanes): a single thread walking
-// 256 slices serially cost ~22 us per launch, 2.4 ms per train step over the 106 finalize launches.
-__device__ __forceinline__ void sum_slices(const double* __restrict__ dpart, int NS, int C, int c, double& s, double& q, double (*sh)[8][32]) {
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    s = 0.0; q = 0.0;
-    if (c < C)
-        for (int i = rl; i < NS; i += 8) { s += dpart[((long)i * 2 + 0) * C + c]; q += dpart[((long)i * 2 + 1) * C + c]; }
-    sh[0][rl][cl] = s;
-    sh[1][rl][cl] = q;
-    __syncthreads();
-    if (rl == 0) {
-        for (int i = 1; i < 8; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
-    }
-}
-
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ dpart, int NS, int C, double count,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float* running_mean, float* running_var, long long* num_batches,
-                                                         float momentum, float eps, float* scale, float* shift,
-                                                         float* save_mean, float* save_invstd) {
-    __shared__ double sh[2][8][32];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-    double s, q;
-    sum_slices(dpart, NS, C, c, s, q, sh);
-    if (c < C && (threadIdx.x >> 5) == 0) {
+// part: [tiles][2][C] fp32 partial sums.  One launch, grid = (C/32, NS): slice s sums tiles s, s+NS, ... in double into
+// dpart [NS][2][C]; the LAST slice block of a 32-channel column group to arrive (device-scope counter behind the dpart
+// slices, left at zero again) sums the NS slices in a fixed order and finishes the per-channel work.  Deterministic, and
+// >= 256 blocks stay busy even for C = 64 (one block per 32 channels alone took 1.1 ms on the stem's 25088 tiles); the
+// separate finalize launch this replaces cost ~5 us x 106 launches per train step.
+struct BnFwdFin {
+    double count;
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    long long* num_batches;
+    float momentum, eps;
+    float *scale, *shift, *save_mean, *save_invstd;
+    __device__ void operator()(int c, double s, double q) const {
         const double mean = s / count;
         double var = q / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -71,8 +35,73 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
         }
+        if (num_batches && c == 0) *num_batches += 1;
     }
-    if (num_batches && blockIdx.x == 0 && threadIdx.x == 0) *num_batches += 1;
+};
+// BN backward pass 2: dgamma, dbeta and the two per-channel coefficients of pass 3
+struct BnBwdFin {
+    double count;
+    float *dgamma, *dbeta, *c1, *c2;
+    __device__ void operator()(int c, double s, double q) const {
+        if (dbeta) dbeta[c] = (float)s;
+        if (dgamma) dgamma[c] = (float)q;
+        c1[c] = (float)(s / count);
+        c2[c] = (float)(q / count);
+    }
+};
+
+template <typename Fin>
+__global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ part, int tiles, int C, int NS, double* dpart,
+                                                             unsigned* counters, const Fin fin) {
+    __shared__ double sh[2][8][32];
+    __shared__ int last;
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        for (int t = blockIdx.y + rl * NS; t < tiles; t += 8 * NS) {
+            s += (double)part[((long)t * 2 + 0) * C + c];
+            q += (double)part[((long)t * 2 + 1) * C + c];
+        }
+    }
+    sh[0][rl][cl] = s;
+    sh[1][rl][cl] = q;
+    __syncthreads();
+    if (rl == 0) {
+        for (int i = 1; i < 8; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
+    }
+    if (NS > 1) {
+        // Hand-off without an agent-scope release/acquire FENCE: on this chip such a fence writes back / invalidates the
+        // whole XCD L2 (full of the conv output just written) and cost ~20 us per launch.  Instead the slice sums are stored
+        // and re-read with agent-scope (write-through / L2-bypassing) atomics, the stores are waited for, and only then the
+        // arrival is counted.
+        if (rl == 0 && c < C) {
+            __hip_atomic_store(&dpart[((long)blockIdx.y * 2 + 0) * C + c], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&dpart[((long)blockIdx.y * 2 + 1) * C + c], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned prev = __hip_atomic_fetch_add(&counters[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = prev == (unsigned)NS - 1;
+            if (last) __hip_atomic_store(&counters[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all arrivals are in
+        }
+        __syncthreads();
+        if (!last) return;
+        s = 0.0; q = 0.0;
+        if (c < C)
+            for (int i = rl; i < NS; i += 8) {
+                s += __hip_atomic_load(&dpart[((long)i * 2 + 0) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q += __hip_atomic_load(&dpart[((long)i * 2 + 1) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        sh[0][rl][cl] = s;
+        sh[1][rl][cl] = q;
+        __syncthreads();
+        if (rl == 0) {
+            for (int i = 1; i < 8; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
+        }
+    }
+    if (rl == 0 && c < C) fin(c, s, q);
 }
 
 __global__ void bn_eval_affine_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
@@ -182,20 +211,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         const int c = i >> 1, which = i & 1;
         part[((long)blockIdx.x * 2 + which) * C + blockIdx.y * SW + c] = t;
     }
-}
-
-// pass 2: (reduce_partials_kernel, then) dgamma, dbeta and the two per-channel coefficients of pass 3
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ dpart, int NS, int C, double count,
-                                                             float* dgamma, float* dbeta, float* c1, float* c2) {
-    __shared__ double sh[2][8][32];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-    double s, q;
-    sum_slices(dpart, NS, C, c, s, q, sh);
-    if (c >= C || (threadIdx.x >> 5) != 0) return;
-    if (dbeta) dbeta[c] = (float)s;
-    if (dgamma) dgamma[c] = (float)q;
-    c1[c] = (float)(s / count);
-    c2[c] = (float)(q / count);
 }
 
 // pass 3: dy = gamma*invstd*(dz - c1 - xhat*c2); optionally also emits dz (gradient of the residual branch)
@@ -476,11 +491,13 @@ static inline int reduce_slices(int tiles, int C) {
     if (ns < 1) ns = 1;
     return ns;
 }
-static int reduce_partials(const float* part, int tiles, int C, double* dpart, int* ns_out, hipStream_t s) {
+template <typename Fin>
+static int reduce_finalize(const float* part, int tiles, int C, double* dpart, const Fin& fin, hipStream_t s) {
+    if (C > 32 * 128) return rpe_set_error(RPE_ERR_SHAPE, "bn: more than 4096 channels");
     const int ns = reduce_slices(tiles, C);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 31) / 32, ns), dim3(256), 0, s, part, tiles, C, ns, dpart);
+    unsigned* counters = (unsigned*)dpart;   // RPE_BN_DPART_DOUBLES(C): 64 doubles of counters (128 column groups), then the slices
+    hipLaunchKernelGGL((reduce_finalize_kernel<Fin>), dim3((C + 31) / 32, ns), dim3(256), 0, s, part, tiles, C, ns, dpart + 64, counters, fin);
     RPE_CHECK_LAUNCH();
-    *ns_out = ns;
     return 0;
 }
 
@@ -522,10 +539,7 @@ int bn_bwd_launch(const void* dA, const void* a_out, const void* y, const float*
     RPE_CHECK_LAUNCH();
     float* c1 = c1c2;
     float* c2 = c1c2 + C;
-    int ns = 0;
-    if (int e = reduce_partials(part, (int)nb, C, dpart, &ns, s)) return e;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, (const double*)dpart, ns, C, (double)M, dgamma, dbeta, c1, c2);
-    RPE_CHECK_LAUNCH();
+    if (int e = reduce_finalize(part, (int)nb, C, dpart, BnBwdFin{(double)M, dgamma, dbeta, c1, c2}, s)) return e;
     const long n = M * C / CE;
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, s, (const T*)dA, (const T*)a_out, (const T*)y, mean, invstd, gamma,
                        (const float*)c1, (const float*)c2, (T*)dy, (T*)dz_out, n, C);
@@ -539,12 +553,9 @@ int bn_bwd_from_dz_launch(const void* dz, const void* y, const float* mean, cons
     constexpr int CE = Elem<T>::kChunk;
     if (C % CE) return rpe_set_error(RPE_ERR_SHAPE, "bn_bwd_from_dz: C must be a multiple of the 16-byte chunk");
     const int cpr = C / CE;
-    int ns = 0;
-    if (int e = reduce_partials(stats_part, tiles, C, dpart, &ns, s)) return e;
     float* c1 = c1c2;
     float* c2 = c1c2 + C;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, (const double*)dpart, ns, C, (double)M, dgamma, dbeta, c1, c2);
-    RPE_CHECK_LAUNCH();
+    if (int e = reduce_finalize(stats_part, tiles, C, dpart, BnBwdFin{(double)M, dgamma, dbeta, c1, c2}, s)) return e;
     const long n = M * C / CE;
     // grid * 256 must be a multiple of chunks-per-row (cpr is a power of two <= 512 for every ResNet width)
     const EwCfg cfg = ew_cfg();
@@ -568,12 +579,8 @@ int rpe_bn_finalize(const float* part, int tiles, int C, long count, const float
                     float* running_var, long long* num_batches, float momentum, float eps, float* scale, float* shift,
                     float* save_mean, float* save_invstd, double* dpart, void* stream) {
     if (tiles <= 0 || C <= 0 || count <= 0) return rpe_set_error(RPE_ERR_SHAPE, "bn_finalize: empty problem");
-    int ns = 0;
-    if (int e = reduce_partials(part, tiles, C, dpart, &ns, (hipStream_t)stream)) return e;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, (const double*)dpart, ns, C, (double)count, gamma,
-                       beta, running_mean, running_var, num_batches, momentum, eps, scale, shift, save_mean, save_invstd);
-    RPE_CHECK_LAUNCH();
-    return 0;
+    return reduce_finalize(part, tiles, C, dpart, BnFwdFin{(double)count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, scale,
+                                                           shift, save_mean, save_invstd}, (hipStream_t)stream);
 }
 
 int rpe_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,

@@ -100,7 +100,7 @@ def bn_backward_from_dz(dz, y, mean, invstd, gamma, stats_part):
     dbeta = torch.empty(c, dtype=torch.float32, device=dev)
     dy = torch.empty_like(y)
     c1c2 = torch.empty(2 * c, dtype=torch.float32, device=dev)
-    dpart = torch.empty(256 * 2 * c, dtype=torch.float64, device=dev)
+    dpart = torch.zeros(256 * 2 * c + 64, dtype=torch.float64, device=dev)  # RPE_BN_DPART_DOUBLES(c); counters start at zero
     lib.rpe_bn_backward_from_dz(dtype_code(y), _p(dz), _p(y), _p(mean), _p(invstd), _p(gamma), _p(stats_part), stats_part.shape[0], _p(dgamma),
                                 _p(dbeta), _p(dy), y.numel() // c, c, _p(c1c2), _p(dpart), _stream())
     return dy, dgamma, dbeta
@@ -161,7 +161,7 @@ def bn_finalize(part, count, gamma, beta, running_mean=None, running_var=None, n
     tiles, _, c = part.shape
     dev = part.device
     scale, shift, mean, invstd = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(4))
-    dpart = torch.empty(256 * 2 * c, dtype=torch.float64, device=dev)
+    dpart = torch.zeros(256 * 2 * c + 64, dtype=torch.float64, device=dev)  # RPE_BN_DPART_DOUBLES(c); counters start at zero
     lib.rpe_bn_finalize(_p(part), tiles, c, count, _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(num_batches),
                         momentum, eps, _p(scale), _p(shift), _p(mean), _p(invstd), _p(dpart), _stream())
     return scale, shift, mean, invstd
@@ -183,7 +183,7 @@ def bn_backward(dA, a_out, y, mean, invstd, gamma, want_dz=False):
     dz = torch.empty_like(y) if want_dz else None
     part = torch.empty(2 * 1024 * c, dtype=torch.float32, device=dev)
     c1c2 = torch.empty(2 * c, dtype=torch.float32, device=dev)
-    dpart = torch.empty(256 * 2 * c, dtype=torch.float64, device=dev)
+    dpart = torch.zeros(256 * 2 * c + 64, dtype=torch.float64, device=dev)  # RPE_BN_DPART_DOUBLES(c); counters start at zero
     lib.rpe_bn_backward(dtype_code(y), _p(dA), _p(a_out), _p(y), _p(mean), _p(invstd), _p(gamma), _p(dgamma), _p(dbeta), _p(dy), _p(dz),
                         y.numel() // c, c, _p(part), part.numel(), _p(c1c2), _p(dpart), _stream())
     return dy, dgamma, dbeta, dz
