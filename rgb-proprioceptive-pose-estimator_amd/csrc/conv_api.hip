@@ -58,6 +58,7 @@ static int conv_fwd_t(const rpe_conv_desc* d, const void* x, const void* w, void
     g.sn = d->stride; g.sd_shift = 0; g.base_h = -d->pad; g.base_w = -d->pad; g.tap_sign = 1;
     g.div_hw = make_fastdiv(Ho * Wo); g.div_w = make_fastdiv(Wo);
     g.img_stride = (long)d->in_h * d->in_w * d->in_c;
+    a.a_elems = (long)d->batch * g.img_stride;
     return launch_nt<T>(a, MODE_CONV, s);
 }
 
@@ -85,6 +86,7 @@ static int conv_dgrad_t(const rpe_conv_desc* d, const void* dy, const void* w_cr
     g.sn = 1; g.sd_shift = ilog2(d->stride); g.base_h = d->pad; g.base_w = d->pad; g.tap_sign = -1;
     g.div_hw = make_fastdiv(d->in_h * d->in_w); g.div_w = make_fastdiv(d->in_w);
     g.img_stride = (long)Ho * Wo * d->out_c;
+    a.a_elems = (long)d->batch * g.img_stride;
     if (dgrad_parity(d)) {
         // enumerate output pixels per parity class; Ho/Wo of the row space become the half dims
         g.parity = 1;

@@ -49,6 +49,8 @@ template <typename T> struct NTArgs {
     const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
     int tiles_m, tiles_n;
     int role;            // 0 conv forward, 1 conv data-gradient, 2 Linear (kernel symbol tag for profiles)
+    long a_elems;        // elements of the tensor behind A (conv modes; 0 = dense, derived from M and lda)
+    unsigned a_bytes, b_bytes;   // buffer-descriptor extents of A and Bw (filled by the launcher, < 2 GiB each)
 };
 
 template <typename T> struct TNArgs {

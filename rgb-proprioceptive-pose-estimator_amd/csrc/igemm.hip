@@ -1,747 +1,16 @@
-// MFMA implicit-GEMM kernels for gfx950 (CDNA4, wave64).
-//
-//   nt_kernel : C[M][N] = gather(A)[M][K] * W[N][K]^T  (+bias, +addend, relu, BN partial stats)
-//               conv forward, conv data-gradient, Linear forward / data-gradient.
-//   tn_kernel : D[I][J] += sum_m P[m][I] * gather(Q)[m][J]   (fp32 atomics)
-//               conv weight-gradient, Linear weight-gradient.
-//
-// Layout: activations NHWC (channels contiguous), weights [N][K] with K = (r, s, c) contiguous.
-// Both operands are staged global -> registers -> LDS in 16-byte chunks (4 chunks = one
-// MFMA K-step per row: 32 bf16 or 16 f32), double buffered, one barrier per K-step.
-// The weight tile is the MFMA "A" operand and the activation tile the "B" operand, so the
-// accumulator registers of a lane run along N (channels): the epilogue stores 4 consecutive
-// channels per lane straight to NHWC memory (8 B bf16 / 16 B f32) without an LDS transpose.
+// Implicit-GEMM entry points: argument checks and dispatch to the per-type / per-mode instantiation units
+// (igemm_nt_*.hip, igemm_tn_*.hip; kernels and configuration choice live in igemm_impl.h).
 #include <stdio.h>
 #include <stdlib.h>
+#include <stdint.h>
 
 #include "igemm.h"
 
 namespace rpe {
 
-// LDS slot permutation of the [row][KCH x 16 B] staging tiles (slot = chunk ^ f(row)).
-// KCH = 4 (64-B rows): f = {0,2,3,1}[(row>>2)&3].  ds_read_b128 is serviced in the 16-lane groups {0-3,12-15,20-27},
-// {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md, LDS); with lane -> (row = l&15, chunk = l>>4) this f puts the four
-// row-quads of every group on four different 16-byte slots.  KCH = 8 (128-B rows): f = row & 7 (T2 of the guide).
-template <int KCH> __device__ __forceinline__ int nt_swz(int row, int chunk) {
-    if (KCH == 4) return chunk ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3);
-    return chunk ^ (row & 7);
-}
+thread_local char g_last_kernel[96] = "";
 
-// Bijective XCD remap: consecutive logical tiles share one XCD's L2 (blocks b, b+8 share an XCD).
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-}
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16> {
-    __device__ static __forceinline__ void run(const u32x4& w, const u32x4& a, f32x4& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
-    }
-};
-template <> struct Mma<float> {
-    // lane (row = l&15, g = l>>4) holds k = 4g..4g+3 of its row; step kk multiplies component kk
-    // of both operands, i.e. the K order inside a 16-wide step is permuted identically on both sides.
-    __device__ static __forceinline__ void run(const u32x4& w, const u32x4& a, f32x4& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.x), __uint_as_float(a.x), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.y), __uint_as_float(a.y), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.z), __uint_as_float(a.z), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.w), __uint_as_float(a.w), acc, 0, 0, 0);
-    }
-};
-
-// 16 bytes of zeros in device memory: the LDS-DMA source for padding taps and tile tails
-__device__ __attribute__((aligned(16))) const unsigned rpe_zero16[4] = {0u, 0u, 0u, 0u};
-
-__device__ __forceinline__ u32x4 ld16(const void* p) { return *(const u32x4*)p; }
-__device__ __forceinline__ u32x4 zero16() { u32x4 z = {0u, 0u, 0u, 0u}; return z; }
-
-// One 16-byte chunk of the stem (conv1) im2col row: x4 is [B][H][W][4], k = (r*8 + s)*4 + c with the
-// 7x7 taps padded to 8x8 (tap 7 reads as zero).  A chunk covers 2 pixels (bf16) or 1 pixel (f32).
-template <typename T>
-__device__ __forceinline__ u32x4 stem_chunk(const T* x, long img_base, int hb, int wb, int H, int W, int k, bool ok) {
-    constexpr int CE = Elem<T>::kChunk;
-    const int r = k >> 5, s0 = (k & 31) >> 2;
-    const int ih = hb + r;
-    u32x4 v = zero16();
-    if (!ok || r >= 7 || ih < 0 || ih >= H) return v;
-    if (CE == 4) {
-        const int iw = wb + s0;
-        if (s0 < 7 && iw >= 0 && iw < W) v = ld16(x + img_base + ((long)ih * W + iw) * 4);
-    } else {
-        const int iw0 = wb + s0, iw1 = iw0 + 1;
-        if (s0 < 7 && iw0 >= 0 && iw0 < W) { u32x2 t = *(const u32x2*)(x + img_base + ((long)ih * W + iw0) * 4); v.x = t.x; v.y = t.y; }
-        if (s0 + 1 < 7 && iw1 >= 0 && iw1 < W) { u32x2 t = *(const u32x2*)(x + img_base + ((long)ih * W + iw1) * 4); v.z = t.x; v.w = t.y; }
-    }
-    return v;
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// -----------------------------------------------------------------------------------------------
-// NT kernel.  Tile BM x BN = (64*WAVES_M) x BN, 2*WAVES_M waves of 64 x (BN/2), K-step = KCH 16-byte chunks per row.
-//   small config  <2, 128|64, 4>: 128-row tile, 64-B rows   (heads, stem, tiny problems)
-//   large config  <4, 128|64, 8>: 256-row tile, 128-B rows  (conv trunk): 2x the FLOPs per byte pulled from L2 into LDS
-//   and every DMA instruction moves whole 128-B lines -- at 128x128x32 the kernel sat at ~16 B/clk/CU of L2->LDS traffic.
-// -----------------------------------------------------------------------------------------------
-// ROLE only tells the symbols apart in profiles: 0 conv forward, 1 conv data-gradient, 2 Linear.
-template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE, bool EPI_PIPE = true>
-__global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
-    constexpr int CE = Elem<T>::kChunk, BK = KCH * CE;
-    constexpr int NW = 2 * WAVES_M, NTHR = 64 * NW;
-    constexpr int BM = 64 * WAVES_M, WM = 64, WN = BN / 2, FM = WM / 16, FN = WN / 16;
-    constexpr int RPI = 64 / KCH;                       // rows covered by one 64-lane x 16-B DMA instruction
-    constexpr int AR = BM / RPI / NW, BR = BN / RPI / NW;  // DMA instructions (= 16-B chunks per thread) per K-step
-    static_assert((BM / RPI) % NW == 0 && (BN / RPI) % NW == 0, "tile rows must split evenly over the waves");
-    constexpr int STAGE = (BM + BN) * KCH;             // 16-byte units
-    constexpr int EPI16 = NW * 16 * (WN + 4) / 4;      // epilogue staging (NW waves x 16 rows x (WN+4) floats)
-    constexpr bool DMA = MODE != MODE_STEM;
-    constexpr int NSTAGE = DMA ? NST : 2;              // DMA path: ring of NST slots, NST-1 tiles in flight
-    static_assert(DMA || (WAVES_M == 2 && KCH == 4), "register staging is only wired for the 128-row / 64-B-row config");
-    static_assert(NST >= 2 && NST <= 3, "ring depth 2 or 3");
-    __shared__ u32x4 lds[(NSTAGE * STAGE > EPI16) ? NSTAGE * STAGE : EPI16];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wave_m = wave >> 1, wave_n = wave & 1;
-    const int lb = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int tile_n = lb % p.tiles_n, tile_m = lb / p.tiles_n;
-    const int n0 = tile_n * BN;
-    const Gather& g = p.g;
-    // Row space.  Normal: row m = m0 + local.  Parity mode (stride-2 dgrad): tile_m = tq * 4 + cls (classes interleaved:
-    // they cost 1 : 2 : 2 : 4 taps, and the XCD remap hands each XCD a contiguous tile range -- class-major order left two
-    // XCDs with all the work); local rows index the class-local pixel list (b, h', w') -> output pixel (b, 2h'+ph, 2w'+pw).
-    int cls = 0, ph = 0, pw = 0, m0 = tile_m * BM, row_lim = p.M;
-    if (MODE == MODE_CONV && g.parity) {
-        cls = tile_m & 3;
-        m0 = (tile_m >> 2) * BM;
-        ph = cls >> 1; pw = cls & 1;
-        row_lim = g.rows_q;
-    }
-    // output row (for C / addend / BN operands) of tile-local row index `lr`, or -1 when outside the problem
-    auto out_row = [&](int lr) -> long {
-        const int m = m0 + lr;
-        if (m >= row_lim) return -1;
-        if (!(MODE == MODE_CONV && g.parity)) return m;
-        const unsigned b = fd_div((unsigned)m, g.div_hw);
-        const unsigned rem = (unsigned)m - b * g.div_hw.d;
-        const unsigned hh = fd_div(rem, g.div_w);
-        const unsigned ww = rem - hh * g.div_w.d;
-        return ((long)b * (2 * g.Ho) + (2 * hh + ph)) * (2 * g.Wo) + (2 * ww + pw);
-    };
-    // Staging.  DMA path (dense / conv): global_load_lds_dwordx4 writes 64 lanes x 16 B = RPI rows x KCH slots straight
-    // into LDS (no VGPR round trip, no ds_write).  The LDS image is lane-linear, so the slot swizzle is applied on the
-    // SOURCE side: the lane that fills slot s of row r fetches logical chunk s ^ f(r).  Padding taps / tails fetch from a
-    // 16-byte zero page.  Stem path (two 8-byte pixels per chunk with separate bounds) keeps register staging.
-    int a_row[AR], a_chunk[AR], b_row[BR], b_chunk[BR];
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-        if (DMA) { a_row[i] = (wave * AR + i) * RPI + lane / KCH; a_chunk[i] = nt_swz<KCH>(a_row[i], lane % KCH); }
-        else { a_row[i] = (tid >> 2) + 64 * i; a_chunk[i] = tid & 3; }
-    }
-#pragma unroll
-    for (int i = 0; i < BR; ++i) {
-        if (DMA) { b_row[i] = (wave * BR + i) * RPI + lane / KCH; b_chunk[i] = nt_swz<KCH>(b_row[i], lane % KCH); }
-        else { b_row[i] = (tid >> 2) + 64 * i; b_chunk[i] = tid & 3; }
-    }
-
-    long a_base[AR];
-    int a_hb[AR], a_wb[AR];
-    bool a_ok[AR];
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-        const int m = m0 + a_row[i];
-        a_ok[i] = m < row_lim;
-        a_hb[i] = a_wb[i] = 0;
-        if (MODE == MODE_DENSE) {
-            a_base[i] = (long)m * p.lda + a_chunk[i] * CE;
-        } else {
-            const unsigned mm = a_ok[i] ? (unsigned)m : 0u;
-            const unsigned b = fd_div(mm, g.div_hw);
-            const unsigned rem = mm - b * g.div_hw.d;
-            unsigned oh = fd_div(rem, g.div_w);
-            unsigned ow = rem - oh * g.div_w.d;
-            if (MODE == MODE_CONV && g.parity) { oh = 2 * oh + ph; ow = 2 * ow + pw; }
-            a_base[i] = (long)b * g.img_stride;
-            a_hb[i] = (int)oh * g.sn + g.base_h;
-            a_wb[i] = (int)ow * g.sn + g.base_w;
-        }
-    }
-    long b_off[BR];
-    bool b_ok[BR];
-#pragma unroll
-    for (int i = 0; i < BR; ++i) {
-        const int n = n0 + b_row[i];
-        b_ok[i] = n < p.N;
-        b_off[i] = (long)n * p.ldb + b_chunk[i] * CE;
-    }
-
-    // uniform K-walk state for MODE_CONV: k = (r*S + s)*C + c0.  Parity mode visits taps r0, r0+2, .. x s0, s0+2, ..
-    int kbase = 0, c0 = 0, tr = 0, ts = 0, tstep = 1, s_first = 0;
-    int nk = (p.K + BK - 1) / BK;
-    if (MODE == MODE_CONV && g.parity) {
-        const int r0 = (ph + g.base_h) & 1, s0 = (pw + g.base_w) & 1;
-        const int nr = r0 < g.R ? (g.R - r0 + 1) / 2 : 0, ns = s0 < g.S ? (g.S - s0 + 1) / 2 : 0;
-        tr = r0; ts = s0; s_first = s0; tstep = 2;
-        kbase = (tr * g.S + ts) * g.C;
-        nk = nr * ns * (g.C / BK);
-    }
-
-    // source address of A chunk i for the current K-step, or nullptr for zero fill
-    auto a_src = [&](int i) -> const T* {
-        const bool kok = (kbase + a_chunk[i] * CE) < p.K;
-        if (MODE == MODE_DENSE) return (a_ok[i] && kok) ? p.A + a_base[i] + kbase : nullptr;
-        const int nh = a_hb[i] + g.tap_sign * tr, nw = a_wb[i] + g.tap_sign * ts;
-        const int msk = (1 << g.sd_shift) - 1;
-        const int ih = nh >> g.sd_shift, iw = nw >> g.sd_shift;
-        const bool ok = a_ok[i] && nh >= 0 && nw >= 0 && ((nh | nw) & msk) == 0 && ih < g.H && iw < g.W;
-        return ok ? p.A + a_base[i] + ((long)ih * g.W + iw) * g.C + c0 + a_chunk[i] * CE : nullptr;
-    };
-    auto b_src = [&](int i) -> const T* {
-        const bool kok = (kbase + b_chunk[i] * CE) < p.K;
-        return (b_ok[i] && kok) ? p.Bw + b_off[i] + kbase : nullptr;
-    };
-    auto advance_k = [&]() {
-        kbase += BK;
-        if (MODE == MODE_CONV) {
-            c0 += BK;
-            if (c0 >= g.C) {
-                c0 = 0;
-                ts += tstep;
-                if (ts >= g.S) { ts = s_first; tr += tstep; }
-                if (tstep != 1) kbase = (tr * g.S + ts) * g.C;
-            }
-        }
-    };
-    typedef __attribute__((address_space(3))) char lds_char;
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    auto dma_tile = [&](int st) {
-        lds_char* base = (lds_char*)lds + st * (STAGE * 16);
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const T* src = a_src(i);
-            const void* sp = src ? (const void*)src : (const void*)rpe_zero16;
-            __builtin_amdgcn_global_load_lds((gptr_t)sp, (__attribute__((address_space(3))) void*)(base + (wave * AR + i) * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            const T* src = b_src(i);
-            const void* sp = src ? (const void*)src : (const void*)rpe_zero16;
-            __builtin_amdgcn_global_load_lds((gptr_t)sp, (__attribute__((address_space(3))) void*)(base + BM * KCH * 16 + (wave * BR + i) * 1024), 16, 0, 0);
-        }
-    };
-    u32x4 ra[AR], rb[BR];
-    auto load_tile = [&]() {  // register staging (stem)
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            if (MODE == MODE_STEM) ra[i] = stem_chunk<T>(p.A, a_base[i], a_hb[i], a_wb[i], g.H, g.W, kbase + a_chunk[i] * CE, a_ok[i]);
-            else { const T* src = a_src(i); ra[i] = src ? ld16(src) : zero16(); }
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) { const T* src = b_src(i); rb[i] = src ? ld16(src) : zero16(); }
-    };
-    auto store_tile = [&](int st) {
-        u32x4* base = lds + st * STAGE;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) base[a_row[i] * KCH + nt_swz<KCH>(a_row[i], a_chunk[i])] = ra[i];
-#pragma unroll
-        for (int i = 0; i < BR; ++i) base[BM * KCH + b_row[i] * KCH + nt_swz<KCH>(b_row[i], b_chunk[i])] = rb[i];
-    };
-
-    // ---- epilogue lane geometry (needed early: the data-gradient form prefetches its epilogue operands) ----
-    constexpr int LDW = WN + 4;     // staged row pitch in floats (+4: conflict-free float4 writes)
-    constexpr int CPW = WN / 8;     // 8-channel chunks per staged row
-    constexpr int RPP = 64 / CPW;   // rows per pass
-    constexpr int NPASS = 16 / RPP;
-    constexpr int NSTEP = FM * NPASS;   // epilogue steps of a wave: (fragment, pass) pairs, 8 channels of one row per lane each
-    const int erow = lane / CPW, echk = lane % CPW;
-    const int nl = wave_n * WN + echk * 8;
-    const int n = n0 + nl;
-    const bool ncol_ok = n < p.N;
-    const bool nfull = n + 7 < p.N;
-    const bool vec_c = nfull && (p.ldc % CE == 0) && (((uintptr_t)p.C) & 15) == 0;
-    const bool vec_add = nfull && p.addend && (p.ld_add % CE == 0) && (((uintptr_t)p.addend) & 15) == 0;
-    const int bn_mode = p.bn_mode;
-    // Data-gradient launches with short K are bound by the epilogue's operand stream (residual gradient, y, a_out: up to
-    // three reads and one write per output element against K/N-th of that for the GEMM operands).  One step at a time
-    // keeps ~1-3 KB per wave in flight; here the operands of the next DEPTH steps are requested ahead (the first DEPTH
-    // before the K loop even starts), 16 B per lane and operand, into registers that are recycled step by step.
-    constexpr bool PIPE = (ROLE == 1) && (CE == 8) && EPI_PIPE;
-    constexpr int DEPTH = PIPE ? (NSTEP < 4 ? NSTEP : 4) : 1;
-    u32x4 qd[DEPTH], qy[DEPTH], qa[DEPTH];
-    auto step_row = [&](int t) -> long { return out_row(wave_m * WM + (t / NPASS) * 16 + (t % NPASS) * RPP + erow); };
-    auto issue = [&](int t) {
-        if (!PIPE) return;
-        const long m = step_row(t);
-        const int sl = t % DEPTH;
-        if (m < 0 || !ncol_ok) return;
-        if (vec_add) qd[sl] = ld16(p.addend + m * p.ld_add + n);
-        if (bn_mode && vec_c) {
-            qy[sl] = ld16(p.bn_y + m * p.ldc + n);
-            if (bn_mode == 1) qa[sl] = ld16(p.bn_a + m * p.ldc + n);
-        }
-    };
-    if (PIPE) {
-#pragma unroll
-        for (int t = 0; t < DEPTH; ++t) issue(t);
-    }
-
-    f32x4 acc[FN][FM];
-#pragma unroll
-    for (int a = 0; a < FN; ++a)
-#pragma unroll
-        for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int fr = lane & 15, fc = lane >> 4;
-    auto compute = [&](int st) {
-        const u32x4* base = lds + st * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < KCH / 4; ++ks) {
-            u32x4 af[FM], wf[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) { const int row = wave_m * WM + i * 16 + fr; af[i] = base[row * KCH + nt_swz<KCH>(row, ks * 4 + fc)]; }
-#pragma unroll
-            for (int i = 0; i < FN; ++i) { const int row = wave_n * WN + i * 16 + fr; wf[i] = base[BM * KCH + row * KCH + nt_swz<KCH>(row, ks * 4 + fc)]; }
-#pragma unroll
-            for (int a = 0; a < FN; ++a)
-#pragma unroll
-                for (int b = 0; b < FM; ++b) Mma<T>::run(wf[a], af[b], acc[a][b]);
-        }
-    };
-    if (DMA) {
-        // 3-slot ring, tiles kt+1 and kt+2 in flight while tile kt is multiplied.  A tile is NI LDS-DMA instructions per
-        // wave; vmcnt counts them in issue order, so "all but the newest NI landed" == tile kt+1 is complete.  The raw
-        // s_barrier (not __syncthreads, which would drain vmcnt to 0) then publishes it to the other waves; slot (kt+2)%3
-        // was last read in iteration kt-1, i.e. before the barrier every wave has already passed.
-        constexpr int NI = AR + BR;
-        constexpr int PF = NSTAGE - 1;  // tiles kept in flight ahead of the one being multiplied
-        // prologue: tiles 0 .. PF-1
-#pragma unroll
-        for (int t = 0; t < PF; ++t) {
-            if (t < nk) { if (t > 0) advance_k(); dma_tile(t); }
-        }
-        // tile 0 must have landed: allow the (min(PF, nk) - 1) newer tiles to stay in flight
-        {
-            const int newer = (nk < PF ? nk : PF) - 1;
-            if (newer >= 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
-        }
-        __builtin_amdgcn_s_barrier();
-        int st = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            const bool pre = kt + PF < nk;
-            if (pre) { advance_k(); int s2 = st + PF; if (s2 >= NSTAGE) s2 -= NSTAGE; dma_tile(s2); }
-            compute(st);
-            // tile kt+1 must be complete; tiles kt+2 .. may still be in flight
-            int newer = nk - 2 - kt;               // tiles issued after kt+1
-            if (newer > PF - 1) newer = PF - 1;
-            if (newer >= 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            if (++st == NSTAGE) st = 0;
-        }
-    } else {
-        load_tile();
-        store_tile(0);
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            const bool more = kt + 1 < nk;
-            if (more) { advance_k(); load_tile(); }
-            compute(cur);
-            if (more) store_tile(cur ^ 1);
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue ---------------------------------------------------------------------------------
-    // A lane's accumulators hold 4 channels of 16 scattered rows.  They go through LDS once so that every lane
-    // ends up with 8 consecutive channels of ONE row: epilogue operands (addend, and for the fused BN-backward
-    // form y / a_out) are then read, and the result written, as 16 bytes per lane = whole 128-B lines per 8 lanes.
-    float* stg = (float*)lds + wave * (16 * LDW);  // 16 staged rows (one 16-row fragment) per wave at a time
-    float cs[8], cq[8], cmean[8], cinv[8], csc[8], csh[8], cbias[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        cs[j] = 0.f; cq[j] = 0.f; cmean[j] = 0.f; cinv[j] = 0.f; csc[j] = 0.f; csh[j] = 0.f; cbias[j] = 0.f;
-        if (n + j < p.N) {
-            if (p.bias) cbias[j] = p.bias[n + j];
-            if (bn_mode) { cmean[j] = p.bn_mean[n + j]; cinv[j] = p.bn_invstd[n + j]; }
-            if (bn_mode == 2) { csc[j] = p.bn_scale[n + j]; csh[j] = p.bn_shift[n + j]; }
-        }
-    }
-    auto load8 = [&](const T* base, long off, bool vec, float* out) {
-        if (vec) {
-            if (CE == 8) { chunk_to_f<T>(ld16(base + off), out); }
-            else { chunk_to_f<T>(ld16(base + off), out); chunk_to_f<T>(ld16(base + off + 4), out + 4); }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) out[j] = (n + j < p.N) ? Elem<T>::to_f(base[off + j]) : 0.f;
-        }
-    };
-    // the staging rows are private to a wave and LDS executes a wave's accesses in order: a wave-level fence between its
-    // writes and its cross-lane reads is enough; the workgroup barrier is only needed once, after the K loop
-    auto wave_sync = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-    __syncthreads();   // every wave is done with the K loop's LDS tiles
-#pragma unroll
-    for (int qf = 0; qf < FM; ++qf) {
-        wave_sync();   // this wave's reads of the previous fragment have been issued (LDS is in order per wave)
-#pragma unroll
-        for (int a = 0; a < FN; ++a) *(f32x4*)(stg + fr * LDW + a * 16 + fc * 4) = acc[a][qf];
-        wave_sync();
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const int r = ps * RPP + erow;
-            const int t = qf * NPASS + ps, sl = t % DEPTH;
-            const long m = out_row(wave_m * WM + qf * 16 + r);
-            float v[8];
-            {
-                const f32x4 t0 = *(const f32x4*)(stg + r * LDW + echk * 8);
-                const f32x4 t1 = *(const f32x4*)(stg + r * LDW + echk * 8 + 4);
-                v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
-            }
-            if (m >= 0 && ncol_ok) {
-                if (p.stats_part && !bn_mode) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { cs[j] += v[j]; cq[j] += v[j] * v[j]; }
-                }
-                if (p.bias) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += cbias[j];
-                }
-                if (p.addend) {
-                    float ad[8];
-                    if (PIPE && vec_add) chunk_to_f<T>(qd[sl], ad);
-                    else load8(p.addend, m * p.ld_add + n, vec_add, ad);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += ad[j];
-                }
-                if (bn_mode) {
-                    // v = dA (gradient wrt the BN output after ReLU).  dz = dA * [a_out > 0]; partial sums of dz and dz*xhat.
-                    float yy[8], aa[8];
-                    if (PIPE && vec_c) {
-                        chunk_to_f<T>(qy[sl], yy);
-                        if (bn_mode == 1) chunk_to_f<T>(qa[sl], aa);
-                    } else {
-                        load8(p.bn_y, m * p.ldc + n, vec_c, yy);
-                        if (bn_mode == 1) load8(p.bn_a, m * p.ldc + n, vec_c, aa);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const bool on = bn_mode == 1 ? (aa[j] > 0.f) : (bn_mode == 2 ? (fmaf(yy[j], csc[j], csh[j]) > 0.f) : true);
-                        const float dz = on ? v[j] : 0.f;
-                        cs[j] += dz;
-                        cq[j] += dz * (yy[j] - cmean[j]) * cinv[j];
-                        v[j] = dz;
-                    }
-                }
-                if (p.relu) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-                }
-                T* cp = p.C + m * p.ldc + n;
-                if (vec_c) {
-                    if (CE == 8) { *(u32x4*)cp = f_to_chunk<T>(v); }
-                    else { *(u32x4*)cp = f_to_chunk<T>(v); *(u32x4*)(cp + 4) = f_to_chunk<T>(v + 4); }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) if (n + j < p.N) cp[j] = Elem<T>::from_f(v[j]);
-                }
-            }
-            if (PIPE && t + DEPTH < NSTEP) issue(t + DEPTH);   // recycle this step's operand registers
-        }
-    }
-    if (p.stats_part) {
-        // column partials: lanes with the same chunk differ in erow -> butterfly over the row bits, then pairs of 64-row
-        // waves via LDS: the partial-sum buffer is always indexed by 128-row tiles (rpe_conv_stats_tiles)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#pragma unroll
-            for (int o = CPW; o < 64; o <<= 1) { cs[j] += __shfl_xor(cs[j], o); cq[j] += __shfl_xor(cq[j], o); }
-        }
-        __syncthreads();  // every wave is done reading its staging rows
-        float* red = (float*)lds;  // [WAVES_M][BN][2]
-        if (erow == 0) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                red[(wave_m * BN + nl + j) * 2 + 0] = cs[j];
-                red[(wave_m * BN + nl + j) * 2 + 1] = cq[j];
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < (WAVES_M / 2) * BN; i += NTHR) {
-            const int h = i / BN, c = i - h * BN;
-            long t128 = (long)tile_m * (WAVES_M / 2) + h;
-            if (MODE == MODE_CONV && g.parity) t128 = (long)cls * ((g.rows_q + 127) / 128) + m0 / 128 + h;
-            if (n0 + c < p.N && m0 + h * 128 < row_lim) {
-                const float s_ = red[((2 * h) * BN + c) * 2] + red[((2 * h + 1) * BN + c) * 2];
-                const float q_ = red[((2 * h) * BN + c) * 2 + 1] + red[((2 * h + 1) * BN + c) * 2 + 1];
-                p.stats_part[(t128 * 2 + 0) * p.N + n0 + c] = s_;
-                p.stats_part[(t128 * 2 + 1) * p.N + n0 + c] = q_;
-            }
-        }
-    }
-}
-
-// -----------------------------------------------------------------------------------------------
-// TN kernel (weight gradients)
-// -----------------------------------------------------------------------------------------------
-// LDS tiles are [m][cols] row-major (cols contiguous, as in memory).  The bf16 operands are
-// fetched with ds_read_b64_tr_b16 (hardware 4x16 transpose), the f32 ones with ds_read_b32.
-// 16-byte chunk permutation inside a row so the 8 rows a 32-lane half touches cover all 64 banks.
-template <typename T, int CPR> __device__ __forceinline__ int tn_swz(int row) {
-    if (sizeof(T) == 4) return (row & 1) << 2;                                  // f32: +16 dwords for odd rows
-    if (CPR >= 16) return ((row & 3) | ((row >> 1) & 4)) << 1;                  // 256-B rows
-    return (((row >> 1) & 1) | ((row >> 2) & 2)) << 1;                          // 128-B rows (parity picks the half)
-}
-
-template <typename T, int BI, int BJ, int MODE, bool USE_DMA = true>
-__global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
-    constexpr int CE = Elem<T>::kChunk, BMK = 4 * CE;
-    constexpr int WI = BI / 2, WJ = BJ / 2, FI = WI / 16, FJ = WJ / 16;
-    constexpr int CPI = BI / CE, CPJ = BJ / CE;        // chunks per row
-    constexpr int RPI = 256 / CPI, RPJ = 256 / CPJ;    // rows per pass
-    constexpr int NPI = (BMK + RPI - 1) / RPI, NPJ = (BMK + RPJ - 1) / RPJ;
-    constexpr int PT = BMK * CPI, QT = BMK * CPJ;      // tile sizes in 16-byte units
-    constexpr int STAGE = PT + QT;
-    constexpr bool DMA = USE_DMA && MODE != MODE_STEM;  // LDS-DMA staging, 3-slot ring (see nt_kernel); stem: registers
-    constexpr int NSTAGE = DMA ? 3 : 2;
-    static_assert(BMK % RPI == 0 && BMK % RPJ == 0, "tile rows must split evenly over the passes");
-    __shared__ u32x4 lds[NSTAGE * STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wave_i = wave >> 1, wave_j = wave & 1;
-    const int nt = p.tiles_i * p.tiles_j;
-    const int lb = xcd_remap(blockIdx.x, nt * p.splits);
-    const int split = lb / nt, t2 = lb - split * nt;
-    const int tile_j = t2 % p.tiles_j, tile_i = t2 / p.tiles_j;
-    const int i0 = tile_i * BI, j0 = tile_j * BJ;
-    const int m_begin = split * p.rows_per_split;
-    const int m_end = min(p.M, m_begin + p.rows_per_split);
-    if (m_begin >= m_end) return;
-    const Gather& g = p.g;
-
-    // thread -> (row, LDS slot) of pass i: row = tid / CP + i * RP, slot = tid % CP (64 consecutive chunks per wave: the
-    // lane-linear image one DMA instruction writes).  The slot holds logical chunk slot ^ swz(row).
-    const int p_slot = tid % CPI, p_r = tid / CPI;
-    const int q_slot = tid % CPJ, q_r = tid / CPJ;
-    // conv: the BJ-wide column tile lies inside one tap (BJ divides C)
-    int tap_r = 0, tap_s = 0, tap_c = 0;
-    if (MODE == MODE_CONV) { const int rs = j0 / g.C; tap_c = j0 - rs * g.C; tap_r = rs / g.S; tap_s = rs - tap_r * g.S; }
-
-    auto p_src = [&](int mb, int i) -> const T* {
-        const int row = p_r + i * RPI;
-        const int cc = p_slot ^ tn_swz<T, CPI>(row);
-        const int m = mb + row;
-        return (m < m_end && (i0 + cc * CE) < p.I) ? p.P + (long)m * p.ldp + i0 + cc * CE : nullptr;
-    };
-    auto q_src = [&](int mb, int i) -> const T* {   // dense / conv only
-        const int row = q_r + i * RPJ;
-        const int cc = q_slot ^ tn_swz<T, CPJ>(row);
-        const int m = mb + row;
-        const bool ok = m < m_end && (j0 + cc * CE) < p.J;
-        if (MODE == MODE_DENSE) return ok ? p.Q + (long)m * p.ldq + j0 + cc * CE : nullptr;
-        const unsigned mm = ok ? (unsigned)m : 0u;
-        const unsigned b = fd_div(mm, g.div_hw);
-        const unsigned rem = mm - b * g.div_hw.d;
-        const unsigned oh = fd_div(rem, g.div_w);
-        const unsigned ow = rem - oh * g.div_w.d;
-        const int ih = (int)oh * g.sn + g.base_h + tap_r, iw = (int)ow * g.sn + g.base_w + tap_s;
-        return (ok && ih >= 0 && iw >= 0 && ih < g.H && iw < g.W)
-                   ? p.Q + (long)b * g.img_stride + ((long)ih * g.W + iw) * g.C + tap_c + cc * CE : nullptr;
-    };
-    typedef __attribute__((address_space(3))) char lds_char;
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    auto dma_tile = [&](int st, int mb) {
-        lds_char* base = (lds_char*)lds + st * (STAGE * 16);
-#pragma unroll
-        for (int i = 0; i < NPI; ++i) {
-            const T* src = p_src(mb, i);
-            const void* sp = src ? (const void*)src : (const void*)rpe_zero16;
-            __builtin_amdgcn_global_load_lds((gptr_t)sp, (__attribute__((address_space(3))) void*)(base + (i * 4 + wave) * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < NPJ; ++i) {
-            const T* src = q_src(mb, i);
-            const void* sp = src ? (const void*)src : (const void*)rpe_zero16;
-            __builtin_amdgcn_global_load_lds((gptr_t)sp, (__attribute__((address_space(3))) void*)(base + PT * 16 + (i * 4 + wave) * 1024), 16, 0, 0);
-        }
-    };
-    u32x4 rp[NPI], rq[NPJ];
-    auto load_tile = [&](int mb) {  // register staging (stem)
-#pragma unroll
-        for (int i = 0; i < NPI; ++i) { const T* src = p_src(mb, i); rp[i] = src ? ld16(src) : zero16(); }
-#pragma unroll
-        for (int i = 0; i < NPJ; ++i) {
-            const int row = q_r + i * RPJ;
-            const int cc = q_slot ^ tn_swz<T, CPJ>(row);
-            const int m = mb + row;
-            const bool ok = m < m_end && (j0 + cc * CE) < p.J;
-            const unsigned mm = ok ? (unsigned)m : 0u;
-            const unsigned b = fd_div(mm, g.div_hw);
-            const unsigned rem = mm - b * g.div_hw.d;
-            const unsigned oh = fd_div(rem, g.div_w);
-            const unsigned ow = rem - oh * g.div_w.d;
-            if (MODE == MODE_STEM) rq[i] = stem_chunk<T>(p.Q, (long)b * g.img_stride, (int)oh * g.sn + g.base_h, (int)ow * g.sn + g.base_w, g.H, g.W, j0 + cc * CE, ok);
-            else { const T* src = q_src(mb, i); rq[i] = src ? ld16(src) : zero16(); }
-        }
-    };
-    auto store_tile = [&](int st) {
-        u32x4* base = lds + st * STAGE;
-#pragma unroll
-        for (int i = 0; i < NPI; ++i) base[(p_r + i * RPI) * CPI + p_slot] = rp[i];
-#pragma unroll
-        for (int i = 0; i < NPJ; ++i) base[PT + (q_r + i * RPJ) * CPJ + q_slot] = rq[i];
-    };
-
-    f32x4 acc[FI][FJ];
-#pragma unroll
-    for (int a = 0; a < FI; ++a)
-#pragma unroll
-        for (int b = 0; b < FJ; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nsteps = (m_end - m_begin + BMK - 1) / BMK;
-    const int fg = lane >> 4, fl = lane & 15;
-    auto compute = [&](int cur) {
-        const char* pb = (const char*)(lds + cur * STAGE);
-        const char* qb = (const char*)(lds + cur * STAGE + PT);
-        if (sizeof(T) == 2) {
-            // lane (g = l>>4, q = (l&15)>>2, pp = l&3) addresses row m = 8g + 4h + q, columns base + 4pp..4pp+3;
-            // it receives column base + (l&15) for rows 8g + 4h + 0..3  -> MFMA k = 8g + (4h + e)
-            const int q = fl >> 2, pp = fl & 3;
-            u32x4 pf[FI], qf[FJ];
-#pragma unroll
-            for (int a = 0; a < FI; ++a) {
-                const int col = wave_i * WI + a * 16 + 4 * pp;  // element column inside the tile
-                unsigned w[4];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int row = 8 * fg + 4 * h + q;
-                    const int chunk = (col >> 3) ^ tn_swz<T, CPI>(row);
-                    const char* ad = pb + (row * CPI + chunk) * 16 + (col & 7) * 2;
-                    s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ad));
-                    u32x2 tt = __builtin_bit_cast(u32x2, t);
-                    w[2 * h] = tt.x; w[2 * h + 1] = tt.y;
-                }
-                pf[a] = u32x4{w[0], w[1], w[2], w[3]};
-            }
-#pragma unroll
-            for (int b = 0; b < FJ; ++b) {
-                const int col = wave_j * WJ + b * 16 + 4 * pp;
-                unsigned w[4];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int row = 8 * fg + 4 * h + q;
-                    const int chunk = (col >> 3) ^ tn_swz<T, CPJ>(row);
-                    const char* ad = qb + (row * CPJ + chunk) * 16 + (col & 7) * 2;
-                    s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ad));
-                    u32x2 tt = __builtin_bit_cast(u32x2, t);
-                    w[2 * h] = tt.x; w[2 * h + 1] = tt.y;
-                }
-                qf[b] = u32x4{w[0], w[1], w[2], w[3]};
-            }
-#pragma unroll
-            for (int a = 0; a < FI; ++a)
-#pragma unroll
-                for (int b = 0; b < FJ; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pf[a]), __builtin_bit_cast(bf16x8, qf[b]), acc[a][b], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int row = kk * 4 + fg;
-                float pf[FI], qf[FJ];
-#pragma unroll
-                for (int a = 0; a < FI; ++a) {
-                    const int col = wave_i * WI + a * 16 + fl;
-                    pf[a] = *(const float*)(pb + (row * CPI + ((col >> 2) ^ tn_swz<T, CPI>(row))) * 16 + (col & 3) * 4);
-                }
-#pragma unroll
-                for (int b = 0; b < FJ; ++b) {
-                    const int col = wave_j * WJ + b * 16 + fl;
-                    qf[b] = *(const float*)(qb + (row * CPJ + ((col >> 2) ^ tn_swz<T, CPJ>(row))) * 16 + (col & 3) * 4);
-                }
-#pragma unroll
-                for (int a = 0; a < FI; ++a)
-#pragma unroll
-                    for (int b = 0; b < FJ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[a], qf[b], acc[a][b], 0, 0, 0);
-            }
-        }
-    };
-    if (DMA) {
-        constexpr int NI = NPI + NPJ;
-        constexpr int PF = NSTAGE - 1;
-#pragma unroll
-        for (int t = 0; t < PF; ++t)
-            if (t < nsteps) dma_tile(t, m_begin + t * BMK);
-        {
-            const int newer = (nsteps < PF ? nsteps : PF) - 1;
-            if (newer >= 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
-        }
-        __builtin_amdgcn_s_barrier();
-        int slot = 0;
-        for (int st = 0; st < nsteps; ++st) {
-            if (st + PF < nsteps) { int s2 = slot + PF; if (s2 >= NSTAGE) s2 -= NSTAGE; dma_tile(s2, m_begin + (st + PF) * BMK); }
-            compute(slot);
-            int newer = nsteps - 2 - st;
-            if (newer > PF - 1) newer = PF - 1;
-            if (newer >= 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            if (++slot == NSTAGE) slot = 0;
-        }
-    } else {
-        load_tile(m_begin);
-        store_tile(0);
-        __syncthreads();
-        for (int st = 0; st < nsteps; ++st) {
-            const int cur = st & 1;
-            const bool more = st + 1 < nsteps;
-            if (more) load_tile(m_begin + (st + 1) * BMK);
-            compute(cur);
-            if (more) store_tile(cur ^ 1);
-            __syncthreads();
-        }
-    }
-    // D[i = ..+4*fg+reg][j = ..+fl]: for a fixed register 16 lanes add 64 contiguous bytes of one row
-#pragma unroll
-    for (int a = 0; a < FI; ++a)
-#pragma unroll
-        for (int b = 0; b < FJ; ++b) {
-            const int j = j0 + wave_j * WJ + b * 16 + fl;
-            if (j >= p.J) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = i0 + wave_i * WI + a * 16 + 4 * fg + r;
-                if (i < p.I) atomicAdd(p.D + (long)i * p.ldd + j, acc[a][b][r]);
-            }
-        }
-}
-
-// -----------------------------------------------------------------------------------------------
-// host launchers
-// -----------------------------------------------------------------------------------------------
-static thread_local char g_last_kernel[96] = "";
-extern "C" const char* rpe_last_kernel_name(void) { return g_last_kernel; }
-
-template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE> static int launch_nt_role(NTArgs<T>& a, hipStream_t s, long nwg) {
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "nt_kernel<%s,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", WAVES_M, BN, KCH, MODE, NST, ROLE);
-    // RPE_NO_EPI_PIPE=1: data-gradient epilogue without the operand prefetch (A/B experiments)
-    static const bool no_pipe = getenv("RPE_NO_EPI_PIPE") != nullptr;
-    if (ROLE == 1 && no_pipe) hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, false>), dim3((unsigned)nwg), dim3(128 * WAVES_M), 0, s, a);
-    else hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, true>), dim3((unsigned)nwg), dim3(128 * WAVES_M), 0, s, a);
-    RPE_CHECK_LAUNCH();
-    return 0;
-}
-
-template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST = 3> static int launch_nt_cfg(NTArgs<T>& a, hipStream_t s) {
-    constexpr int BM = 64 * WAVES_M;
-    a.tiles_m = (MODE == MODE_CONV && a.g.parity) ? 4 * ceil_div(a.g.rows_q, BM) : ceil_div(a.M, BM);
-    a.tiles_n = ceil_div(a.N, BN);
-    const long nwg = (long)a.tiles_m * a.tiles_n;
-    if (nwg <= 0 || nwg > 0x7fffffffL) return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: bad grid");
-    if (a.role == 1) return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 1>(a, s, nwg);
-    if (a.role == 2) return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 2>(a, s, nwg);
-    return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 0>(a, s, nwg);
-}
+template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s);
 
 template <typename T> int launch_nt(NTArgs<T>& a, int mode, hipStream_t s) {
     constexpr int CE = Elem<T>::kChunk;
@@ -750,95 +19,20 @@ template <typename T> int launch_nt(NTArgs<T>& a, int mode, hipStream_t s) {
         return rpe_set_error(RPE_ERR_ALIGN, "igemm_nt: operands must be 16-byte aligned with ld a multiple of the 16-byte chunk");
     if (mode == MODE_DENSE && ((a.lda % CE) || (a.K % CE))) return rpe_set_error(RPE_ERR_ALIGN, "igemm_nt: dense lda/K must be chunk multiples");
     if (mode == MODE_CONV && (a.g.C % (8 * CE))) return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: conv channels must be a multiple of 8 chunks");
-    const bool wide = a.N > 64;
-    // BN partial sums are always indexed by 128-row tiles (rpe_conv_stats_tiles), whatever the M tile
-    if (mode == MODE_STEM) return launch_nt_cfg<T, 2, 64, 4, MODE_STEM>(a, s);
-    // 256-row / 8-wave tiles (1 workgroup per CU): measured on the ResNet shapes at bs256 they gain 3..10 % in isolation
-    // for K >= 1024 and lose 10..25 % for short K, and LOSE overall inside the train step (fused epilogues, 2 waves/SIMD
-    // in lockstep): 34.4 vs 32.9 ms/step.  Kept selectable for experiments (RPE_NT_BIG=1), off by default.
-    static const bool big_enabled = getenv("RPE_NT_BIG") != nullptr;
-    const bool big = big_enabled && a.M >= 4096 && a.K >= 1024;
-    // Long reductions (K >= 1024: the 3x3 convs from layer2 on and the deep 1x1s): 128-B K rows (BK 64) with a 2-slot ring
-    // (64 KB LDS, 2 workgroups per CU) -- half the barriers per FLOP; measured +10..15 % there, -5..15 % on short K.
-    static const bool bk64_all = getenv("RPE_NT_BK64") != nullptr, bk64_off = getenv("RPE_NT_NOBK64") != nullptr;
-    if (!big && !bk64_off && a.M >= 1024 && (bk64_all ? a.K >= 16 * CE : a.K >= 1024)) {
-        if (mode == MODE_DENSE) return wide ? launch_nt_cfg<T, 2, 128, 8, MODE_DENSE, 2>(a, s) : launch_nt_cfg<T, 2, 64, 8, MODE_DENSE, 2>(a, s);
-        return wide ? launch_nt_cfg<T, 2, 128, 8, MODE_CONV, 2>(a, s) : launch_nt_cfg<T, 2, 64, 8, MODE_CONV, 2>(a, s);
+    if (mode != MODE_STEM) {
+        // buffer-descriptor extents of the two DMA operands; rows that must read as zero use offset 2^31, so both stay below it
+        const long ab = (mode == MODE_DENSE ? (long)a.M * a.lda : a.a_elems) * (long)sizeof(T), bb = (long)a.N * a.ldb * (long)sizeof(T);
+        if (ab <= 0 || bb <= 0 || ab >= (1L << 31) || bb >= (1L << 31))
+            return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: an operand of 2 GiB or more (split the batch)");
+        a.a_bytes = (unsigned)ab; a.b_bytes = (unsigned)bb;
     }
-    // experiment: 2-slot ring (32 KB LDS -> more resident workgroups) for the short-K, epilogue-dominated launches
-    static const bool nst2 = getenv("RPE_NT_NST2") != nullptr;
-    if (nst2 && !big && a.K <= 512) {
-        if (mode == MODE_DENSE) return wide ? launch_nt_cfg<T, 2, 128, 4, MODE_DENSE, 2>(a, s) : launch_nt_cfg<T, 2, 64, 4, MODE_DENSE, 2>(a, s);
-        return wide ? launch_nt_cfg<T, 2, 128, 4, MODE_CONV, 2>(a, s) : launch_nt_cfg<T, 2, 64, 4, MODE_CONV, 2>(a, s);
-    }
-    if (mode == MODE_DENSE) {
-        if (big) return wide ? launch_nt_cfg<T, 4, 128, 8, MODE_DENSE>(a, s) : launch_nt_cfg<T, 4, 64, 8, MODE_DENSE>(a, s);
-        // few-row Linear layers (the 256-row fusion MLP and ResNet fc: 4..16 tiles of 128x128 on 256 CUs, each walking K alone
-        // at the fp32 MFMA rate -- 277 us for 256x1024x3655): 64x64 tiles / 2 waves put 4..8x as many workgroups on the chip
-        if (!a.stats_part && (long)ceil_div(a.M, 128) * ceil_div(a.N, wide ? 128 : 64) < 96) return launch_nt_cfg<T, 1, 64, 4, MODE_DENSE>(a, s);
-        return wide ? launch_nt_cfg<T, 2, 128, 4, MODE_DENSE>(a, s) : launch_nt_cfg<T, 2, 64, 4, MODE_DENSE>(a, s);
-    }
-    if (big) return wide ? launch_nt_cfg<T, 4, 128, 8, MODE_CONV>(a, s) : launch_nt_cfg<T, 4, 64, 8, MODE_CONV>(a, s);
-    return wide ? launch_nt_cfg<T, 2, 128, 4, MODE_CONV>(a, s) : launch_nt_cfg<T, 2, 64, 4, MODE_CONV>(a, s);
+    if (mode == MODE_STEM) return launch_nt_mode<T, MODE_STEM>(a, s);
+    if (mode == MODE_DENSE) return launch_nt_mode<T, MODE_DENSE>(a, s);
+    return launch_nt_mode<T, MODE_CONV>(a, s);
 }
 template int launch_nt<float>(NTArgs<float>&, int, hipStream_t);
 template int launch_nt<bf16>(NTArgs<bf16>&, int, hipStream_t);
 
-template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<T>& a, hipStream_t s) {
-    constexpr int BMK = 4 * Elem<T>::kChunk;
-    a.tiles_i = ceil_div(a.I, BI);
-    a.tiles_j = ceil_div(a.J, BJ);
-    const long tiles = (long)a.tiles_i * a.tiles_j;
-    // Every workgroup adds its whole BIxBJ fp32 tile with atomics (64 KB at 128x128), and float atomics run at ~1.3 TB/s
-    // chip-wide: 1536 workgroups = 100 MB = 77 us per launch, more than the GEMM itself.  ~2 workgroups per CU keeps the
-    // chip busy with a third of that traffic.
-    static const long target_wgs = getenv("RPE_TN_WGS") ? atol(getenv("RPE_TN_WGS")) : 512;
-    // (scaled so the atomic bytes, not the workgroup count, stay constant across tile sizes)
-    const long wgs = target_wgs * (128 * 128) / (BI * BJ);
-    long want = (wgs + tiles - 1) / tiles;
-    long max_splits = a.M / (16 * BMK);
-    if (max_splits < 1) max_splits = 1;
-    if (want > max_splits) want = max_splits;
-    if (want < 1) want = 1;
-    long rps = (a.M + want - 1) / want;
-    rps = (rps + BMK - 1) / BMK * BMK;
-    a.rows_per_split = (int)rps;
-    a.splits = (int)((a.M + rps - 1) / rps);
-    const long nwg = tiles * a.splits;
-    // A/B on one MI355X (bs256 ResNet shapes): the LDS-DMA 3-slot ring is 8 % SLOWER here than 2-stage register staging
-    // (5.67 vs 5.22 ms per step; 48 KB LDS costs occupancy and the transposed reads, not the staging, bound this kernel).
-    // Register staging is the default; RPE_TN_DMA=1 selects the ring.
-    static const bool dma = getenv("RPE_TN_DMA") != nullptr;
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "tn_kernel<%s,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", BI, BJ, MODE, dma ? 1 : 0);
-    if (dma) hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, false>), dim3((unsigned)nwg), dim3(256), 0, s, a);
-    RPE_CHECK_LAUNCH();
-    return 0;
-}
-
-template <typename T> int launch_tn(TNArgs<T>& a, int mode, hipStream_t s) {
-    constexpr int CE = Elem<T>::kChunk;
-    if (a.M <= 0 || a.I <= 0 || a.J <= 0) return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: empty problem");
-    if ((a.ldp % CE) || (((uintptr_t)a.P) & 15) || (((uintptr_t)a.Q) & 15))
-        return rpe_set_error(RPE_ERR_ALIGN, "igemm_tn: operands must be 16-byte aligned with ld a multiple of the 16-byte chunk");
-    if (mode == MODE_DENSE && (a.ldq % CE)) return rpe_set_error(RPE_ERR_ALIGN, "igemm_tn: dense ldq must be a chunk multiple");
-    if (mode == MODE_STEM) return launch_tn_cfg<T, 64, 64, MODE_STEM>(a, s);
-    const bool wide_i = a.I > 64;
-    if (mode == MODE_DENSE) {
-        const bool wide_j = a.J > 64;
-        if (wide_i && wide_j) return launch_tn_cfg<T, 128, 128, MODE_DENSE>(a, s);
-        if (wide_j) return launch_tn_cfg<T, 64, 128, MODE_DENSE>(a, s);
-        if (wide_i) return launch_tn_cfg<T, 128, 64, MODE_DENSE>(a, s);
-        return launch_tn_cfg<T, 64, 64, MODE_DENSE>(a, s);
-    }
-    if (a.g.C % 64) return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: conv channels must be a multiple of 64");
-    const bool wide_j = (a.g.C % 128) == 0;
-    if (wide_i && wide_j) return launch_tn_cfg<T, 128, 128, MODE_CONV>(a, s);
-    if (wide_j) return launch_tn_cfg<T, 64, 128, MODE_CONV>(a, s);
-    if (wide_i) return launch_tn_cfg<T, 128, 64, MODE_CONV>(a, s);
-    return launch_tn_cfg<T, 64, 64, MODE_CONV>(a, s);
-}
-template int launch_tn<float>(TNArgs<float>&, int, hipStream_t);
-template int launch_tn<bf16>(TNArgs<bf16>&, int, hipStream_t);
-
 }  // namespace rpe
+
+extern "C" const char* rpe_last_kernel_name(void) { return rpe::g_last_kernel; }

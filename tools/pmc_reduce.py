@@ -17,7 +17,28 @@ from collections import defaultdict
 csv.field_size_limit(1 << 30)
 
 
+def demangle(name):
+    """rocprofv3 leaves names with bf16 template arguments (DF16b) mangled and binutils' c++filt cannot read them: parse the
+    `_ZN3rpe<len><name>I<args>E...` form of this library's kernels by hand."""
+    m = re.match(r"_ZN3rpe(\d+)", name)
+    if not m:
+        return name
+    n = int(m.group(1))
+    base = name[m.end():m.end() + n]
+    rest = name[m.end() + n:]
+    targs = ""
+    if rest.startswith("I"):
+        parts = re.findall(r"DF16b|Li(\d+)E|Lb([01])E|^f|(?<=I)f", rest.split("EEv")[0] + "E")
+        toks = []
+        for tok in re.finditer(r"DF16b|Li\d+E|Lb[01]E|f", rest[1:].split("EEv")[0] + "E"):
+            t = tok.group(0)
+            toks.append("bf16" if t == "DF16b" else "f32" if t == "f" else t[2:-1])
+        targs = "<" + ",".join(toks) + ">"
+    return "rpe::" + base + targs + "("
+
+
 def symbol(name):
+    name = demangle(name)
     name = name.replace("void ", "").replace("rpe::", "").replace("(anonymous namespace)::", "")
     m = re.match(r"([A-Za-z_0-9]+)(<.*?>)?\(", name)
     if not m:
@@ -25,9 +46,12 @@ def symbol(name):
         return m.group(1) if m else name[:60]
     base, targs = m.group(1), m.group(2) or ""
     if base in ("nt_kernel", "tn_kernel"):
-        targs = targs.replace("__hip_bfloat16", "bf16").replace("float", "f32").replace(" ", "").replace("true", "1").replace("false", "0")
+        targs = targs.replace("__hip_bfloat16", "bf16").replace("__bf16", "bf16").replace("float", "f32").replace(" ", "").replace("true", "1").replace("false", "0")
         targs = re.sub(r"\(rpe::[A-Za-z]+\)", "", targs)
-        return base + targs
+        parts = targs[1:-1].split(",")
+        if base == "nt_kernel" and len(parts) == 8:
+            parts = parts[:7]   # the epilogue-prefetch flag is not part of the name bench.py reports
+        return base + "<" + ",".join(parts) + ">"
     return base
 
 
