@@ -111,6 +111,7 @@ static int conv_wgrad_t(const rpe_conv_desc* d, const void* x, const void* dy, f
     g.sn = d->stride; g.sd_shift = 0; g.base_h = -d->pad; g.base_w = -d->pad; g.tap_sign = 1;
     g.div_hw = make_fastdiv(Ho * Wo); g.div_w = make_fastdiv(Wo);
     g.img_stride = (long)d->in_h * d->in_w * d->in_c;
+    a.q_elems = (long)d->batch * g.img_stride;
     return launch_tn<T>(a, MODE_CONV, s);
 }
 

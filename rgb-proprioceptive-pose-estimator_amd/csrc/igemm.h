@@ -62,6 +62,8 @@ template <typename T> struct TNArgs {
     Gather g;
     int tiles_i, tiles_j, splits;
     int rows_per_split;  // multiple of the m-step
+    long q_elems;        // elements of the tensor behind Q (conv modes; dense: derived from M and ldq)
+    unsigned p_bytes, q_bytes;   // buffer-descriptor extents (filled by the launcher, < 2 GiB each)
 };
 
 }  // namespace rpe

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
     constexpr bool DMA = MODE != MODE_STEM;
     constexpr int NSTAGE = DMA ? NST : 2;              // DMA path: ring of NST slots, NST-1 tiles in flight
     static_assert(DMA || (WAVES_M == 2 && KCH == 4), "register staging is only wired for the 128-row / 64-B-row config");
-    static_assert(NST >= 2 && NST <= 4, "ring depth 2..4");
+    static_assert(NST >= 2 && NST <= 5, "ring depth 2..5");
     __shared__ u32x4 lds[(NSTAGE * STAGE > EPI16) ? NSTAGE * STAGE : EPI16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
         // tile 0 must have landed: allow the (min(PF, nk) - 1) newer tiles to stay in flight
         {
             const int newer = (nk < PF ? nk : PF) - 1;
-            if (newer >= 3) wait_vmcnt<3 * NI>(); else if (newer == 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
+            if (newer >= 4) wait_vmcnt<4 * NI>(); else if (newer == 3) wait_vmcnt<3 * NI>(); else if (newer == 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
         int st = 0;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
             // tile kt+1 must be complete; tiles kt+2 .. may still be in flight
             int newer = nk - 2 - kt;               // tiles issued after kt+1
             if (newer > PF - 1) newer = PF - 1;
-            if (newer >= 3) wait_vmcnt<3 * NI>(); else if (newer == 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
+            if (newer >= 4) wait_vmcnt<4 * NI>(); else if (newer == 3) wait_vmcnt<3 * NI>(); else if (newer == 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             if (++st == NSTAGE) st = 0;
         }
@@ -529,15 +529,17 @@ template <typename T, int CPR> __device__ __forceinline__ int tn_swz(int row) {
 
 template <typename T, int BI, int BJ, int MODE, bool USE_DMA = true>
 __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
-    constexpr int CE = Elem<T>::kChunk, BMK = 4 * CE;
+    constexpr bool DMA = USE_DMA && MODE != MODE_STEM;  // LDS-DMA staging through buffer descriptors; stem: registers
+    constexpr int CE = Elem<T>::kChunk, ES = (int)sizeof(T);
+    constexpr int KSUB = DMA ? 2 : 1;                  // MFMA K sub-steps (4 chunks = 32 bf16 / 16 f32 rows each) per staged tile
+    constexpr int BMK = 4 * CE * KSUB;
     constexpr int WI = BI / 2, WJ = BJ / 2, FI = WI / 16, FJ = WJ / 16;
     constexpr int CPI = BI / CE, CPJ = BJ / CE;        // chunks per row
     constexpr int RPI = 256 / CPI, RPJ = 256 / CPJ;    // rows per pass
     constexpr int NPI = (BMK + RPI - 1) / RPI, NPJ = (BMK + RPJ - 1) / RPJ;
     constexpr int PT = BMK * CPI, QT = BMK * CPJ;      // tile sizes in 16-byte units
     constexpr int STAGE = PT + QT;
-    constexpr bool DMA = USE_DMA && MODE != MODE_STEM;  // LDS-DMA staging, 3-slot ring (see nt_kernel); stem: registers
-    constexpr int NSTAGE = DMA ? 3 : 2;
+    constexpr int NSTAGE = 2;                          // DMA: 2-slot ring, the next tile in flight while this one is multiplied
     static_assert(BMK % RPI == 0 && BMK % RPJ == 0, "tile rows must split evenly over the passes");
     __shared__ u32x4 lds[NSTAGE * STAGE];
 
@@ -582,21 +584,60 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
         return (ok && ih >= 0 && iw >= 0 && ih < g.H && iw < g.W)
                    ? p.Q + (long)b * g.img_stride + ((long)ih * g.W + iw) * g.C + tap_c + cc * CE : nullptr;
     };
+    // DMA path addressing (as in nt_kernel): raw buffer descriptors, a 32-bit byte offset per lane and chunk.  Rows advance
+    // by BMK per step: dense operands add a uniform byte stride to their offsets; the conv operand re-derives (image, oh, ow)
+    // of its rows with two multiply-shift divisions.  Rows past M fall outside num_records and read as zero (the hardware
+    // range check covers the voffset, which is why the row advance lives there and not in the SGPR offset); columns past I / J
+    // and padding taps are sent there explicitly (0x80000000; extents < 2 GiB are checked by the launcher).
     typedef __attribute__((address_space(3))) char lds_char;
-    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void lds_void;
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)p.P, 0, (int)p.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)p.Q, 0, (int)p.q_bytes, 0x00020000);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    unsigned p_voff[NPI], q_voff[NPJ];
+    int q_cc[NPJ];
+    bool q_okc[NPJ];
+    if (DMA) {
+#pragma unroll
+        for (int i = 0; i < NPI; ++i) {
+            const int row = p_r + i * RPI;
+            const int cc = p_slot ^ tn_swz<T, CPI>(row);
+            p_voff[i] = (i0 + cc * CE) < p.I ? (unsigned)(((long)(m_begin + row) * p.ldp + i0 + cc * CE) * ES) : OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < NPJ; ++i) {
+            const int row = q_r + i * RPJ;
+            q_cc[i] = q_slot ^ tn_swz<T, CPJ>(row);
+            q_okc[i] = (j0 + q_cc[i] * CE) < p.J;
+            q_voff[i] = OOB;
+            if (MODE == MODE_DENSE && q_okc[i]) q_voff[i] = (unsigned)(((long)(m_begin + row) * p.ldq + j0 + q_cc[i] * CE) * ES);
+        }
+    }
+    const unsigned p_step = (unsigned)(BMK * p.ldp * ES), q_step = (unsigned)(BMK * p.ldq * ES);
     auto dma_tile = [&](int st, int mb) {
         lds_char* base = (lds_char*)lds + st * (STAGE * 16);
 #pragma unroll
         for (int i = 0; i < NPI; ++i) {
-            const T* src = p_src(mb, i);
-            const void* sp = src ? (const void*)src : (const void*)rpe_zero16;
-            __builtin_amdgcn_global_load_lds((gptr_t)sp, (__attribute__((address_space(3))) void*)(base + (i * 4 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_p, (lds_void*)(base + (i * 4 + wave_u) * 1024), 16, (int)p_voff[i], 0, 0, 0);
+            if (p_voff[i] < OOB) p_voff[i] += p_step;   // (the compare keeps the out-of-range marker where it is)
         }
 #pragma unroll
         for (int i = 0; i < NPJ; ++i) {
-            const T* src = q_src(mb, i);
-            const void* sp = src ? (const void*)src : (const void*)rpe_zero16;
-            __builtin_amdgcn_global_load_lds((gptr_t)sp, (__attribute__((address_space(3))) void*)(base + PT * 16 + (i * 4 + wave) * 1024), 16, 0, 0);
+            unsigned vo = q_voff[i];
+            if (MODE == MODE_DENSE) {
+                if (q_voff[i] < OOB) q_voff[i] += q_step;
+            } else {
+                const unsigned m = (unsigned)(mb + q_r + i * RPJ);
+                const unsigned b = fd_div(m, g.div_hw);
+                const unsigned rem = m - b * g.div_hw.d;
+                const unsigned oh = fd_div(rem, g.div_w);
+                const unsigned ow = rem - oh * g.div_w.d;
+                const int ih = (int)oh * g.sn + g.base_h + tap_r, iw = (int)ow * g.sn + g.base_w + tap_s;
+                const bool ok = q_okc[i] && m < (unsigned)p.M && ih >= 0 && iw >= 0 && ih < g.H && iw < g.W;
+                vo = ok ? (b * (unsigned)g.img_stride + (unsigned)((ih * g.W + iw) * g.C + tap_c + q_cc[i] * CE)) * ES : OOB;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_void*)(base + PT * 16 + (i * 4 + wave_u) * 1024), 16, (int)vo, 0, 0, 0);
         }
     };
     u32x4 rp[NPI], rq[NPJ];
@@ -637,6 +678,9 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
     auto compute = [&](int cur) {
         const char* pb = (const char*)(lds + cur * STAGE);
         const char* qb = (const char*)(lds + cur * STAGE + PT);
+#pragma unroll
+        for (int ks = 0; ks < KSUB; ++ks) {
+        const int rb = ks * 4 * CE;   // first row of this K sub-step inside the staged tile
         if (sizeof(T) == 2) {
             // lane (g = l>>4, q = (l&15)>>2, pp = l&3) addresses row m = 8g + 4h + q, columns base + 4pp..4pp+3;
             // it receives column base + (l&15) for rows 8g + 4h + 0..3  -> MFMA k = 8g + (4h + e)
@@ -648,7 +692,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
                 unsigned w[4];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int row = 8 * fg + 4 * h + q;
+                    const int row = rb + 8 * fg + 4 * h + q;
                     const int chunk = (col >> 3) ^ tn_swz<T, CPI>(row);
                     const char* ad = pb + (row * CPI + chunk) * 16 + (col & 7) * 2;
                     s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ad));
@@ -663,7 +707,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
                 unsigned w[4];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int row = 8 * fg + 4 * h + q;
+                    const int row = rb + 8 * fg + 4 * h + q;
                     const int chunk = (col >> 3) ^ tn_swz<T, CPJ>(row);
                     const char* ad = qb + (row * CPJ + chunk) * 16 + (col & 7) * 2;
                     s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ad));
@@ -680,7 +724,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
         } else {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const int row = kk * 4 + fg;
+                const int row = rb + kk * 4 + fg;
                 float pf[FI], qf[FJ];
 #pragma unroll
                 for (int a = 0; a < FI; ++a) {
@@ -698,27 +742,19 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
                     for (int b = 0; b < FJ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[a], qf[b], acc[a][b], 0, 0, 0);
             }
         }
+        }
     };
     if (DMA) {
-        constexpr int NI = NPI + NPJ;
-        constexpr int PF = NSTAGE - 1;
-#pragma unroll
-        for (int t = 0; t < PF; ++t)
-            if (t < nsteps) dma_tile(t, m_begin + t * BMK);
-        {
-            const int newer = (nsteps < PF ? nsteps : PF) - 1;
-            if (newer >= 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
-        }
+        dma_tile(0, m_begin);
+        wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         int slot = 0;
         for (int st = 0; st < nsteps; ++st) {
-            if (st + PF < nsteps) { int s2 = slot + PF; if (s2 >= NSTAGE) s2 -= NSTAGE; dma_tile(s2, m_begin + (st + PF) * BMK); }
+            if (st + 1 < nsteps) dma_tile(slot ^ 1, m_begin + (st + 1) * BMK);   // its previous readers all passed the last barrier
             compute(slot);
-            int newer = nsteps - 2 - st;
-            if (newer > PF - 1) newer = PF - 1;
-            if (newer >= 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
+            wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
-            if (++slot == NSTAGE) slot = 0;
+            slot ^= 1;
         }
     } else {
         load_tile(m_begin);
@@ -793,6 +829,9 @@ template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s) 
         // (A 4-slot ring of 64-B rows, same LDS and 96 instead of 64 K elements in flight, measured 10 % slower: the
         // per-step cost, not the prefetch depth, is what the longer rows buy back.)
         static const bool bk64_all = getenv("RPE_NT_BK64") != nullptr, bk64_off = getenv("RPE_NT_NOBK64") != nullptr;
+        static const int ring = getenv("RPE_NT_RING") ? atoi(getenv("RPE_NT_RING")) : 0;   // experiment: 4/5-slot rings of 64-B rows
+        if (ring == 4 && !big && a.M >= 1024 && a.K >= 1024) return wide ? launch_nt_cfg<T, 2, 128, 4, MODE, 4>(a, s) : launch_nt_cfg<T, 2, 64, 4, MODE, 4>(a, s);
+        if (ring == 5 && !big && a.M >= 1024 && a.K >= 1024) return wide ? launch_nt_cfg<T, 2, 128, 4, MODE, 5>(a, s) : launch_nt_cfg<T, 2, 64, 4, MODE, 5>(a, s);
         if (!big && !bk64_off && a.M >= 1024 && (bk64_all ? a.K >= 16 * CE : a.K >= 1024))
             return wide ? launch_nt_cfg<T, 2, 128, 8, MODE, 2>(a, s) : launch_nt_cfg<T, 2, 64, 8, MODE, 2>(a, s);
         if (big) return wide ? launch_nt_cfg<T, 4, 128, 8, MODE>(a, s) : launch_nt_cfg<T, 4, 64, 8, MODE>(a, s);
@@ -807,7 +846,10 @@ template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s) 
 }
 
 template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<T>& a, hipStream_t s) {
-    constexpr int BMK = 4 * Elem<T>::kChunk;
+    // register staging (the stem, or RPE_TN_REG=1 for experiments) walks 4 chunks of rows per step, the LDS-DMA ring 8
+    static const bool reg = getenv("RPE_TN_REG") != nullptr;
+    const bool dma = MODE != MODE_STEM && !reg;
+    const int BMK = (dma ? 8 : 4) * Elem<T>::kChunk;
     a.tiles_i = ceil_div(a.I, BI);
     a.tiles_j = ceil_div(a.J, BJ);
     const long tiles = (long)a.tiles_i * a.tiles_j;
@@ -817,7 +859,10 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
     static const long target_wgs = getenv("RPE_TN_WGS") ? atol(getenv("RPE_TN_WGS")) : 512;
     // (scaled so the atomic bytes, not the workgroup count, stay constant across tile sizes)
     const long wgs = target_wgs * (128 * 128) / (BI * BJ);
-    long want = (wgs + tiles - 1) / tiles;
+    // round DOWN when that still fills >= 70 % of the target: the target is what is resident at once (64 KB of LDS per
+    // 128x128 workgroup = 2 per CU), and e.g. 144 tiles x 4 splits = 576 workgroups ran as a full round plus a 12 % round
+    long want = wgs / tiles;
+    if (want < 1 || tiles * want * 10 < wgs * 7) want = (wgs + tiles - 1) / tiles;
     long max_splits = a.M / (16 * BMK);
     if (max_splits < 1) max_splits = 1;
     if (want > max_splits) want = max_splits;
@@ -827,10 +872,11 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
     a.rows_per_split = (int)rps;
     a.splits = (int)((a.M + rps - 1) / rps);
     const long nwg = tiles * a.splits;
-    // A/B on one MI355X (bs256 ResNet shapes): the LDS-DMA 3-slot ring is 8 % SLOWER here than 2-stage register staging
-    // (5.67 vs 5.22 ms per step; 48 KB LDS costs occupancy and the transposed reads, not the staging, bound this kernel).
-    // Register staging is the default; RPE_TN_DMA=1 selects the ring.
-    static const bool dma = getenv("RPE_TN_DMA") != nullptr;
+    // buffer-descriptor extents (DMA path): rows past M must fall outside them, padding uses offset 2^31
+    const long pb = (long)a.M * a.ldp * (long)sizeof(T), qb = (MODE == MODE_DENSE ? (long)a.M * a.ldq : a.q_elems) * (long)sizeof(T);
+    if (dma && (pb <= 0 || qb <= 0 || pb >= (1L << 31) || qb >= (1L << 31)))
+        return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: an operand of 2 GiB or more (split the batch)");
+    a.p_bytes = (unsigned)pb; a.q_bytes = (unsigned)qb;
     snprintf(g_last_kernel, sizeof(g_last_kernel), "tn_kernel<%s,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", BI, BJ, MODE, dma ? 1 : 0);
     if (dma) hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, false>), dim3((unsigned)nwg), dim3(256), 0, s, a);
