@@ -598,6 +598,18 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
     unsigned p_voff[NPI], q_voff[NPJ];
     int q_cc[NPJ];
     bool q_okc[NPJ];
+    // conv operand: (image, oh, ow) of each of the thread's rows, advanced by BMK rows per step with adds and carries only
+    // (BMK = nb images + qh output rows + rw pixels); offsets are built with 24-bit multiplies (full rate; the launcher
+    // checks that the image stride and pixel counts fit)
+    unsigned q_b[NPJ], q_oh[NPJ], q_ow[NPJ];
+    unsigned adv_b = 0, adv_h = 0, adv_w = 0;
+    if (DMA && MODE == MODE_CONV) {
+        const unsigned hw = g.div_hw.d, wo = g.div_w.d;
+        adv_b = BMK / hw;
+        const unsigned rem = BMK - adv_b * hw;
+        adv_h = rem / wo;
+        adv_w = rem - adv_h * wo;
+    }
     if (DMA) {
 #pragma unroll
         for (int i = 0; i < NPI; ++i) {
@@ -611,11 +623,19 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
             q_cc[i] = q_slot ^ tn_swz<T, CPJ>(row);
             q_okc[i] = (j0 + q_cc[i] * CE) < p.J;
             q_voff[i] = OOB;
+            q_b[i] = q_oh[i] = q_ow[i] = 0;
             if (MODE == MODE_DENSE && q_okc[i]) q_voff[i] = (unsigned)(((long)(m_begin + row) * p.ldq + j0 + q_cc[i] * CE) * ES);
+            if (MODE == MODE_CONV) {
+                const unsigned m = (unsigned)(m_begin + row);
+                q_b[i] = fd_div(m, g.div_hw);
+                const unsigned rem = m - q_b[i] * g.div_hw.d;
+                q_oh[i] = fd_div(rem, g.div_w);
+                q_ow[i] = rem - q_oh[i] * g.div_w.d;
+            }
         }
     }
     const unsigned p_step = (unsigned)(BMK * p.ldp * ES), q_step = (unsigned)(BMK * p.ldq * ES);
-    auto dma_tile = [&](int st, int mb) {
+    auto dma_tile = [&](int st) {
         lds_char* base = (lds_char*)lds + st * (STAGE * 16);
 #pragma unroll
         for (int i = 0; i < NPI; ++i) {
@@ -628,14 +648,18 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
             if (MODE == MODE_DENSE) {
                 if (q_voff[i] < OOB) q_voff[i] += q_step;
             } else {
-                const unsigned m = (unsigned)(mb + q_r + i * RPJ);
-                const unsigned b = fd_div(m, g.div_hw);
-                const unsigned rem = m - b * g.div_hw.d;
-                const unsigned oh = fd_div(rem, g.div_w);
-                const unsigned ow = rem - oh * g.div_w.d;
-                const int ih = (int)oh * g.sn + g.base_h + tap_r, iw = (int)ow * g.sn + g.base_w + tap_s;
-                const bool ok = q_okc[i] && m < (unsigned)p.M && ih >= 0 && iw >= 0 && ih < g.H && iw < g.W;
-                vo = ok ? (b * (unsigned)g.img_stride + (unsigned)((ih * g.W + iw) * g.C + tap_c + q_cc[i] * CE)) * ES : OOB;
+                // rows past M have q_b >= batch: their offset lies beyond num_records, no separate test
+                const int ih = (int)__umul24(q_oh[i], (unsigned)g.sn) + g.base_h + tap_r, iw = (int)__umul24(q_ow[i], (unsigned)g.sn) + g.base_w + tap_s;
+                const bool ok = q_okc[i] && ih >= 0 && iw >= 0 && ih < g.H && iw < g.W;
+                const unsigned pix = __umul24((unsigned)ih, (unsigned)g.W) + (unsigned)iw;
+                vo = ok ? (__umul24(q_b[i], (unsigned)g.img_stride) + __umul24(pix, (unsigned)g.C) + (unsigned)(tap_c + q_cc[i] * CE)) * ES : OOB;
+                q_ow[i] += adv_w;
+                const bool cw = q_ow[i] >= g.div_w.d;
+                q_ow[i] -= cw ? g.div_w.d : 0u;
+                q_oh[i] += adv_h + (cw ? 1u : 0u);
+                const bool ch = q_oh[i] >= (unsigned)g.Ho;
+                q_oh[i] -= ch ? (unsigned)g.Ho : 0u;
+                q_b[i] += adv_b + (ch ? 1u : 0u);
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_void*)(base + PT * 16 + (i * 4 + wave_u) * 1024), 16, (int)vo, 0, 0, 0);
         }
@@ -745,12 +769,12 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
         }
     };
     if (DMA) {
-        dma_tile(0, m_begin);
+        dma_tile(0);
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         int slot = 0;
         for (int st = 0; st < nsteps; ++st) {
-            if (st + 1 < nsteps) dma_tile(slot ^ 1, m_begin + (st + 1) * BMK);   // its previous readers all passed the last barrier
+            if (st + 1 < nsteps) dma_tile(slot ^ 1);   // (tiles are requested in row order; the slot's previous readers all passed the last barrier)
             compute(slot);
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
@@ -826,12 +850,10 @@ template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s) 
         const bool big = big_enabled && a.M >= 4096 && a.K >= 1024;
         // Long reductions (K >= 1024: the 3x3 convs from layer2 on and the deep 1x1s): 128-B K rows (BK 64) with a 2-slot
         // ring (64 KB LDS, 2 workgroups per CU) -- half the barriers per FLOP; measured +10..15 % there, -5..15 % on short K.
-        // (A 4-slot ring of 64-B rows, same LDS and 96 instead of 64 K elements in flight, measured 10 % slower: the
-        // per-step cost, not the prefetch depth, is what the longer rows buy back.)
+        // (4- and 5-slot rings of 64-B rows, same or 1.25x the LDS and 96 / 128 instead of 64 K elements in flight, measured
+        // 8 % slower on the forward shapes and level on the data gradients: the per-step cost, not the prefetch depth, is
+        // what the longer rows buy back.  Only the stride-2 parity-class data gradients, 1-4 taps deep, gained 15 %.)
         static const bool bk64_all = getenv("RPE_NT_BK64") != nullptr, bk64_off = getenv("RPE_NT_NOBK64") != nullptr;
-        static const int ring = getenv("RPE_NT_RING") ? atoi(getenv("RPE_NT_RING")) : 0;   // experiment: 4/5-slot rings of 64-B rows
-        if (ring == 4 && !big && a.M >= 1024 && a.K >= 1024) return wide ? launch_nt_cfg<T, 2, 128, 4, MODE, 4>(a, s) : launch_nt_cfg<T, 2, 64, 4, MODE, 4>(a, s);
-        if (ring == 5 && !big && a.M >= 1024 && a.K >= 1024) return wide ? launch_nt_cfg<T, 2, 128, 4, MODE, 5>(a, s) : launch_nt_cfg<T, 2, 64, 4, MODE, 5>(a, s);
         if (!big && !bk64_off && a.M >= 1024 && (bk64_all ? a.K >= 16 * CE : a.K >= 1024))
             return wide ? launch_nt_cfg<T, 2, 128, 8, MODE, 2>(a, s) : launch_nt_cfg<T, 2, 64, 8, MODE, 2>(a, s);
         if (big) return wide ? launch_nt_cfg<T, 4, 128, 8, MODE>(a, s) : launch_nt_cfg<T, 4, 64, 8, MODE>(a, s);
@@ -900,6 +922,8 @@ template <typename T> int launch_tn(TNArgs<T>& a, int mode, hipStream_t s) {
         return launch_tn_cfg<T, 64, 64, MODE_DENSE>(a, s);
     }
     if (a.g.C % 64) return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: conv channels must be a multiple of 64");
+    if (a.g.img_stride >= (1L << 24) || (long)a.g.H * a.g.W >= (1L << 24))
+        return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: an image of 2^24 elements or more (offsets are built with 24-bit multiplies)");
     const bool wide_j = (a.g.C % 128) == 0;
     if (wide_i && wide_j) return launch_tn_cfg<T, 128, 128, MODE_CONV>(a, s);
     if (wide_j) return launch_tn_cfg<T, 64, 128, MODE_CONV>(a, s);
