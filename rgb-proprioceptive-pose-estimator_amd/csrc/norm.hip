@@ -59,7 +59,18 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
     const int c = blockIdx.x * 32 + cl;
     double s = 0.0, q = 0.0;
     if (c < C) {
-        for (int t = blockIdx.y + rl * NS; t < tiles; t += 8 * NS) {
+        // 4 independent row loads in flight per thread (the loop is latency-, not bandwidth-bound)
+        const int st = 8 * NS;
+        int t = blockIdx.y + rl * NS;
+        for (; t + 3 * st < tiles; t += 4 * st) {
+            const float a0 = part[((long)t * 2 + 0) * C + c], b0 = part[((long)t * 2 + 1) * C + c];
+            const float a1 = part[((long)(t + st) * 2 + 0) * C + c], b1 = part[((long)(t + st) * 2 + 1) * C + c];
+            const float a2 = part[((long)(t + 2 * st) * 2 + 0) * C + c], b2 = part[((long)(t + 2 * st) * 2 + 1) * C + c];
+            const float a3 = part[((long)(t + 3 * st) * 2 + 0) * C + c], b3 = part[((long)(t + 3 * st) * 2 + 1) * C + c];
+            s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+            q += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+        }
+        for (; t < tiles; t += st) {
             s += (double)part[((long)t * 2 + 0) * C + c];
             q += (double)part[((long)t * 2 + 1) * C + c];
         }
@@ -89,11 +100,21 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
         __syncthreads();
         if (!last) return;
         s = 0.0; q = 0.0;
-        if (c < C)
-            for (int i = rl; i < NS; i += 8) {
-                s += __hip_atomic_load(&dpart[((long)i * 2 + 0) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                q += __hip_atomic_load(&dpart[((long)i * 2 + 1) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c < C) {
+            // NS <= 64 (reduce_slices): at most 8 slices per thread, all requested before the first is added
+            double vs[8], vq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = rl + 8 * u;
+                vs[u] = 0.0; vq[u] = 0.0;
+                if (i < NS) {
+                    vs[u] = __hip_atomic_load(&dpart[((long)i * 2 + 0) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    vq[u] = __hip_atomic_load(&dpart[((long)i * 2 + 1) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s += vs[u]; q += vq[u]; }
+        }
         sh[0][rl][cl] = s;
         sh[1][rl][cl] = q;
         __syncthreads();
