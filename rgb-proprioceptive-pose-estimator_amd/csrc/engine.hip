@@ -70,7 +70,7 @@ struct rpe_resnet50 {
     float* fc_wt = nullptr;      // fc weight transposed [2048][latent_pad]
     int latent_pad = 0;
     void* early_grad = nullptr;
-    void* G[4] = {nullptr, nullptr, nullptr, nullptr};  // gradient scratch, each max activation size
+    void* G[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // gradient scratch, each max activation size
     float* stats_part = nullptr;
     long stats_floats = 0;
     float* bwd_part = nullptr;
@@ -81,7 +81,8 @@ struct rpe_resnet50 {
     std::vector<Named> named;
     int train_mode = 0;
     int fused_tiles = 0;
-    void* cur[4] = {nullptr, nullptr, nullptr, nullptr};  // rotating gradient buffers of a backward in progress
+    void* cur[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // rotating gradient buffers of a backward in progress
+    bool wgrad_lag = false;                 // experiment (RPE_WGRAD_LAG=1): issue a layer's weight gradient AFTER the data gradient that follows it
     int bwd_next = -2;                                     // next block of a staged backward (-1: blocks done, -2: idle)
     // conv/fc weight gradients are accumulated with atomics: when the bound gradient tensors form one contiguous block
     // (they do in the flat arena) it is zeroed by ONE memset per backward instead of 54 (15 us each)
@@ -102,8 +103,8 @@ struct rpe_resnet50 {
     bool overlap = true;
     std::vector<hipEvent_t> sync_pool;
     size_t sync_next = 0;
-    const void* pend_buf[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t pend_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    const void* pend_buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t pend_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double flops[RPE_PROF_NUM] = {0};   // algorithmic FLOPs per pass, per category
     double bytes[RPE_PROF_NUM] = {0};   // algorithmic bytes per pass, per category
 };
@@ -227,7 +228,7 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
     want(e, (void**)&e->d_pooled, (long)batch * 2048 * 4);
     want(e, (void**)&e->fc_wt, 2048L * e->latent_pad * 4);
     want(e, &e->early_grad, st.rows * 64 * es);
-    for (int i = 0; i < 4; ++i) want(e, &e->G[i], max_act * es);
+    for (int i = 0; i < 5; ++i) want(e, &e->G[i], max_act * es);
     want(e, (void**)&e->stats_part, e->stats_floats * 4);
     e->bwd_part_floats = 1024L * 2 * 2048;
     want(e, (void**)&e->bwd_part, e->bwd_part_floats * 4);
@@ -333,7 +334,7 @@ extern "C" int rpe_resnet50_bind(rpe_resnet50_t* e, void* workspace, long worksp
     }
     e->named.push_back({"pool", e->pool, (long)e->B * (e->convs[0].Ho / 2) * (e->convs[0].Wo / 2), 64});
     e->named.push_back({"x4", e->x4, (long)e->B * e->H * e->W, 4});
-    for (int i = 0; i < 4; ++i) e->named.push_back({"G" + std::to_string(i), e->G[i], 0, 0});
+    for (int i = 0; i < 5; ++i) e->named.push_back({"G" + std::to_string(i), e->G[i], 0, 0});
     {   // descriptor table of the per-step weight packing (bind is a setup call: one small synchronous upload)
         std::vector<rpe_pack_desc> tab;
         long start = 0;
@@ -501,7 +502,7 @@ static hipEvent_t sync_event(rpe_resnet50* e) {
 
 // the main stream is about to WRITE gradient buffer `buf`: wait for a side-stream weight-gradient still reading it
 static int writable(rpe_resnet50* e, const void* buf, void* stream) {
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 6; ++i)
         if (e->pend_buf[i] == buf && e->pend_ev[i]) {
             HIPTRY(hipStreamWaitEvent((hipStream_t)stream, e->pend_ev[i], 0));
             e->pend_ev[i] = nullptr;
@@ -530,7 +531,7 @@ static int wgrad(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, void*
         if (!done) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
         HIPTRY(hipEventRecord(done, run));
         int slot = -1;
-        for (int i = 0; i < 4; ++i) if (e->pend_buf[i] == dy || (slot < 0 && !e->pend_ev[i])) { slot = i; if (e->pend_buf[i] == dy) break; }
+        for (int i = 0; i < 6; ++i) if (e->pend_buf[i] == dy || (slot < 0 && !e->pend_ev[i])) { slot = i; if (e->pend_buf[i] == dy) break; }
         if (slot < 0) slot = 0;
         e->pend_buf[slot] = dy;
         e->pend_ev[slot] = done;
@@ -557,6 +558,7 @@ extern "C" int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_fea
         if (!e->grads[i]) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward: gradient tensors were not bound");
     hipStream_t s = (hipStream_t)stream;
     if (e->overlap && !e->side) {
+        if (const char* lg = getenv("RPE_WGRAD_LAG")) e->wgrad_lag = atoi(lg) != 0;
         if (getenv("RPE_NO_OVERLAP")) e->overlap = false;
         else {
             // weight gradients are off the critical path (the data-gradient chain is): RPE_SIDE_PRIO=low|high asks for a
@@ -570,7 +572,7 @@ extern "C" int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_fea
         }
     }
     e->sync_next = 0;
-    for (int i = 0; i < 4; ++i) { e->pend_buf[i] = nullptr; e->pend_ev[i] = nullptr; }
+    for (int i = 0; i < 6; ++i) { e->pend_buf[i] = nullptr; e->pend_ev[i] = nullptr; }
     if (e->gspan_lo) HIPTRY(hipMemsetAsync(e->gspan_lo, 0, e->gspan_bytes, s));
     // fc
     float* dWfc = e->grads[np - 2];
@@ -584,7 +586,7 @@ extern "C" int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_fea
     TRY(rpe_linear_fwd(RPE_F32, d_features, (int)ld_d_features, e->fc_wt, e->latent_pad, nullptr, e->d_pooled, 2048, e->B, 2048, e->latent_pad, 0,
                        nullptr, 0, stream));
     ConvL& last = e->convs[e->blocks.back().c3];
-    for (int i = 0; i < 4; ++i) e->cur[i] = e->G[i];
+    for (int i = 0; i < 5; ++i) e->cur[i] = e->G[i];
     TRY(rpe_avgpool_bwd(e->dtype, e->d_pooled, e->cur[0], e->B, last.Ho * last.Wo, 2048, stream));
     e->bwd_next = (int)e->blocks.size() - 1;
     return 0;
@@ -597,8 +599,14 @@ extern "C" int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_fea
 // partial sums (rpe_conv2d_dgrad_bn), so each BN costs one more pass (dz, y -> dy) instead of two full passes.
 extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int join, void* stream) {
     if (!e || !e->bound || e->bwd_next < -1) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward_blocks: call rpe_resnet50_backward_begin first");
-    void *gA = e->cur[0], *gB = e->cur[1], *gC = e->cur[2], *gD = e->cur[3];
+    void *gA = e->cur[0], *gB = e->cur[1], *gC = e->cur[2], *gD = e->cur[3], *gE = e->cur[4];
     int bi = e->bwd_next;
+    // Side-stream pairing.  A weight gradient issued right when its dy is ready runs beside the data gradient of the SAME
+    // layer (same shape class: two MFMA-bound 3x3s, or two HBM-bound 1x1s).  Issuing it one launch later, beside the next
+    // BN pass and the NEXT layer's data gradient (1x1 beside 3x3), measured SLOWER (26.2 vs 25.9 ms/step, A/B on one
+    // device; RPE_WGRAD_LAG=1 selects it).  What did pay is the fifth scratch buffer both orders use: dz1 no longer
+    // overwrites dy3, so the main stream does not wait for conv3's weight gradient before conv2's data gradient.
+    const bool lag = e->wgrad_lag;
     for (; bi >= 0 && count > 0; --bi, --count) {
         Block& b = e->blocks[bi];
         ConvL &c1 = e->convs[b.c1], &c2 = e->convs[b.c2], &c3 = e->convs[b.c3];
@@ -610,33 +618,37 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
             TRY(writable(e, gB, stream));
             TRY(bn_from_dz(e, c3, gA, gB, stream));       // dy3 -> gB (gA keeps dz3 = shortcut gradient)
         }
-        TRY(wgrad(e, c3, c2.a, gB, stream));
+        if (!lag) TRY(wgrad(e, c3, c2.a, gB, stream));
         TRY(writable(e, gC, stream));
         TRY(dgrad_fused(e, c3, gB, gC, nullptr, &c2, 2, stream));   // dz2 -> gC
+        if (lag) TRY(wgrad(e, c3, c2.a, gB, stream));
         TRY(bn_from_dz(e, c2, gC, gC, stream));
-        TRY(wgrad(e, c2, c1.a, gC, stream));
-        TRY(writable(e, gB, stream));
-        TRY(dgrad_fused(e, c2, gC, gB, nullptr, &c1, 2, stream));   // dz1 -> gB
-        TRY(bn_from_dz(e, c1, gB, gB, stream));
-        TRY(wgrad(e, c1, x_in, gB, stream));
+        if (!lag) TRY(wgrad(e, c2, c1.a, gC, stream));
+        TRY(writable(e, gE, stream));
+        TRY(dgrad_fused(e, c2, gC, gE, nullptr, &c1, 2, stream));   // dz1 -> gE
+        if (lag) TRY(wgrad(e, c2, c1.a, gC, stream));
+        TRY(bn_from_dz(e, c1, gE, gE, stream));
+        if (!lag) TRY(wgrad(e, c1, x_in, gE, stream));
         const void* shortcut = gA;
         if (b.cd >= 0) {
             ConvL& cd = e->convs[b.cd];
             TRY(bn_back(e, cd, gA, 0, gA, nullptr, stream));          // no ReLU on the projection shortcut
-            TRY(wgrad(e, cd, x_in, gA, stream));
-            TRY(writable(e, gC, stream));
-            PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&cd.d, e->dtype, gA, cd.wd, gC, nullptr, stream));
-            shortcut = gC;
+            if (!lag) TRY(wgrad(e, cd, x_in, gA, stream));
+            TRY(writable(e, gB, stream));
+            PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&cd.d, e->dtype, gA, cd.wd, gB, nullptr, stream));
+            if (lag) TRY(wgrad(e, cd, x_in, gA, stream));
+            shortcut = gB;
         }
         TRY(writable(e, gD, stream));
         if (bi > 0) {
-            TRY(dgrad_fused(e, c1, gB, gD, shortcut, &e->convs[e->blocks[bi - 1].c3], 1, stream));  // dz3 of the previous block
+            TRY(dgrad_fused(e, c1, gE, gD, shortcut, &e->convs[e->blocks[bi - 1].c3], 1, stream));  // dz3 of the previous block
         } else {
-            PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&c1.d, e->dtype, gB, c1.wd, gD, shortcut, stream));
+            PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&c1.d, e->dtype, gE, c1.wd, gD, shortcut, stream));
         }
+        if (lag) TRY(wgrad(e, c1, x_in, gE, stream));
         void* t = gA; gA = gD; gD = t;
     }
-    e->cur[0] = gA; e->cur[1] = gB; e->cur[2] = gC; e->cur[3] = gD;
+    e->cur[0] = gA; e->cur[1] = gB; e->cur[2] = gC; e->cur[3] = gD; e->cur[4] = gE;
     e->bwd_next = bi;
     if (join) TRY(join_side(e, (hipStream_t)stream));
     return 0;
