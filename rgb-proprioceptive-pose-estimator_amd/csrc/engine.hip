@@ -72,11 +72,13 @@ struct rpe_resnet50 {
     void* early_grad = nullptr;
     void* G[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // gradient scratch, each max activation size
     float* stats_part = nullptr;
+    float* stats_part2 = nullptr;           // second set for the projection-shortcut branch (runs on the side stream in the forward)
     long stats_floats = 0;
     float* bwd_part = nullptr;
     long bwd_part_floats = 0;
     float* c1c2 = nullptr;
     double* dpart = nullptr;     // staged BN partial-sum reduction scratch
+    double* dpart2 = nullptr;    // ... of the projection-shortcut branch
     float* stem_dw = nullptr;    // [64][8][8][4]
     std::vector<Named> named;
     int train_mode = 0;
@@ -230,10 +232,12 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
     want(e, &e->early_grad, st.rows * 64 * es);
     for (int i = 0; i < 5; ++i) want(e, &e->G[i], max_act * es);
     want(e, (void**)&e->stats_part, e->stats_floats * 4);
+    want(e, (void**)&e->stats_part2, e->stats_floats * 4);
     e->bwd_part_floats = 1024L * 2 * 2048;
     want(e, (void**)&e->bwd_part, e->bwd_part_floats * 4);
     want(e, (void**)&e->c1c2, 2 * 2048 * 4L);
     want(e, (void**)&e->dpart, RPE_BN_DPART_DOUBLES(2048) * 8);
+    want(e, (void**)&e->dpart2, RPE_BN_DPART_DOUBLES(2048) * 8);
     want(e, (void**)&e->stem_dw, 64L * 256 * 4);
     want(e, (void**)&e->pack_tab, 64L * sizeof(rpe_pack_desc));
     for (auto& c : e->convs) {
@@ -354,6 +358,7 @@ extern "C" int rpe_resnet50_bind(rpe_resnet50_t* e, void* workspace, long worksp
             return rpe_set_error_hip(he, __FILE__, __LINE__);
         // arrival counters of the fused BN reduce+finalize launches start at zero (and are left at zero by every launch)
         if (hipError_t he = hipMemset(e->dpart, 0, 64 * sizeof(double))) return rpe_set_error_hip(he, __FILE__, __LINE__);
+        if (hipError_t he = hipMemset(e->dpart2, 0, 64 * sizeof(double))) return rpe_set_error_hip(he, __FILE__, __LINE__);
     }
     e->gspan_lo = nullptr; e->gspan_bytes = 0;
     if (grads_host) {
@@ -377,6 +382,17 @@ extern "C" int rpe_resnet50_bind(rpe_resnet50_t* e, void* workspace, long worksp
 }
 
 #define TRY(x) do { if (int err__ = (x)) return err__; } while (0)
+#define HIPTRY(x) do { hipError_t he__ = (x); if (he__ != hipSuccess) return rpe_set_error_hip(he__, __FILE__, __LINE__); } while (0)
+
+static hipEvent_t sync_event(rpe_resnet50* e) {
+    if (e->sync_next == e->sync_pool.size()) {
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+        e->sync_pool.push_back(ev);
+    }
+    return e->sync_pool[e->sync_next++];
+}
+
 
 extern "C" int rpe_resnet50_pack_weights(rpe_resnet50_t* e, void* stream) {
     if (!e || !e->bound) return rpe_set_error(RPE_ERR_STATE, "resnet50_pack_weights: engine not bound");
@@ -395,17 +411,38 @@ static double conv_flops(const ConvL& c) { return 2.0 * (double)c.rows * c.d.out
 static const void* fwd_weight(rpe_resnet50* e, ConvL& c) { return (e->dtype == RPE_F32 && &c != &e->convs[0]) ? (const void*)e->params[c.p_w] : c.wf; }
 
 // conv -> batch statistics -> BN apply (+residual) (+relu)
-static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residual, int relu, void* stream) {
+// the second HIP stream (weight gradients in the backward, the projection-shortcut branch in the forward), created on first use
+static int ensure_side(rpe_resnet50* e) {
+    if (e->overlap && !e->side) {
+        if (const char* lg = getenv("RPE_WGRAD_LAG")) e->wgrad_lag = atoi(lg) != 0;
+        if (getenv("RPE_NO_OVERLAP")) e->overlap = false;
+        else {
+            // weight gradients are off the critical path (the data-gradient chain is): RPE_SIDE_PRIO=low|high asks for a
+            // lower / higher dispatch priority than the caller's stream (experiment switch; default: same priority)
+            int least = 0, greatest = 0;
+            HIPTRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            const char* pr = getenv("RPE_SIDE_PRIO");
+            if (pr && pr[0] == 'l') HIPTRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, least));
+            else if (pr && pr[0] == 'h') HIPTRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, greatest));
+            else HIPTRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+        }
+    }
+    return 0;
+}
+
+static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residual, int relu, void* stream, bool second_set = false) {
     const bool train = e->train_mode != 0;
+    float* stats = second_set ? e->stats_part2 : e->stats_part;
+    double* dpart = second_set ? e->dpart2 : e->dpart;
     e->pending_flops = conv_flops(c);
     e->pending_bytes = conv_in_bytes(e, c) + conv_out_bytes(e, c);
-    if (&c == &e->convs[0]) PROF(e, RPE_PROF_CONV_FWD, stream, rpe_stem_conv_fwd(e->dtype, x, c.wf, c.y, train ? e->stats_part : nullptr, e->B, e->H, e->W, stream));
-    else PROF(e, RPE_PROF_CONV_FWD, stream, rpe_conv2d_fwd(&c.d, e->dtype, x, fwd_weight(e, c), c.y, train ? e->stats_part : nullptr, stream));
+    if (&c == &e->convs[0]) PROF(e, RPE_PROF_CONV_FWD, stream, rpe_stem_conv_fwd(e->dtype, x, c.wf, c.y, train ? stats : nullptr, e->B, e->H, e->W, stream));
+    else PROF(e, RPE_PROF_CONV_FWD, stream, rpe_conv2d_fwd(&c.d, e->dtype, x, fwd_weight(e, c), c.y, train ? stats : nullptr, stream));
     float* rm = e->running[2 * c.bn_i];
     float* rv = e->running[2 * c.bn_i + 1];
     if (train) {
-        PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_finalize(e->stats_part, (int)rpe_conv_stats_tiles(c.rows), c.d.out_c, c.rows, e->params[c.p_g], e->params[c.p_b], rm, rv,
-                            e->nbt[c.bn_i], 0.1f, 1e-5f, c.scale, c.shift, c.mean, c.invstd, e->dpart, stream));
+        PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_finalize(stats, (int)rpe_conv_stats_tiles(c.rows), c.d.out_c, c.rows, e->params[c.p_g], e->params[c.p_b], rm, rv,
+                            e->nbt[c.bn_i], 0.1f, 1e-5f, c.scale, c.shift, c.mean, c.invstd, dpart, stream));
     } else {
         if (!rm || !rv) return rpe_set_error(RPE_ERR_STATE, "resnet50_forward: eval mode needs running statistics");
         TRY(rpe_bn_eval_affine(c.d.out_c, e->params[c.p_g], e->params[c.p_b], rm, rv, 1e-5f, c.scale, c.shift, stream));
@@ -425,12 +462,29 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
     TRY(conv_bn(e, st, e->x4, nullptr, 1, stream));
     PROF(e, RPE_PROF_OTHER, stream, rpe_maxpool3x3s2_fwd(e->dtype, st.a, e->pool, e->pool_idx, e->B, st.Ho, st.Wo, 64, stream));
     const void* x = e->pool;
+    TRY(ensure_side(e));
+    e->sync_next = 0;
+    static const bool fwd_overlap = getenv("RPE_NO_FWD_OVERLAP") == nullptr;
     for (auto& b : e->blocks) {
         ConvL &c1 = e->convs[b.c1], &c2 = e->convs[b.c2], &c3 = e->convs[b.c3];
+        const void* idn = x;
+        hipEvent_t ds_done = nullptr;
+        if (b.cd >= 0 && e->overlap && e->side && fwd_overlap) {
+            // projection shortcut (conv + BN, no ReLU): independent of conv1..conv2, joined before conv3's BN adds it
+            ConvL& cd = e->convs[b.cd];
+            hipEvent_t x_ready = sync_event(e);
+            ds_done = sync_event(e);
+            if (!x_ready || !ds_done) return rpe_set_error(RPE_ERR_HIP, "resnet50_forward: hipEventCreate failed");
+            HIPTRY(hipEventRecord(x_ready, (hipStream_t)stream));
+            HIPTRY(hipStreamWaitEvent(e->side, x_ready, 0));
+            TRY(conv_bn(e, cd, x, nullptr, 0, e->side, true));
+            HIPTRY(hipEventRecord(ds_done, e->side));
+            idn = cd.a;
+        }
         TRY(conv_bn(e, c1, x, nullptr, 1, stream));
         TRY(conv_bn(e, c2, c1.a, nullptr, 1, stream));
-        const void* idn = x;
-        if (b.cd >= 0) { ConvL& cd = e->convs[b.cd]; TRY(conv_bn(e, cd, x, nullptr, 0, stream)); idn = cd.a; }
+        if (b.cd >= 0 && !ds_done) { ConvL& cd = e->convs[b.cd]; TRY(conv_bn(e, cd, x, nullptr, 0, stream)); idn = cd.a; }
+        if (ds_done) HIPTRY(hipStreamWaitEvent((hipStream_t)stream, ds_done, 0));
         TRY(conv_bn(e, c3, c2.a, idn, 1, stream));
         x = c3.a;
     }
@@ -487,17 +541,6 @@ static int bn_from_dz(rpe_resnet50* e, ConvL& c, const void* dz, void* dy, void*
                                                               e->fused_tiles, e->grads[c.p_g], e->grads[c.p_b], dy, c.rows,
                                                               c.d.out_c, e->c1c2, e->dpart, stream));
     return 0;
-}
-
-#define HIPTRY(x) do { hipError_t he__ = (x); if (he__ != hipSuccess) return rpe_set_error_hip(he__, __FILE__, __LINE__); } while (0)
-
-static hipEvent_t sync_event(rpe_resnet50* e) {
-    if (e->sync_next == e->sync_pool.size()) {
-        hipEvent_t ev;
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
-        e->sync_pool.push_back(ev);
-    }
-    return e->sync_pool[e->sync_next++];
 }
 
 // the main stream is about to WRITE gradient buffer `buf`: wait for a side-stream weight-gradient still reading it
@@ -557,20 +600,7 @@ extern "C" int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_fea
     for (int i = 0; i < np; ++i)
         if (!e->grads[i]) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward: gradient tensors were not bound");
     hipStream_t s = (hipStream_t)stream;
-    if (e->overlap && !e->side) {
-        if (const char* lg = getenv("RPE_WGRAD_LAG")) e->wgrad_lag = atoi(lg) != 0;
-        if (getenv("RPE_NO_OVERLAP")) e->overlap = false;
-        else {
-            // weight gradients are off the critical path (the data-gradient chain is): RPE_SIDE_PRIO=low|high asks for a
-            // lower / higher dispatch priority than the caller's stream (experiment switch; default: same priority)
-            int least = 0, greatest = 0;
-            HIPTRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            const char* pr = getenv("RPE_SIDE_PRIO");
-            if (pr && pr[0] == 'l') HIPTRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, least));
-            else if (pr && pr[0] == 'h') HIPTRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, greatest));
-            else HIPTRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-        }
-    }
+    TRY(ensure_side(e));
     e->sync_next = 0;
     for (int i = 0; i < 6; ++i) { e->pend_buf[i] = nullptr; e->pend_ev[i] = nullptr; }
     if (e->gspan_lo) HIPTRY(hipMemsetAsync(e->gspan_lo, 0, e->gspan_bytes, s));
