@@ -148,6 +148,17 @@ int rpe_bn_backward_from_dz(int dtype, const void* dz, const void* y, const floa
 int rpe_maxpool3x3s2_fwd(int dtype, const void* x, void* out, unsigned char* idx, int B, int H, int W, int C, void* stream);
 int rpe_maxpool3x3s2_bwd(int dtype, const void* dout, const unsigned char* idx, const void* addend, void* dx, int B, int H, int W, int C,
                          void* stream);
+/* Stem backward in two passes over y (fused form of rpe_maxpool3x3s2_bwd + the aux head's scatter + rpe_bn_backward for the
+ * 64-channel bn1): the gradient of a1 = relu(bn1(y)) is gathered on the fly from dpool / pool_idx (B, H/2, W/2, 64) and,
+ * when aux_dout != NULL, from the aux head (gradient dout[b*aux_ld + pos] (x aux_depth_feat) of the winner pixel aux_idx of
+ * each 2x2 window, times aux_w[c]); the ReLU mask is recomputed from y*scale + shift.  part: >= 128 floats per block of the
+ * reduction pass (up to 8192 blocks are used when it is large enough); c1c2: 128
+ * floats; dpart as for rpe_bn_finalize.  replaces: autograd through torchvision's bn1 / relu / maxpool and the aux branch
+ * (models/naive.py:203-211,223-231). */
+int rpe_stem_bwd(int dtype, const void* dpool, const unsigned char* pool_idx, const void* y, const float* scale, const float* shift, const float* mean,
+                 const float* invstd, const float* gamma, const float* aux_dout, long aux_ld, const float* aux_depth_feat,
+                 const unsigned char* aux_idx, const float* aux_w, float* dgamma, float* dbeta, void* dy, int B, int H, int W, float* part,
+                 long part_floats, float* c1c2, double* dpart, void* stream);
 /* replaces: nn.AdaptiveAvgPool2d((1,1)) + flatten; output fp32 [B][C] */
 int rpe_avgpool_fwd(int dtype, const void* x, float* out, int B, int HW, int C, void* stream);
 int rpe_avgpool_bwd(int dtype, const float* dout, void* dx, int B, int HW, int C, void* stream);
@@ -159,6 +170,7 @@ int rpe_avgpool_bwd(int dtype, const float* dout, void* dx, int B, int HW, int C
  * un-multiplied value, idx the winning pixel. */
 int rpe_aux_head_fwd(int dtype, const void* a1, const float* w, const float* bias, const float* depth_feat, float* out, long ld_out,
                      float* raw, unsigned char* idx, int B, int H, int W, void* stream);
+/* d_a1 (dense gradient of a1, zero except the winner pixels) may be NULL when the stem backward gathers it itself (rpe_stem_bwd) */
 int rpe_aux_head_bwd(int dtype, const float* dout, long ld_dout, const void* a1, const float* w, const float* depth_feat, const float* raw,
                      const unsigned char* idx, void* d_a1, float* dw, float* dbias, float* d_depth_feat, int B, int H, int W, void* stream);
 /* replaces: depth_nets[i] = AvgPool2d(2) x2 -> InstanceNorm2d(1, affine) -> Flatten (models/naive.py:233-240) */
@@ -254,6 +266,11 @@ const char* rpe_last_kernel_name(void);
 int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_features, long ld_d_features, void* stream);
 int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int join, void* stream);
 int rpe_resnet50_backward_end(rpe_resnet50_t* e, int use_d_early, void* stream);
+/* Instead of a dense early-feature gradient tensor (rpe_resnet50_early_grad), hand the aux head's gradient to the next backward
+ * in its compact form (see rpe_stem_bwd); the pointers must stay valid until that backward's end stage has been enqueued.
+ * aux_dout == NULL clears it. */
+int rpe_resnet50_set_aux_grad(rpe_resnet50_t* e, const float* aux_dout, long aux_ld, const float* aux_depth_feat, const unsigned char* aux_idx,
+                              const float* aux_w);
 /* debugging / parity: device pointer, rows and channels of a named intermediate (e.g. "layer1.0.y1") */
 int rpe_resnet50_tensor(const rpe_resnet50_t* e, const char* name, const void** ptr, long* rows, int* channels);
 

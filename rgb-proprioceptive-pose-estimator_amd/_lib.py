@@ -60,6 +60,7 @@ _SPEC = {
     "rpe_bn_backward": (I, [I, P, P, P, P, P, P, P, P, P, P, L, I, P, L, P, P, P]),
     "rpe_maxpool3x3s2_fwd": (I, [I, P, P, P, I, I, I, I, P]),
     "rpe_maxpool3x3s2_bwd": (I, [I, P, P, P, P, I, I, I, I, P]),
+    "rpe_stem_bwd": (I, [I, P, P, P, P, P, P, P, P, P, L, P, P, P, P, P, P, I, I, I, P, L, P, P, P]),
     "rpe_avgpool_fwd": (I, [I, P, P, I, I, I, P]),
     "rpe_avgpool_bwd": (I, [I, P, P, I, I, I, P]),
     "rpe_aux_head_fwd": (I, [I, P, P, P, P, P, L, P, P, I, I, I, P]),
@@ -93,6 +94,7 @@ _SPEC = {
     "rpe_resnet50_backward_begin": (I, [P, P, L, P]),
     "rpe_resnet50_backward_blocks": (I, [P, I, I, P]),
     "rpe_resnet50_backward_end": (I, [P, I, P]),
+    "rpe_resnet50_set_aux_grad": (I, [P, P, L, P, P, P]),
     "rpe_resnet50_profile_kernels": (L, [P, P, L]),
     "rpe_last_kernel_name": (c_char_p, []),
     "rpe_resnet50_tensor": (I, [P, c_char_p, POINTER(c_void_p), POINTER(c_long), POINTER(c_int)]),

@@ -79,6 +79,8 @@ struct rpe_resnet50 {
     float* c1c2 = nullptr;
     double* dpart = nullptr;     // staged BN partial-sum reduction scratch
     double* dpart2 = nullptr;    // ... of the projection-shortcut branch
+    // aux-head gradient in compact form for the fused stem backward (rpe_resnet50_set_aux_grad)
+    const float* aux_dout = nullptr; long aux_ld = 0; const float* aux_df = nullptr; const unsigned char* aux_idx = nullptr; const float* aux_w = nullptr;
     float* stem_dw = nullptr;    // [64][8][8][4]
     std::vector<Named> named;
     int train_mode = 0;
@@ -691,13 +693,33 @@ extern "C" int rpe_resnet50_backward_end(rpe_resnet50_t* e, int use_d_early, voi
     // stem: g0 = gradient wrt maxpool output
     ConvL& st = e->convs[0];
     TRY(writable(e, g1, stream));
-    PROF(e, RPE_PROF_OTHER, stream, rpe_maxpool3x3s2_bwd(e->dtype, g0, e->pool_idx, use_d_early ? e->early_grad : nullptr, g1, e->B, st.Ho, st.Wo, 64, stream));
-    TRY(bn_back(e, st, g1, 1, g1, nullptr, stream));
+    static const bool unfused = getenv("RPE_STEM_UNFUSED") != nullptr;
+    if ((use_d_early && !e->aux_dout) || unfused) {
+        // dense early-feature gradient supplied by the caller (rpe_resnet50_early_grad): pool backward, then BN backward
+        if (use_d_early && e->aux_dout) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward_end: RPE_STEM_UNFUSED needs the dense early gradient");
+        PROF(e, RPE_PROF_OTHER, stream, rpe_maxpool3x3s2_bwd(e->dtype, g0, e->pool_idx, use_d_early ? e->early_grad : nullptr, g1, e->B, st.Ho, st.Wo, 64, stream));
+        TRY(bn_back(e, st, g1, 1, g1, nullptr, stream));
+    } else {
+        const bool aux = use_d_early != 0;
+        PROF(e, RPE_PROF_BN_BWD, stream, rpe_stem_bwd(e->dtype, g0, e->pool_idx, st.y, st.scale, st.shift, st.mean, st.invstd, e->params[st.p_g],
+                                                      aux ? e->aux_dout : nullptr, e->aux_ld, aux ? e->aux_df : nullptr, aux ? e->aux_idx : nullptr,
+                                                      aux ? e->aux_w : nullptr, e->grads[st.p_g], e->grads[st.p_b], g1, e->B, st.Ho, st.Wo,
+                                                      e->bwd_part, e->bwd_part_floats, e->c1c2, e->dpart, stream));
+    }
+    e->aux_dout = nullptr;
     if (hipError_t he = hipMemsetAsync(e->stem_dw, 0, 64 * 256 * 4, s)) return rpe_set_error_hip(he, __FILE__, __LINE__);
     PROF(e, RPE_PROF_CONV_WGRAD, stream, rpe_stem_conv_wgrad(e->dtype, e->x4, g1, e->stem_dw, e->B, e->H, e->W, stream));
     TRY(rpe_unpack_stem_grad(e->stem_dw, e->grads[st.p_w], stream));
     TRY(join_side(e, s));
     e->bwd_next = -2;
+    return 0;
+}
+
+extern "C" int rpe_resnet50_set_aux_grad(rpe_resnet50_t* e, const float* aux_dout, long aux_ld, const float* aux_depth_feat,
+                                         const unsigned char* aux_idx, const float* aux_w) {
+    if (!e) return rpe_set_error(RPE_ERR_STATE, "resnet50_set_aux_grad: null engine");
+    if (aux_dout && (!aux_idx || !aux_w || aux_ld <= 0)) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_set_aux_grad: winner indices, weight and row pitch are required");
+    e->aux_dout = aux_dout; e->aux_ld = aux_ld; e->aux_df = aux_depth_feat; e->aux_idx = aux_idx; e->aux_w = aux_w;
     return 0;
 }
 

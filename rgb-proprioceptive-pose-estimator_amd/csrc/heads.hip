@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void aux_fwd_kernel(const T* __restrict__ a1, 
     }
 }
 
-// backward: d_a1 (full tensor, zero except the winning pixel), dw (64), dbias, d_depth_feat
+// backward: d_a1 (full tensor, zero except the winning pixel; skipped when null), dw (64), dbias, d_depth_feat
 template <typename T>
 __global__ __launch_bounds__(256) void aux_bwd_kernel(const float* __restrict__ dout, long ld_dout, const T* __restrict__ a1,
                                                      const float* __restrict__ w, const float* __restrict__ depth_feat,
@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void aux_bwd_kernel(const float* __restrict__ 
 #pragma unroll
                 for (int e = 0; e < CE; ++e) g[e] = 0.f;
             }
-            *(u32x4*)(d_a1 + off) = f_to_chunk<T>(g);
+            if (d_a1) *(u32x4*)(d_a1 + off) = f_to_chunk<T>(g);
+            else if (k == bi) break;   // compact form (rpe_stem_bwd gathers the a1 gradient itself): only the winner is read
         }
         if (sub == 0) gb += d;
     }

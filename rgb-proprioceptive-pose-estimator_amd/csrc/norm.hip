@@ -387,6 +387,139 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stem backward, fused: gradient of a1 = relu(bn1(y)) gathered on the fly from its two consumers -- the 3x3/2 max pool
+// (winner taps) and, optionally, the aux head (1x1 conv 64->1 + 2x2 max pool: winner pixel of each window gets g*w[c]) --
+// then the ReLU mask (recomputed from y) and BatchNorm backward.  Two passes over y (reduce, apply) instead of
+// maxpool_bwd + aux scatter + bn_bwd_reduce + bn_bwd_apply over three 411 MB tensors (dA, d_a1, a1) that no longer exist.
+// ---------------------------------------------------------------------------------------------
+struct StemAux {
+    const float* dout;            // [B][ld] gradient of the aux feature columns, or null (no aux head)
+    long ld;
+    const float* depth_feat;      // [B][Ho2*Wo2] or null: aux feature was multiplied by it
+    const unsigned char* idx;     // [B][Ho2*Wo2] winner (0..3) of each 2x2 window
+    const float* w;               // [64] aux conv weight
+};
+
+// One a1 pixel (b, h, w), CE channels from c0.  A pixel belongs to the pool windows oh in {(h+1)/2 [tap row 1 for even h, 0 for
+// odd h], (h-1)/2 [tap row 2, odd h only]} x the same in w: 1, 2 or 4 windows.  The callers walk a row with all lanes on the
+// same column parity, so which windows exist is wave-uniform (only the right/bottom edge is a lane predicate).
+template <typename T>
+__device__ __forceinline__ void stem_dz_chunk(const T* __restrict__ dpool, const unsigned char* __restrict__ pidx, const StemAux& ax, const float* axw,
+                                              const float* sc, const float* sh, const float* yy, int b, int h, int w, int c0,
+                                              int H, int W, int Ho, int Wo, float* dz) {
+    constexpr int CE = Elem<T>::kChunk;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) dz[e] = 0.f;
+    const int oh_a = (h + 1) >> 1, kh_a = h + 1 - 2 * oh_a, ow_a = (w + 1) >> 1, kw_a = w + 1 - 2 * ow_a;
+    auto window = [&](int oh, int ow, int tap) {
+        const long o = (((long)b * Ho + oh) * Wo + ow) * 64 + c0;
+        float d[CE];
+        chunk_to_f<T>(*(const u32x4*)(dpool + o), d);
+        unsigned long long taps;   // the CE winner taps of this chunk in one load (o is a multiple of CE)
+        if (CE == 8) taps = *(const unsigned long long*)(pidx + o);
+        else taps = *(const unsigned*)(pidx + o);
+#pragma unroll
+        for (int e = 0; e < CE; ++e)
+            if (((taps >> (8 * e)) & 0xffull) == (unsigned long long)tap) dz[e] += d[e];
+    };
+    const bool row_a = oh_a < Ho, col_a = ow_a < Wo, row_b = h & 1, col_b = w & 1;
+    if (row_a && col_a) window(oh_a, ow_a, kh_a * 3 + kw_a);
+    if (row_a && col_b) window(oh_a, ow_a - 1, kh_a * 3 + 2);
+    if (row_b && col_a) window(oh_a - 1, ow_a, 6 + kw_a);
+    if (row_b && col_b) window(oh_a - 1, ow_a - 1, 8);
+    if (ax.dout) {
+        const int Ho2 = H >> 1, Wo2 = W >> 1;
+        const long pos = (long)(h >> 1) * Wo2 + (w >> 1);
+        const long flat = (long)b * Ho2 * Wo2 + pos;
+        if (ax.idx[flat] == (unsigned char)((h & 1) * 2 + (w & 1))) {
+            float g = ax.dout[(long)b * ax.ld + pos];
+            if (ax.depth_feat) g *= ax.depth_feat[flat];
+#pragma unroll
+            for (int e = 0; e < CE; ++e) dz[e] += g * axw[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < CE; ++e)
+        if (!(fmaf(yy[e], sc[e], sh[e]) > 0.f)) dz[e] = 0.f;   // the forward's expression (bn_apply_kernel)
+}
+
+// pass 1: block partial sums of dz and dz*xhat -> part [gridDim.x][2][64]
+template <typename T>
+__global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(const T* __restrict__ dpool, const unsigned char* __restrict__ pidx, const StemAux ax,
+                                                             const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd, int B, int H, int W,
+                                                             int Ho, int Wo, float* __restrict__ part) {
+    constexpr int CE = Elem<T>::kChunk, CPR = 64 / CE, PPB = 256 / CPR;   // chunks per pixel, pixels per block pass
+    __shared__ float sh[PPB][64][2];
+    const int cc = threadIdx.x % CPR, pl = threadIdx.x / CPR, c0 = cc * CE;
+    float sc[CE], sf[CE], mu[CE], is[CE], s1[CE], s2[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { sc[e] = scale[c0 + e]; sf[e] = shift[c0 + e]; mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e]; s1[e] = 0.f; s2[e] = 0.f; }
+    float axw[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) axw[e] = ax.dout ? ax.w[c0 + e] : 0.f;
+    // one image row (b, h) at a time per block: the row decomposition is one scalar division per row, not two 64-bit
+    // divisions per element (which, not HBM, bounded the first version of this kernel: 0.5 ms per pass)
+    for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
+        const int b = row / H, h = row - b * H;
+        for (int pw = 0; pw < 2; ++pw)   // all lanes on the same column parity: the set of pool windows is wave-uniform
+            for (int w = 2 * pl + pw; w < W; w += 2 * PPB) {
+                const long pix = (long)row * W + w;
+                float yy[CE], dz[CE];
+                chunk_to_f<T>(*(const u32x4*)(y + pix * 64 + c0), yy);
+                stem_dz_chunk<T>(dpool, pidx, ax, axw, sc, sf, yy, b, h, w, c0, H, W, Ho, Wo, dz);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) { s1[e] += dz[e]; s2[e] += dz[e] * (yy[e] - mu[e]) * is[e]; }
+            }
+    }
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { sh[pl][c0 + e][0] = s1[e]; sh[pl][c0 + e][1] = s2[e]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int c = threadIdx.x >> 1, which = threadIdx.x & 1;
+        float t = 0.f;
+        for (int k = 0; k < PPB; ++k) t += sh[k][c][which];
+        part[((long)blockIdx.x * 2 + which) * 64 + c] = t;
+    }
+}
+
+// pass 2: dy = gamma*invstd*(dz - c1 - xhat*c2)
+template <typename T>
+__global__ __launch_bounds__(256) void stem_bwd_apply_kernel(const T* __restrict__ dpool, const unsigned char* __restrict__ pidx, const StemAux ax,
+                                                            const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ c1, const float* __restrict__ c2,
+                                                            T* __restrict__ dy, int B, int H, int W, int Ho, int Wo) {
+    constexpr int CE = Elem<T>::kChunk, CPR = 64 / CE, PPB = 256 / CPR;
+    const int cc = threadIdx.x % CPR, pl = threadIdx.x / CPR, c0 = cc * CE;
+    float sc[CE], sf[CE], k0[CE], k1[CE], k2[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+        sc[e] = scale[c0 + e]; sf[e] = shift[c0 + e];
+        const float gi = gamma[c0 + e] * invstd[c0 + e];
+        k0[e] = gi;
+        k2[e] = -gi * invstd[c0 + e] * c2[c0 + e];
+        k1[e] = -gi * c1[c0 + e] - k2[e] * mean[c0 + e];
+    }
+    float axw[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) axw[e] = ax.dout ? ax.w[c0 + e] : 0.f;
+    for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
+        const int b = row / H, h = row - b * H;
+        for (int pw = 0; pw < 2; ++pw)
+            for (int w = 2 * pl + pw; w < W; w += 2 * PPB) {
+                const long pix = (long)row * W + w;
+                float yy[CE], dz[CE];
+                chunk_to_f<T>(*(const u32x4*)(y + pix * 64 + c0), yy);
+                stem_dz_chunk<T>(dpool, pidx, ax, axw, sc, sf, yy, b, h, w, c0, H, W, Ho, Wo, dz);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) dz[e] = fmaf(k0[e], dz[e], fmaf(k2[e], yy[e], k1[e]));
+                *(u32x4*)(dy + pix * 64 + c0) = f_to_chunk<T>(dz);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Global average pool [B][HW][C] (T) -> [B][C] (f32), and its backward
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -590,6 +723,29 @@ int bn_bwd_from_dz_launch(const void* dz, const void* y, const float* mean, cons
     return 0;
 }
 
+template <typename T>
+int stem_bwd_launch(const void* dpool, const unsigned char* pidx, const StemAux& ax, const void* y, const float* scale, const float* shift,
+                    const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta, void* dy, int B, int H, int W,
+                    float* part, long part_floats, float* c1c2, double* dpart, hipStream_t s) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    // the gather is latency-bound (a few dependent loads per pixel): as many rows in flight as the partial-sum workspace allows
+    long nbl = part_floats / (2 * 64);
+    if (nbl > 8192) nbl = 8192;
+    if (nbl > (long)B * H) nbl = (long)B * H;
+    if (nbl < 1) return rpe_set_error(RPE_ERR_WORKSPACE, "stem_bwd: partial-sum workspace too small");
+    const int nb = (int)nbl;
+    hipLaunchKernelGGL((stem_bwd_reduce_kernel<T>), dim3(nb), dim3(256), 0, s, (const T*)dpool, pidx, ax, (const T*)y, scale, shift, mean, invstd, B, H, W,
+                       Ho, Wo, part);
+    RPE_CHECK_LAUNCH();
+    float* c1 = c1c2;
+    float* c2 = c1c2 + 64;
+    if (int e = reduce_finalize(part, nb, 64, dpart, BnBwdFin{(double)B * H * W, dgamma, dbeta, c1, c2}, s)) return e;
+    hipLaunchKernelGGL((stem_bwd_apply_kernel<T>), dim3(B * H < 16384 ? B * H : 16384), dim3(256), 0, s, (const T*)dpool, pidx, ax, (const T*)y, scale, shift, mean, invstd,
+                       gamma, (const float*)c1, (const float*)c2, (T*)dy, B, H, W, Ho, Wo);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace rpe
 
 using namespace rpe;
@@ -696,6 +852,18 @@ int rpe_stage_frames_u8(int dtype, const unsigned char* frames, void* out, int B
     else return rpe_set_error(RPE_ERR_DTYPE, "stage_frames_u8: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;
+}
+
+int rpe_stem_bwd(int dtype, const void* dpool, const unsigned char* pool_idx, const void* y, const float* scale, const float* shift, const float* mean,
+                 const float* invstd, const float* gamma, const float* aux_dout, long aux_ld, const float* aux_depth_feat,
+                 const unsigned char* aux_idx, const float* aux_w, float* dgamma, float* dbeta, void* dy, int B, int H, int W, float* part,
+                 long part_floats, float* c1c2, double* dpart, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || ((H | W) & 1)) return rpe_set_error(RPE_ERR_SHAPE, "stem_bwd: H and W must be even");
+    if (aux_dout && (!aux_idx || !aux_w)) return rpe_set_error(RPE_ERR_SHAPE, "stem_bwd: aux gradient needs its winner indices and weight");
+    const StemAux ax{aux_dout, aux_ld, aux_depth_feat, aux_idx, aux_w};
+    if (dtype == RPE_F32) return stem_bwd_launch<float>(dpool, pool_idx, ax, y, scale, shift, mean, invstd, gamma, dgamma, dbeta, dy, B, H, W, part, part_floats, c1c2, dpart, (hipStream_t)stream);
+    if (dtype == RPE_BF16) return stem_bwd_launch<bf16>(dpool, pool_idx, ax, y, scale, shift, mean, invstd, gamma, dgamma, dbeta, dy, B, H, W, part, part_floats, c1c2, dpart, (hipStream_t)stream);
+    return rpe_set_error(RPE_ERR_DTYPE, "stem_bwd: unsupported dtype");
 }
 
 }  // extern "C"

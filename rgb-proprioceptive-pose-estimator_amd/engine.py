@@ -213,6 +213,11 @@ class _Plan:
         off = ptr - base
         return self.workspace[off:off + n * esz].view(self.dtype).view(shape)
 
+    def set_aux_grad(self, d_cols, depth_feat, idx, conv_w):
+        """Hand the aux head's gradient to the next backward in compact form (the stem backward gathers it on the fly); the
+        tensors must stay alive until that backward has been enqueued."""
+        lib.rpe_resnet50_set_aux_grad(self.handle, ops._p(d_cols), d_cols.stride(0), ops._p(depth_feat), ops._p(idx), ops._p(conv_w))
+
     def tensor(self, name):
         ptr, rows, ch = ctypes.c_void_p(), ctypes.c_long(), ctypes.c_int()
         lib.rpe_resnet50_tensor(self.handle, name.encode(), ctypes.byref(ptr), ctypes.byref(rows), ctypes.byref(ch))

@@ -4,6 +4,8 @@ gradients into the parameters' arena gradient views (p._rpe_grad) and returns th
 Everything is fp32; row buffers are [rows, pad4(cols)] with zero padding columns so every GEMM
 operand is 16-byte aligned.
 """
+import os
+
 import torch
 
 from . import ops
@@ -188,7 +190,10 @@ class AuxHeadOp:
         gradient buffer and the head's parameter gradients."""
         plan, raw, idx, feat, xhat, b, h, w, n = self.saved
         a1 = plan.early_feature()
-        d_a1 = plan.early_grad()
+        # The gradient of a1 is NOT materialised (a 411 MB tensor at 256 images, zero in 3 of 4 pixels): the trunk's fused stem
+        # backward gathers it from (d_cols, depth feature, winner index, conv weight).  RPE_STEM_UNFUSED=1: dense form.
+        dense = os.environ.get("RPE_STEM_UNFUSED") is not None
+        d_a1 = plan.early_grad() if dense else None
         dev = a1.device
         if self.trainable:
             gw, gb = _grad_of(self.conv_w), _grad_of(self.conv_b)
@@ -200,6 +205,9 @@ class AuxHeadOp:
         s = ops._stream()
         lib.rpe_aux_head_bwd(ops.dtype_code(a1), ops._p(d_cols), d_cols.stride(0), ops._p(a1), ops._p(self.conv_w.data), ops._p(feat), ops._p(raw),
                              ops._p(idx), ops._p(d_a1), ops._p(gw), ops._p(gb), ops._p(d_feat), b, h, w, s)
+        if not dense:
+            self._keep = (d_cols, feat, idx)   # alive until the trunk backward has been enqueued
+            plan.set_aux_grad(d_cols, feat, idx, self.conv_w.data)
         if feat is not None and self.trainable:
             giw, gib = _grad_of(self.in_w), _grad_of(self.in_b)
             giw.zero_(), gib.zero_()

@@ -424,3 +424,65 @@ def test_small_utils():
     dst = torch.zeros(300, 80, device=DEV)
     ops.copy2d(x.to(DEV), dst[:, 5:], cols=70)
     assert torch.equal(dst[:, 5:75].cpu(), x)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("use_aux,use_depth", [(False, False), (True, False), (True, True)])
+def test_stem_backward_fused(dtype, use_aux, use_depth):
+    """rpe_stem_bwd == autograd through relu(bn1(y)) -> {maxpool 3x3/2, aux conv 64->1 + maxpool 2 (x depth feature)}."""
+    import ctypes
+    from rgb_proprioceptive_pose_estimator_amd._lib import lib
+    g = torch.Generator().manual_seed(21)
+    b, h = 3, 12
+    y = q(torch.randn(b, 64, h, h, generator=g) * 1.5 + 0.2, dtype).requires_grad_(True)
+    gamma = (torch.rand(64, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(64, generator=g) * 0.3).requires_grad_(True)
+    mean = y.detach().mean((0, 2, 3))
+    var = y.detach().var((0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale, shift = gamma.detach() * invstd, beta.detach() - mean * gamma.detach() * invstd
+    a1 = F.relu(F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5))
+    pool = F.max_pool2d(a1, 3, 2, 1)
+    dpool = q(torch.randn(pool.shape, generator=g), dtype)
+    loss = (pool * dpool).sum()
+    w = torch.randn(1, 64, 1, 1, generator=g) * 0.2
+    bias = torch.tensor([0.1])
+    n = (h // 2) ** 2
+    ld = n + 4
+    dout = torch.randn(b, n, generator=g)
+    df = torch.rand(b, n, generator=g) + 0.5
+    if use_aux:
+        aux = po.aux_head(a1, w, bias)
+        if use_depth:
+            aux = aux * df
+        loss = loss + (aux * dout).sum()
+    gy, gg, gb_ = torch.autograd.grad(loss, (y, gamma, beta))
+
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    S = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    code = ops.dtype_code(dtype)
+    yd = nhwc(y.detach()).to(dtype).to(DEV)
+    sc, sh, mu, iv, gm = (t.float().to(DEV) for t in (scale, shift, mean, invstd, gamma.detach()))
+    a1d = ops.bn_apply(yd, sc, sh, None, True)
+    _, pidx = ops.maxpool_fwd(a1d)
+    dpd = nhwc(dpool).to(dtype).to(DEV)
+    aux_idx = aux_w = doutd = dfd = None
+    if use_aux:
+        aux_w, bd = w.reshape(64).to(DEV), bias.to(DEV)
+        dfd = df.to(DEV) if use_depth else None
+        out = torch.zeros(b, ld, device=DEV)
+        raw = torch.empty(b, n, device=DEV)
+        aux_idx = torch.empty(b, n, dtype=torch.uint8, device=DEV)
+        lib.rpe_aux_head_fwd(code, P(a1d), P(aux_w), P(bd), P(dfd), P(out), ld, P(raw), P(aux_idx), b, h, h, S)
+        doutd = torch.zeros(b, ld, device=DEV)
+        doutd[:, :n] = dout.to(DEV)
+    dgam, dbet = torch.empty(64, device=DEV), torch.empty(64, device=DEV)
+    dy = torch.empty_like(yd)
+    part = torch.empty(2 * 1024 * 64, device=DEV)
+    c1c2 = torch.empty(128, device=DEV)
+    dpart = torch.zeros(256 * 2 * 64 + 64, dtype=torch.float64, device=DEV)
+    lib.rpe_stem_bwd(code, P(dpd), P(pidx), P(yd), P(sc), P(sh), P(mu), P(iv), P(gm), P(doutd), ld, P(dfd), P(aux_idx), P(aux_w), P(dgam), P(dbet),
+                     P(dy), b, h, h, P(part), part.numel(), P(c1c2), P(dpart), S)
+    t = 2e-4 if dtype == torch.float32 else 3e-2
+    assert rel_err(nchw(dy), gy) < t
+    assert rel_err(dgam, gg) < t and rel_err(dbet, gb_) < t
