@@ -65,6 +65,11 @@ long rpe_conv_stats_tiles(long rows);
  * stats_part (nullable): per-128-row-tile column sums and sums of squares of the fp32
  * accumulators, consumed by rpe_bn_finalize. */
 int rpe_conv2d_fwd(const rpe_conv_desc* d, int dtype, const void* x, const void* w_krsc, void* y, float* stats_part, void* stream);
+/* inference form: out = [relu](conv(x, w) + bias[out_c] (+ addend[rows][out_c])) in one launch.  With w = weight * BN scale
+ * (rpe_pack_desc.scale) and bias = BN shift this is conv -> BatchNorm2d(eval) -> (+identity) -> ReLU of torchvision's
+ * Bottleneck (called at models/naive.py:316 in eval mode / rollout). */
+int rpe_conv2d_fwd_affine(const rpe_conv_desc* d, int dtype, const void* x, const void* w_krsc, void* out, const float* bias, const void* addend,
+                          int relu, void* stream);
 /* dx[B][H][W][in_c] = conv_transpose(dy, w) (+ addend);  w_crsk = [in_c][kh][kw][out_c]. */
 int rpe_conv2d_dgrad(const rpe_conv_desc* d, int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, void* stream);
 /* Data gradient with the BatchNorm-backward reduction of the PRODUCING layer fused into the epilogue:
@@ -87,6 +92,8 @@ int rpe_conv2d_wgrad(const rpe_conv_desc* d, int dtype, const void* x, const voi
 /* ResNet stem conv1 (3->64, 7x7 / 2, pad 3) on the NHWC4 image produced by
  * rpe_stage_image_nhwc4; w_packed = [64][8][8][4] from rpe_pack_stem_weight. */
 int rpe_stem_conv_fwd(int dtype, const void* x4, const void* w_packed, void* y, float* stats_part, int B, int H, int W, void* stream);
+int rpe_stem_conv_fwd_affine(int dtype, const void* x4, const void* w_packed, void* out, const float* bias, int relu, int B, int H, int W,
+                             void* stream);
 int rpe_stem_conv_wgrad(int dtype, const void* x4, const void* dy, float* dw_packed, int B, int H, int W, void* stream);
 
 /* weight layouts.  w_krsc_f32 is the fp32 master in channels_last storage. */
@@ -99,9 +106,11 @@ typedef struct {
     int Co, RS, Ci;
     int pad_;
     long start;       /* first flat element index of this layer */
+    const float* scale; /* NULL, or [Co]: the forward copy is written as w * scale[co] (inference: BatchNorm folded into the conv) */
 } rpe_pack_desc;
 int rpe_pack_conv_weights_multi(int dtype, const rpe_pack_desc* table_dev, int nlayers, long total, void* stream);
-int rpe_pack_stem_weight(int dtype, const float* w_oihw, void* out, void* stream);
+/* scale: NULL or [64] (see rpe_pack_desc.scale) */
+int rpe_pack_stem_weight(int dtype, const float* w_oihw, const float* scale, void* out, void* stream);
 int rpe_unpack_stem_grad(const float* d_packed, float* dw_oihw, void* stream);
 
 /* replaces: the per-tensor .cuda() staging of util/learn_utils.py:130-138 for `img`

@@ -41,16 +41,18 @@ _SPEC = {
     "rpe_conv_out_hw": (I, [PD, POINTER(c_int), POINTER(c_int)]),
     "rpe_conv_stats_tiles": (L, [L]),
     "rpe_conv2d_fwd": (I, [PD, I, P, P, P, P, P]),
+    "rpe_conv2d_fwd_affine": (I, [PD, I, P, P, P, P, P, I, P]),
     "rpe_conv2d_dgrad": (I, [PD, I, P, P, P, P, P]),
     "rpe_conv2d_dgrad_stats_tiles": (L, [PD]),
     "rpe_conv2d_dgrad_bn": (I, [PD, I, P, P, P, P, POINTER(BnBwdEpilogue), P]),
     "rpe_bn_backward_from_dz": (I, [I, P, P, P, P, P, P, I, P, P, P, L, I, P, P, P]),
     "rpe_conv2d_wgrad": (I, [PD, I, P, P, P, P]),
     "rpe_stem_conv_fwd": (I, [I, P, P, P, P, I, I, I, P]),
+    "rpe_stem_conv_fwd_affine": (I, [I, P, P, P, P, I, I, I, I, P]),
     "rpe_stem_conv_wgrad": (I, [I, P, P, P, I, I, I, P]),
     "rpe_pack_conv_weight": (I, [I, P, P, P, I, I, I, I, P]),
     "rpe_pack_conv_weights_multi": (I, [I, P, I, L, P]),
-    "rpe_pack_stem_weight": (I, [I, P, P, P]),
+    "rpe_pack_stem_weight": (I, [I, P, P, P, P]),
     "rpe_unpack_stem_grad": (I, [P, P, P]),
     "rpe_stage_image_nhwc4": (I, [I, P, P, I, I, I, P]),
     "rpe_stage_frames_u8": (I, [I, P, P, I, I, I, I, I, POINTER(c_float), POINTER(c_float), P]),

@@ -44,7 +44,8 @@ static inline bool dgrad_parity(const rpe_conv_desc* d) {
 static inline bool is_dense(const rpe_conv_desc* d) { return d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0; }
 
 template <typename T>
-static int conv_fwd_t(const rpe_conv_desc* d, const void* x, const void* w, void* y, float* stats, hipStream_t s) {
+static int conv_fwd_t(const rpe_conv_desc* d, const void* x, const void* w, void* y, float* stats, const float* bias, const void* addend, int relu,
+                      hipStream_t s) {
     const int Ho = out_dim(d->in_h, d->kh, d->stride, d->pad), Wo = out_dim(d->in_w, d->kw, d->stride, d->pad);
     NTArgs<T> a;
     memset(&a, 0, sizeof(a));
@@ -52,6 +53,7 @@ static int conv_fwd_t(const rpe_conv_desc* d, const void* x, const void* w, void
     a.M = d->batch * Ho * Wo; a.N = d->out_c; a.K = d->kh * d->kw * d->in_c;
     a.lda = d->in_c; a.ldb = a.K; a.ldc = d->out_c;
     a.stats_part = stats;
+    a.bias = bias; a.addend = (const T*)addend; a.ld_add = d->out_c; a.relu = relu;
     if (is_dense(d)) return launch_nt<T>(a, MODE_DENSE, s);
     Gather& g = a.g;
     g.H = d->in_h; g.W = d->in_w; g.C = d->in_c; g.Ho = Ho; g.Wo = Wo; g.R = d->kh; g.S = d->kw;
@@ -124,7 +126,7 @@ static void stem_gather(Gather& g, int H, int W) {
 }
 
 template <typename T>
-static int stem_fwd_t(const void* x4, const void* w, void* y, float* stats, int B, int H, int W, hipStream_t s) {
+static int stem_fwd_t(const void* x4, const void* w, void* y, float* stats, const float* bias, int relu, int B, int H, int W, hipStream_t s) {
     NTArgs<T> a;
     memset(&a, 0, sizeof(a));
     stem_gather(a.g, H, W);
@@ -132,6 +134,7 @@ static int stem_fwd_t(const void* x4, const void* w, void* y, float* stats, int 
     a.M = B * a.g.Ho * a.g.Wo; a.N = 64; a.K = 256;
     a.lda = 4; a.ldb = 256; a.ldc = 64;
     a.stats_part = stats;
+    a.bias = bias; a.relu = relu;
     return launch_nt<T>(a, MODE_STEM, s);
 }
 
@@ -194,7 +197,13 @@ long rpe_conv2d_dgrad_stats_tiles(const rpe_conv_desc* d) {
 
 int rpe_conv2d_fwd(const rpe_conv_desc* d, int dtype, const void* x, const void* w_krsc, void* y, float* stats_part, void* stream) {
     if (int e = check_desc(d)) return e;
-    DISPATCH(dtype, conv_fwd_t, d, x, w_krsc, y, stats_part, (hipStream_t)stream);
+    DISPATCH(dtype, conv_fwd_t, d, x, w_krsc, y, stats_part, nullptr, nullptr, 0, (hipStream_t)stream);
+}
+
+int rpe_conv2d_fwd_affine(const rpe_conv_desc* d, int dtype, const void* x, const void* w_krsc, void* out, const float* bias, const void* addend,
+                          int relu, void* stream) {
+    if (int e = check_desc(d)) return e;
+    DISPATCH(dtype, conv_fwd_t, d, x, w_krsc, out, nullptr, bias, addend, relu, (hipStream_t)stream);
 }
 
 int rpe_conv2d_dgrad(const rpe_conv_desc* d, int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, void* stream) {
@@ -216,7 +225,13 @@ int rpe_conv2d_wgrad(const rpe_conv_desc* d, int dtype, const void* x, const voi
 
 int rpe_stem_conv_fwd(int dtype, const void* x4, const void* w_packed, void* y, float* stats_part, int B, int H, int W, void* stream) {
     if (B <= 0 || H < 7 || W < 7) return rpe_set_error(RPE_ERR_SHAPE, "stem_conv: bad shape");
-    DISPATCH(dtype, stem_fwd_t, x4, w_packed, y, stats_part, B, H, W, (hipStream_t)stream);
+    DISPATCH(dtype, stem_fwd_t, x4, w_packed, y, stats_part, nullptr, 0, B, H, W, (hipStream_t)stream);
+}
+
+int rpe_stem_conv_fwd_affine(int dtype, const void* x4, const void* w_packed, void* out, const float* bias, int relu, int B, int H, int W,
+                             void* stream) {
+    if (B <= 0 || H < 7 || W < 7) return rpe_set_error(RPE_ERR_SHAPE, "stem_conv: bad shape");
+    DISPATCH(dtype, stem_fwd_t, x4, w_packed, out, nullptr, bias, relu, B, H, W, (hipStream_t)stream);
 }
 
 int rpe_stem_conv_wgrad(int dtype, const void* x4, const void* dy, float* dw_packed, int B, int H, int W, void* stream) {

@@ -91,6 +91,8 @@ struct rpe_resnet50 {
     // conv/fc weight gradients are accumulated with atomics: when the bound gradient tensors form one contiguous block
     // (they do in the flat arena) it is zeroed by ONE memset per backward instead of 54 (15 us each)
     rpe_pack_desc* pack_tab = nullptr;   // device table for the one-launch weight packing
+    rpe_pack_desc* pack_tab_fold = nullptr;  // ... with the BN scale folded into the forward copy (inference)
+    int pack_state = 0;                  // what the forward copies hold: 0 unknown, 1 plain weights, 2 weights * BN scale (eval)
     long pack_total = 0;
     char* gspan_lo = nullptr;
     size_t gspan_bytes = 0;
@@ -212,7 +214,7 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
         if (&c == &e->convs[0]) {
             want(e, &c.wf, 64L * 256 * es);
         } else {
-            if (dtype != RPE_F32) want(e, &c.wf, wn * es);
+            want(e, &c.wf, wn * es);   // (fp32 training reads the masters in place; the copy holds the BN-folded inference weights)
             want(e, &c.wd, wn * es);
         }
         want(e, (void**)&c.scale, c.d.out_c * 4L);
@@ -242,6 +244,7 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
     want(e, (void**)&e->dpart2, RPE_BN_DPART_DOUBLES(2048) * 8);
     want(e, (void**)&e->stem_dw, 64L * 256 * 4);
     want(e, (void**)&e->pack_tab, 64L * sizeof(rpe_pack_desc));
+    want(e, (void**)&e->pack_tab_fold, 64L * sizeof(rpe_pack_desc));
     for (auto& c : e->convs) {
         const double mnk = 2.0 * (double)c.rows * c.d.out_c * (double)(c.d.kh * c.d.kw * c.d.in_c);
         const double in_b = (double)batch * c.d.in_h * c.d.in_w * c.d.in_c * es, out_b = (double)c.rows * c.d.out_c * es;
@@ -351,6 +354,7 @@ extern "C" int rpe_resnet50_bind(rpe_resnet50_t* e, void* workspace, long worksp
             d.wf = e->dtype == RPE_F32 ? nullptr : c.wf;
             d.wd = c.wd;
             d.Co = c.d.out_c; d.RS = c.d.kh * c.d.kw; d.Ci = c.d.in_c; d.pad_ = 0;
+            d.scale = nullptr;
             d.start = start;
             start += (long)d.Co * d.RS * d.Ci;
             tab.push_back(d);
@@ -358,6 +362,15 @@ extern "C" int rpe_resnet50_bind(rpe_resnet50_t* e, void* workspace, long worksp
         e->pack_total = start;
         if (hipError_t he = hipMemcpy(e->pack_tab, tab.data(), tab.size() * sizeof(rpe_pack_desc), hipMemcpyHostToDevice))
             return rpe_set_error_hip(he, __FILE__, __LINE__);
+        for (size_t i = 1; i < e->convs.size(); ++i) {   // inference table: forward copy only, scaled by the layer's BN scale
+            ConvL& c = e->convs[i];
+            tab[i - 1].wf = c.wf;
+            tab[i - 1].wd = nullptr;
+            tab[i - 1].scale = c.scale;
+        }
+        if (hipError_t he = hipMemcpy(e->pack_tab_fold, tab.data(), tab.size() * sizeof(rpe_pack_desc), hipMemcpyHostToDevice))
+            return rpe_set_error_hip(he, __FILE__, __LINE__);
+        e->pack_state = 0;
         // arrival counters of the fused BN reduce+finalize launches start at zero (and are left at zero by every launch)
         if (hipError_t he = hipMemset(e->dpart, 0, 64 * sizeof(double))) return rpe_set_error_hip(he, __FILE__, __LINE__);
         if (hipError_t he = hipMemset(e->dpart2, 0, 64 * sizeof(double))) return rpe_set_error_hip(he, __FILE__, __LINE__);
@@ -398,8 +411,9 @@ static hipEvent_t sync_event(rpe_resnet50* e) {
 
 extern "C" int rpe_resnet50_pack_weights(rpe_resnet50_t* e, void* stream) {
     if (!e || !e->bound) return rpe_set_error(RPE_ERR_STATE, "resnet50_pack_weights: engine not bound");
-    PROF(e, RPE_PROF_OTHER, stream, rpe_pack_stem_weight(e->dtype, e->params[e->convs[0].p_w], e->convs[0].wf, stream));
+    PROF(e, RPE_PROF_OTHER, stream, rpe_pack_stem_weight(e->dtype, e->params[e->convs[0].p_w], nullptr, e->convs[0].wf, stream));
     PROF(e, RPE_PROF_OTHER, stream, rpe_pack_conv_weights_multi(e->dtype, e->pack_tab, (int)e->convs.size() - 1, e->pack_total, stream));
+    e->pack_state = 1;
     const int np = (int)e->pnames.size();
     TRY(rpe_transpose_f32(e->params[np - 2], e->fc_wt, e->latent, 2048, 2048, e->latent_pad, stream));
     return 0;
@@ -410,7 +424,24 @@ static double conv_in_bytes(const rpe_resnet50* e, const ConvL& c) { return (dou
 static double conv_out_bytes(const rpe_resnet50* e, const ConvL& c) { return (double)c.rows * c.d.out_c * e->esz; }
 static double conv_flops(const ConvL& c) { return 2.0 * (double)c.rows * c.d.out_c * (double)(c.d.kh * c.d.kw * c.d.in_c); }
 
-static const void* fwd_weight(rpe_resnet50* e, ConvL& c) { return (e->dtype == RPE_F32 && &c != &e->convs[0]) ? (const void*)e->params[c.p_w] : c.wf; }
+static const void* fwd_weight(rpe_resnet50* e, ConvL& c) {
+    return (e->dtype == RPE_F32 && &c != &e->convs[0] && e->train_mode) ? (const void*)e->params[c.p_w] : c.wf;
+}
+
+// Inference: every BN is an affine map of fixed running statistics -> scale into the packed forward weights (once, until the
+// weights or the mode change), shift + residual + ReLU into the conv epilogue: one launch per conv instead of three.
+static int fold_for_eval(rpe_resnet50* e, void* stream) {
+    for (auto& c : e->convs) {
+        float* rm = e->running[2 * c.bn_i];
+        float* rv = e->running[2 * c.bn_i + 1];
+        if (!rm || !rv) return rpe_set_error(RPE_ERR_STATE, "resnet50_forward: eval mode needs running statistics");
+        TRY(rpe_bn_eval_affine(c.d.out_c, e->params[c.p_g], e->params[c.p_b], rm, rv, 1e-5f, c.scale, c.shift, stream));
+    }
+    TRY(rpe_pack_stem_weight(e->dtype, e->params[e->convs[0].p_w], e->convs[0].scale, e->convs[0].wf, stream));
+    TRY(rpe_pack_conv_weights_multi(e->dtype, e->pack_tab_fold, (int)e->convs.size() - 1, e->pack_total, stream));
+    e->pack_state = 2;
+    return 0;
+}
 
 // conv -> batch statistics -> BN apply (+residual) (+relu)
 // the second HIP stream (weight gradients in the backward, the projection-shortcut branch in the forward), created on first use
@@ -438,17 +469,18 @@ static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residua
     double* dpart = second_set ? e->dpart2 : e->dpart;
     e->pending_flops = conv_flops(c);
     e->pending_bytes = conv_in_bytes(e, c) + conv_out_bytes(e, c);
-    if (&c == &e->convs[0]) PROF(e, RPE_PROF_CONV_FWD, stream, rpe_stem_conv_fwd(e->dtype, x, c.wf, c.y, train ? stats : nullptr, e->B, e->H, e->W, stream));
-    else PROF(e, RPE_PROF_CONV_FWD, stream, rpe_conv2d_fwd(&c.d, e->dtype, x, fwd_weight(e, c), c.y, train ? stats : nullptr, stream));
+    if (!train) {
+        // folded inference form (fold_for_eval): a = relu(conv(x, w*scale) + shift (+ residual)); y is not written
+        if (&c == &e->convs[0]) PROF(e, RPE_PROF_CONV_FWD, stream, rpe_stem_conv_fwd_affine(e->dtype, x, c.wf, c.a, c.shift, relu, e->B, e->H, e->W, stream));
+        else PROF(e, RPE_PROF_CONV_FWD, stream, rpe_conv2d_fwd_affine(&c.d, e->dtype, x, c.wf, c.a, c.shift, residual, relu, stream));
+        return 0;
+    }
+    if (&c == &e->convs[0]) PROF(e, RPE_PROF_CONV_FWD, stream, rpe_stem_conv_fwd(e->dtype, x, c.wf, c.y, stats, e->B, e->H, e->W, stream));
+    else PROF(e, RPE_PROF_CONV_FWD, stream, rpe_conv2d_fwd(&c.d, e->dtype, x, fwd_weight(e, c), c.y, stats, stream));
     float* rm = e->running[2 * c.bn_i];
     float* rv = e->running[2 * c.bn_i + 1];
-    if (train) {
-        PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_finalize(stats, (int)rpe_conv_stats_tiles(c.rows), c.d.out_c, c.rows, e->params[c.p_g], e->params[c.p_b], rm, rv,
-                            e->nbt[c.bn_i], 0.1f, 1e-5f, c.scale, c.shift, c.mean, c.invstd, dpart, stream));
-    } else {
-        if (!rm || !rv) return rpe_set_error(RPE_ERR_STATE, "resnet50_forward: eval mode needs running statistics");
-        TRY(rpe_bn_eval_affine(c.d.out_c, e->params[c.p_g], e->params[c.p_b], rm, rv, 1e-5f, c.scale, c.shift, stream));
-    }
+    PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_finalize(stats, (int)rpe_conv_stats_tiles(c.rows), c.d.out_c, c.rows, e->params[c.p_g], e->params[c.p_b], rm, rv,
+                        e->nbt[c.bn_i], 0.1f, 1e-5f, c.scale, c.shift, c.mean, c.invstd, dpart, stream));
     PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_apply(e->dtype, c.y, residual, c.a, c.scale, c.shift, c.rows, c.d.out_c, relu, stream));
     return 0;
 }
@@ -458,6 +490,8 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
     if (!e || !e->bound) return rpe_set_error(RPE_ERR_STATE, "resnet50_forward: engine not bound");
     if ((!img_nchw && !frames) || !features || ld_features < e->latent) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_forward: bad img/features");
     e->train_mode = training;
+    if (training && e->pack_state != 1) TRY(rpe_resnet50_pack_weights(e, stream));
+    if (!training && e->pack_state != 2) TRY(fold_for_eval(e, stream));
     if (frames) PROF(e, RPE_PROF_OTHER, stream, rpe_stage_frames_u8(e->dtype, frames, e->x4, e->B, Hs, Ws, e->H, e->W, mean3, std3, stream));
     else PROF(e, RPE_PROF_OTHER, stream, rpe_stage_image_nhwc4(e->dtype, img_nchw, e->x4, e->B, e->H, e->W, stream));
     ConvL& st = e->convs[0];

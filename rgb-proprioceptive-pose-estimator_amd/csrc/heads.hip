@@ -382,9 +382,12 @@ __global__ __launch_bounds__(256) void pack_conv_weights_multi_kernel(const rpe_
             for (int it = 0; it < 4; ++it) {
                 const int co = tr + 16 * it;
                 const long j = ((long)(co0 + co) * d.RS + rs) * d.Ci + ci0 + tc;
-                const f32x4 v = *(const f32x4*)(d.src + j);
+                f32x4 v = *(const f32x4*)(d.src + j);
                 tile[co][tc] = v.x; tile[co][tc + 1] = v.y; tile[co][tc + 2] = v.z; tile[co][tc + 3] = v.w;
-                if (d.wf) store4<T>((T*)d.wf + j, v.x, v.y, v.z, v.w);
+                if (d.wf) {
+                    if (d.scale) { const float sc = d.scale[co0 + co]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }   // tile[] keeps the unscaled value for wd
+                    store4<T>((T*)d.wf + j, v.x, v.y, v.z, v.w);
+                }
             }
             __syncthreads();
             if (d.wd) {
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(256) void pack_conv_weights_multi_kernel(const rpe_
             const long t = j / e.Ci;
             const int rs = (int)(t % e.RS), co = (int)(t / e.RS);
             const float v = e.src[j];
-            if (e.wf) ((T*)e.wf)[j] = Elem<T>::from_f(v);
+            if (e.wf) ((T*)e.wf)[j] = Elem<T>::from_f(e.scale ? v * e.scale[co] : v);
             if (e.wd) ((T*)e.wd)[((long)ci * e.RS + rs) * e.Co + co] = Elem<T>::from_f(v);
         }
     }
@@ -414,12 +417,13 @@ __global__ __launch_bounds__(256) void pack_conv_weights_multi_kernel(const rpe_
 
 // stem: OIHW [64][3][7][7] fp32 -> [64][8][8][4] T (taps and channel zero padded)
 template <typename T>
-__global__ void pack_stem_weight_kernel(const float* __restrict__ w, T* __restrict__ out) {
+__global__ void pack_stem_weight_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 64 * 256) return;
     const int c = i & 3, s = (i >> 2) & 7, r = (i >> 5) & 7, co = i >> 8;
     float v = 0.f;
     if (c < 3 && s < 7 && r < 7) v = w[((co * 3 + c) * 7 + r) * 7 + s];
+    if (scale) v *= scale[co];
     out[i] = Elem<T>::from_f(v);
 }
 __global__ void unpack_stem_grad_kernel(const float* __restrict__ d, float* __restrict__ dw) {
@@ -579,9 +583,9 @@ int rpe_pack_conv_weights_multi(int dtype, const rpe_pack_desc* table_dev, int n
     return 0;
 }
 
-int rpe_pack_stem_weight(int dtype, const float* w_oihw, void* out, void* stream) {
-    if (dtype == RPE_F32) hipLaunchKernelGGL((pack_stem_weight_kernel<float>), dim3(64), dim3(256), 0, (hipStream_t)stream, w_oihw, (float*)out);
-    else if (dtype == RPE_BF16) hipLaunchKernelGGL((pack_stem_weight_kernel<bf16>), dim3(64), dim3(256), 0, (hipStream_t)stream, w_oihw, (bf16*)out);
+int rpe_pack_stem_weight(int dtype, const float* w_oihw, const float* scale, void* out, void* stream) {
+    if (dtype == RPE_F32) hipLaunchKernelGGL((pack_stem_weight_kernel<float>), dim3(64), dim3(256), 0, (hipStream_t)stream, w_oihw, scale, (float*)out);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((pack_stem_weight_kernel<bf16>), dim3(64), dim3(256), 0, (hipStream_t)stream, w_oihw, scale, (bf16*)out);
     else return rpe_set_error(RPE_ERR_DTYPE, "pack_stem_weight: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;

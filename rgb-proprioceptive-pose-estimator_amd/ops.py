@@ -70,6 +70,17 @@ def conv2d_fwd(x, w_krsc, stride, pad, want_stats=False):
     return (y, st) if want_stats else y
 
 
+def conv2d_fwd_affine(x, w_krsc, stride, pad, bias, addend=None, relu=True):
+    """Inference form: relu(conv(x, w) + bias (+ addend)) in one launch (BatchNorm folded: w = weight * scale, bias = shift)."""
+    _chk(x, "x"), _chk(w_krsc, "w")
+    co, k = w_krsc.shape[0], w_krsc.shape[1]
+    d = conv_desc(x.shape, co, k, stride, pad)
+    ho, wo = conv_out_hw(d)
+    out = torch.empty((x.shape[0], ho, wo, co), dtype=x.dtype, device=x.device)
+    lib.rpe_conv2d_fwd_affine(ctypes.byref(d), dtype_code(x), _p(x), _p(w_krsc), _p(out), _p(bias), _p(addend), int(relu), _stream())
+    return out
+
+
 def conv2d_dgrad(dy, w_crsk, x_shape, stride, pad, addend=None):
     """dy [B,Ho,Wo,Co], w_crsk [Ci,kh,kw,Co] -> dx [B,H,W,Ci] (+ addend)."""
     _chk(dy, "dy"), _chk(w_crsk, "w")
@@ -135,7 +146,7 @@ def stage_image(img_nchw, dtype):
 
 def pack_stem_weight(w_oihw, dtype):
     out = torch.empty((64, 8, 8, 4), dtype=dtype, device=w_oihw.device)
-    lib.rpe_pack_stem_weight(dtype_code(dtype), _p(_chk(w_oihw, "w")), _p(out), _stream())
+    lib.rpe_pack_stem_weight(dtype_code(dtype), _p(_chk(w_oihw, "w")), None, _p(out), _stream())
     return out
 
 

@@ -486,3 +486,25 @@ def test_stem_backward_fused(dtype, use_aux, use_depth):
     t = 2e-4 if dtype == torch.float32 else 3e-2
     assert rel_err(nchw(dy), gy) < t
     assert rel_err(dgam, gg) < t and rel_err(dbet, gb_) < t
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 14, 64, 64, 3, 1, 1), (2, 14, 256, 512, 1, 2, 0), (3, 8, 64, 256, 1, 1, 0), (8, 24, 128, 128, 3, 1, 1)])
+@pytest.mark.parametrize("residual", [False, True])
+def test_conv_fwd_affine_inference_form(dtype, cfg, residual):
+    """relu(conv(x, w*scale) + shift (+ identity)) in one launch == conv -> BatchNorm2d(eval) -> add -> ReLU."""
+    b, h, ci, co, k, s, p = cfg
+    x, w = _conv_inputs(cfg, dtype)
+    g = torch.Generator().manual_seed(5)
+    scale = torch.rand(co, generator=g) + 0.5
+    shift = torch.randn(co, generator=g) * 0.3
+    wq = q(w * scale[:, None, None, None], dtype)
+    ref = F.conv2d(x, wq, None, s, p) + shift[None, :, None, None]
+    add = None
+    if residual:
+        add = q(torch.randn(ref.shape, generator=g), dtype)
+        ref = ref + add
+    ref = F.relu(ref)
+    out = ops.conv2d_fwd_affine(nhwc(x).to(dtype).to(DEV), wq.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV), s, p, shift.to(DEV),
+                                None if add is None else nhwc(add).to(dtype).to(DEV), True)
+    assert rel_err(nchw(out), ref) < tol(dtype)

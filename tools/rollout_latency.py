@@ -1,0 +1,46 @@
+"""Diagnostic: latency of one rollout step -- eval-mode forward of one 224x224 frame with the LSTM state carried
+on the device -- for the sequence models, fp32 and bf16 trunks.  usage: python tools/rollout_latency.py [n_calls]"""
+import contextlib
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from rgb_proprioceptive_pose_estimator_amd import models as M
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+
+
+def bench(name, make, dtype):
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(sys.stderr):
+        model = make(dtype)
+    model.cuda().eval()
+    model.rollout = True
+    if hasattr(model, "reset_initial_state"):
+        model.reset_initial_state(1)
+    seq = getattr(model, "requires_sequence", False)
+    img = torch.randn((1, 1, 3, 224, 224) if seq else (1, 3, 224, 224), device="cuda")
+    x0 = torch.randn((1, 1, 7) if seq else (1, 7), device="cuda")
+    with torch.no_grad():
+        for _ in range(10):
+            model(img, None, x0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(N):
+            model(img, None, x0)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / N
+    print("%-8s %-9s %.3f ms per rollout step (%.0f frames/s)" % (name, str(dtype).replace("torch.", ""), dt * 1e3, 1.0 / dt))
+
+
+MODELS = {
+    "no": lambda dt: M.NaiveObjectStateEstimator("cube", [1024, 256, 64], 50, 512, False, (9,), False, False, False, compute_dtype=dt),
+    "tdo": lambda dt: M.TemporallyDependentObjectStateEstimator("hammer", 512, 50, 512, 10, 0.1, False, (9,), False, False, False, compute_dtype=dt),
+    "tdo_v2": lambda dt: M.TemporallyDependentObjectStateEstimatorV2("robot1_eef", 512, 64, 50, 512, 10, 0.1, False, (9,), False, False, compute_dtype=dt),
+}
+for name, make in MODELS.items():
+    for dt in (torch.bfloat16, torch.float32):
+        bench(name, make, dt)
