@@ -30,11 +30,13 @@ struct ConvL {
     void* wd = nullptr;  // packed dgrad weight [Ci][R][S][Co]
     void* y = nullptr;   // raw conv output
     void* a = nullptr;   // after BN (+residual) (+ReLU)
+    void* dy = nullptr;  // backward: dz of this layer's BN output, turned into dy (gradient of the raw conv output) in place
     float *scale = nullptr, *shift = nullptr, *mean = nullptr, *invstd = nullptr;
 };
 
 struct Block {
     int c1, c2, c3, cd;  // conv indices (cd = -1: identity shortcut)
+    void* dz = nullptr;  // backward: ReLU-masked gradient at the block output (kept as the shortcut gradient)
 };
 
 struct Named {
@@ -70,7 +72,8 @@ struct rpe_resnet50 {
     float* fc_wt = nullptr;      // fc weight transposed [2048][latent_pad]
     int latent_pad = 0;
     void* early_grad = nullptr;
-    void* G[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // gradient scratch, each max activation size
+    void* G[2] = {nullptr, nullptr};      // main-stream-only gradient scratch (projection-shortcut dx; stem dy), max activation size
+    void* d_pool = nullptr;              // gradient of the max-pool output (input of layer1)
     float* stats_part = nullptr;
     float* stats_part2 = nullptr;           // second set for the projection-shortcut branch (runs on the side stream in the forward)
     long stats_floats = 0;
@@ -85,8 +88,6 @@ struct rpe_resnet50 {
     std::vector<Named> named;
     int train_mode = 0;
     int fused_tiles = 0;
-    void* cur[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // rotating gradient buffers of a backward in progress
-    bool wgrad_lag = false;                 // experiment (RPE_WGRAD_LAG=1): issue a layer's weight gradient AFTER the data gradient that follows it
     int bwd_next = -2;                                     // next block of a staged backward (-1: blocks done, -2: idle)
     // conv/fc weight gradients are accumulated with atomics: when the bound gradient tensors form one contiguous block
     // (they do in the flat arena) it is zeroed by ONE memset per backward instead of 54 (15 us each)
@@ -109,8 +110,6 @@ struct rpe_resnet50 {
     bool overlap = true;
     std::vector<hipEvent_t> sync_pool;
     size_t sync_next = 0;
-    const void* pend_buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t pend_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double flops[RPE_PROF_NUM] = {0};   // algorithmic FLOPs per pass, per category
     double bytes[RPE_PROF_NUM] = {0};   // algorithmic bytes per pass, per category
 };
@@ -210,6 +209,7 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
         if (n > max_act) max_act = n;
         want(e, &c.y, n * es);
         want(e, &c.a, n * es);
+        want(e, &c.dy, n * es);
         const long wn = (long)c.d.out_c * c.d.kh * c.d.kw * c.d.in_c;
         if (&c == &e->convs[0]) {
             want(e, &c.wf, 64L * 256 * es);
@@ -234,7 +234,9 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
     want(e, (void**)&e->d_pooled, (long)batch * 2048 * 4);
     want(e, (void**)&e->fc_wt, 2048L * e->latent_pad * 4);
     want(e, &e->early_grad, st.rows * 64 * es);
-    for (int i = 0; i < 5; ++i) want(e, &e->G[i], max_act * es);
+    for (int i = 0; i < 2; ++i) want(e, &e->G[i], max_act * es);
+    for (auto& b : e->blocks) { const ConvL& c3 = e->convs[b.c3]; want(e, &b.dz, c3.rows * c3.d.out_c * es); }
+    want(e, &e->d_pool, (long)batch * (e->convs[0].Ho / 2) * (e->convs[0].Wo / 2) * 64 * es);
     want(e, (void**)&e->stats_part, e->stats_floats * 4);
     want(e, (void**)&e->stats_part2, e->stats_floats * 4);
     e->bwd_part_floats = 1024L * 2 * 2048;
@@ -343,7 +345,7 @@ extern "C" int rpe_resnet50_bind(rpe_resnet50_t* e, void* workspace, long worksp
     }
     e->named.push_back({"pool", e->pool, (long)e->B * (e->convs[0].Ho / 2) * (e->convs[0].Wo / 2), 64});
     e->named.push_back({"x4", e->x4, (long)e->B * e->H * e->W, 4});
-    for (int i = 0; i < 5; ++i) e->named.push_back({"G" + std::to_string(i), e->G[i], 0, 0});
+    for (int i = 0; i < 2; ++i) e->named.push_back({"G" + std::to_string(i), e->G[i], 0, 0});
     {   // descriptor table of the per-step weight packing (bind is a setup call: one small synchronous upload)
         std::vector<rpe_pack_desc> tab;
         long start = 0;
@@ -447,7 +449,6 @@ static int fold_for_eval(rpe_resnet50* e, void* stream) {
 // the second HIP stream (weight gradients in the backward, the projection-shortcut branch in the forward), created on first use
 static int ensure_side(rpe_resnet50* e) {
     if (e->overlap && !e->side) {
-        if (const char* lg = getenv("RPE_WGRAD_LAG")) e->wgrad_lag = atoi(lg) != 0;
         if (getenv("RPE_NO_OVERLAP")) e->overlap = false;
         else {
             // weight gradients are off the critical path (the data-gradient chain is): RPE_SIDE_PRIO=low|high asks for a
@@ -579,18 +580,6 @@ static int bn_from_dz(rpe_resnet50* e, ConvL& c, const void* dz, void* dy, void*
     return 0;
 }
 
-// the main stream is about to WRITE gradient buffer `buf`: wait for a side-stream weight-gradient still reading it
-static int writable(rpe_resnet50* e, const void* buf, void* stream) {
-    for (int i = 0; i < 6; ++i)
-        if (e->pend_buf[i] == buf && e->pend_ev[i]) {
-            HIPTRY(hipStreamWaitEvent((hipStream_t)stream, e->pend_ev[i], 0));
-            e->pend_ev[i] = nullptr;
-            e->pend_buf[i] = nullptr;
-        }
-    return 0;
-}
-
-// dW = x (*) dy.  Runs on the side stream once `dy` is complete on the main stream; `dy_buf` stays reserved until it is done.
 static int wgrad(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, void* stream) {
     float* dw = e->grads[c.p_w];
     hipStream_t run = (hipStream_t)stream;
@@ -605,19 +594,8 @@ static int wgrad(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, void*
     e->pending_flops = conv_flops(c);
     e->pending_bytes = conv_in_bytes(e, c) + conv_out_bytes(e, c);
     PROF(e, RPE_PROF_CONV_WGRAD, run, rpe_conv2d_wgrad(&c.d, e->dtype, x, dy, dw, run));
-    if (run != (hipStream_t)stream) {
-        hipEvent_t done = sync_event(e);
-        if (!done) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
-        HIPTRY(hipEventRecord(done, run));
-        int slot = -1;
-        for (int i = 0; i < 6; ++i) if (e->pend_buf[i] == dy || (slot < 0 && !e->pend_ev[i])) { slot = i; if (e->pend_buf[i] == dy) break; }
-        if (slot < 0) slot = 0;
-        e->pend_buf[slot] = dy;
-        e->pend_ev[slot] = done;
-    }
     return 0;
 }
-
 static int join_side(rpe_resnet50* e, hipStream_t s) {
     // everything the side stream produced so far (weight gradients) is complete before the caller's next launch on s
     if (e->overlap && e->side) {
@@ -638,7 +616,6 @@ extern "C" int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_fea
     hipStream_t s = (hipStream_t)stream;
     TRY(ensure_side(e));
     e->sync_next = 0;
-    for (int i = 0; i < 6; ++i) { e->pend_buf[i] = nullptr; e->pend_ev[i] = nullptr; }
     if (e->gspan_lo) HIPTRY(hipMemsetAsync(e->gspan_lo, 0, e->gspan_bytes, s));
     // fc
     float* dWfc = e->grads[np - 2];
@@ -652,8 +629,7 @@ extern "C" int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_fea
     TRY(rpe_linear_fwd(RPE_F32, d_features, (int)ld_d_features, e->fc_wt, e->latent_pad, nullptr, e->d_pooled, 2048, e->B, 2048, e->latent_pad, 0,
                        nullptr, 0, stream));
     ConvL& last = e->convs[e->blocks.back().c3];
-    for (int i = 0; i < 5; ++i) e->cur[i] = e->G[i];
-    TRY(rpe_avgpool_bwd(e->dtype, e->d_pooled, e->cur[0], e->B, last.Ho * last.Wo, 2048, stream));
+    TRY(rpe_avgpool_bwd(e->dtype, e->d_pooled, e->blocks.back().dz, e->B, last.Ho * last.Wo, 2048, stream));
     e->bwd_next = (int)e->blocks.size() - 1;
     return 0;
 }
@@ -665,56 +641,42 @@ extern "C" int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_fea
 // partial sums (rpe_conv2d_dgrad_bn), so each BN costs one more pass (dz, y -> dy) instead of two full passes.
 extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int join, void* stream) {
     if (!e || !e->bound || e->bwd_next < -1) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward_blocks: call rpe_resnet50_backward_begin first");
-    void *gA = e->cur[0], *gB = e->cur[1], *gC = e->cur[2], *gD = e->cur[3], *gE = e->cur[4];
     int bi = e->bwd_next;
-    // Side-stream pairing.  A weight gradient issued right when its dy is ready runs beside the data gradient of the SAME
-    // layer (same shape class: two MFMA-bound 3x3s, or two HBM-bound 1x1s).  Issuing it one launch later, beside the next
-    // BN pass and the NEXT layer's data gradient (1x1 beside 3x3), measured SLOWER (26.2 vs 25.9 ms/step, A/B on one
-    // device; RPE_WGRAD_LAG=1 selects it).  What did pay is the fifth scratch buffer both orders use: dz1 no longer
-    // overwrites dy3, so the main stream does not wait for conv3's weight gradient before conv2's data gradient.
-    const bool lag = e->wgrad_lag;
+    // Gradient buffers.  Every layer owns the buffer its dz / dy lives in (ConvL::dy) and every block the buffer of its
+    // output gradient (Block::dz): 8.5 GB more workspace at 256 images than rotating a handful of scratch buffers, but a weight
+    // gradient on the side stream then never reads a buffer the main stream writes again, so the main stream waits for the
+    // side stream nowhere inside the backward (each such event wait cost a ~10 us bubble: 70 per step, 0.8 ms).
+    // A weight gradient is issued right when its dy is final and so runs beside the data gradient of the SAME layer; issuing
+    // it one launch later (1x1 beside 3x3) measured slower (+0.3 ms/step).
     for (; bi >= 0 && count > 0; --bi, --count) {
         Block& b = e->blocks[bi];
         ConvL &c1 = e->convs[b.c1], &c2 = e->convs[b.c2], &c3 = e->convs[b.c3];
         const void* x_in = bi == 0 ? (const void*)e->pool : (const void*)e->convs[e->blocks[bi - 1].c3].a;
-        if (bi == (int)e->blocks.size() - 1) {
-            TRY(writable(e, gB, stream));
-            TRY(bn_back(e, c3, gA, 1, gB, gA, stream));  // unfused: dy3 -> gB, dz3 -> gA (in place)
-        } else {
-            TRY(writable(e, gB, stream));
-            TRY(bn_from_dz(e, c3, gA, gB, stream));       // dy3 -> gB (gA keeps dz3 = shortcut gradient)
-        }
-        if (!lag) TRY(wgrad(e, c3, c2.a, gB, stream));
-        TRY(writable(e, gC, stream));
-        TRY(dgrad_fused(e, c3, gB, gC, nullptr, &c2, 2, stream));   // dz2 -> gC
-        if (lag) TRY(wgrad(e, c3, c2.a, gB, stream));
-        TRY(bn_from_dz(e, c2, gC, gC, stream));
-        if (!lag) TRY(wgrad(e, c2, c1.a, gC, stream));
-        TRY(writable(e, gE, stream));
-        TRY(dgrad_fused(e, c2, gC, gE, nullptr, &c1, 2, stream));   // dz1 -> gE
-        if (lag) TRY(wgrad(e, c2, c1.a, gC, stream));
-        TRY(bn_from_dz(e, c1, gE, gE, stream));
-        if (!lag) TRY(wgrad(e, c1, x_in, gE, stream));
+        void* gA = b.dz;                                             // dz3 (for the last block: the raw dA)
+        void* gD = bi == 0 ? e->d_pool : e->blocks[bi - 1].dz;       // where the gradient of the block input goes
+        if (bi == (int)e->blocks.size() - 1) TRY(bn_back(e, c3, gA, 1, c3.dy, gA, stream));  // unfused: dy3, dz3 (in place)
+        else TRY(bn_from_dz(e, c3, gA, c3.dy, stream));                                       // dy3 (gA keeps dz3 = shortcut gradient)
+        TRY(wgrad(e, c3, c2.a, c3.dy, stream));
+        TRY(dgrad_fused(e, c3, c3.dy, c2.dy, nullptr, &c2, 2, stream));   // dz2
+        TRY(bn_from_dz(e, c2, c2.dy, c2.dy, stream));
+        TRY(wgrad(e, c2, c1.a, c2.dy, stream));
+        TRY(dgrad_fused(e, c2, c2.dy, c1.dy, nullptr, &c1, 2, stream));   // dz1
+        TRY(bn_from_dz(e, c1, c1.dy, c1.dy, stream));
+        TRY(wgrad(e, c1, x_in, c1.dy, stream));
         const void* shortcut = gA;
         if (b.cd >= 0) {
             ConvL& cd = e->convs[b.cd];
-            TRY(bn_back(e, cd, gA, 0, gA, nullptr, stream));          // no ReLU on the projection shortcut
-            if (!lag) TRY(wgrad(e, cd, x_in, gA, stream));
-            TRY(writable(e, gB, stream));
-            PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&cd.d, e->dtype, gA, cd.wd, gB, nullptr, stream));
-            if (lag) TRY(wgrad(e, cd, x_in, gA, stream));
-            shortcut = gB;
+            TRY(bn_back(e, cd, gA, 0, cd.dy, nullptr, stream));          // no ReLU on the projection shortcut
+            TRY(wgrad(e, cd, x_in, cd.dy, stream));
+            PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&cd.d, e->dtype, cd.dy, cd.wd, e->G[0], nullptr, stream));
+            shortcut = e->G[0];
         }
-        TRY(writable(e, gD, stream));
         if (bi > 0) {
-            TRY(dgrad_fused(e, c1, gE, gD, shortcut, &e->convs[e->blocks[bi - 1].c3], 1, stream));  // dz3 of the previous block
+            TRY(dgrad_fused(e, c1, c1.dy, gD, shortcut, &e->convs[e->blocks[bi - 1].c3], 1, stream));  // dz3 of the previous block
         } else {
-            PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&c1.d, e->dtype, gE, c1.wd, gD, shortcut, stream));
+            PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&c1.d, e->dtype, c1.dy, c1.wd, gD, shortcut, stream));
         }
-        if (lag) TRY(wgrad(e, c1, x_in, gE, stream));
-        void* t = gA; gA = gD; gD = t;
     }
-    e->cur[0] = gA; e->cur[1] = gB; e->cur[2] = gC; e->cur[3] = gD; e->cur[4] = gE;
     e->bwd_next = bi;
     if (join) TRY(join_side(e, (hipStream_t)stream));
     return 0;
@@ -723,10 +685,9 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
 extern "C" int rpe_resnet50_backward_end(rpe_resnet50_t* e, int use_d_early, void* stream) {
     if (!e || !e->bound || e->bwd_next != -1) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward_end: blocks not finished");
     hipStream_t s = (hipStream_t)stream;
-    void *g0 = e->cur[0], *g1 = e->cur[1];
+    void *g0 = e->d_pool, *g1 = e->convs[0].dy;
     // stem: g0 = gradient wrt maxpool output
     ConvL& st = e->convs[0];
-    TRY(writable(e, g1, stream));
     static const bool unfused = getenv("RPE_STEM_UNFUSED") != nullptr;
     if ((use_d_early && !e->aux_dout) || unfused) {
         // dense early-feature gradient supplied by the caller (rpe_resnet50_early_grad): pool backward, then BN backward
