@@ -26,6 +26,12 @@ template <typename T> int launch_nt(NTArgs<T>& a, int mode, hipStream_t s) {
             return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: an operand of 2 GiB or more (split the batch)");
         a.a_bytes = (unsigned)ab; a.b_bytes = (unsigned)bb;
     }
+    if (a.role != 2) {
+        // conv roles run the vector-only epilogue: whole 16-byte chunks of 8 channels, aligned rows
+        if ((a.N % 8) || (a.ldc % CE) || (((uintptr_t)a.C) & 15) || (a.addend && ((a.ld_add % CE) || (((uintptr_t)a.addend) & 15))) ||
+            (a.bn_mode && ((((uintptr_t)a.bn_y) & 15) || (a.bn_a && (((uintptr_t)a.bn_a) & 15)))))
+            return rpe_set_error(RPE_ERR_ALIGN, "igemm_nt: conv outputs need N % 8 == 0 and 16-byte aligned rows");
+    }
     if (mode == MODE_STEM) return launch_nt_mode<T, MODE_STEM>(a, s);
     if (mode == MODE_DENSE) return launch_nt_mode<T, MODE_DENSE>(a, s);
     return launch_nt_mode<T, MODE_CONV>(a, s);

@@ -86,8 +86,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 //   and every DMA instruction moves whole 128-B lines -- at 128x128x32 the kernel sat at ~16 B/clk/CU of L2->LDS traffic.
 // -----------------------------------------------------------------------------------------------
 // ROLE only tells the symbols apart in profiles: 0 conv forward, 1 conv data-gradient, 2 Linear.
-template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE, bool EPI_PIPE = true>
-__global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
+// BNM: the data gradient's fused BN-backward mode (NTArgs::bn_mode), a template parameter so that each launch carries one
+// epilogue variant only (role 1; 0 elsewhere).
+// (second launch-bound = minimum waves per SIMD: with the mode a constant hipcc hoisted the epilogue loads of mode 2 into 252
+// VGPRs -- one workgroup per CU, 25 % slower)
+template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE, int BNM = 0>
+__global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p) {
     constexpr int CE = Elem<T>::kChunk, BK = KCH * CE;
     constexpr int NW = 2 * WAVES_M, NTHR = 64 * NW;
     constexpr int BM = 64 * WAVES_M, WM = 64, WN = BN / 2, FM = WM / 16, FN = WN / 16;
@@ -289,15 +293,22 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
     const int nl = wave_n * WN + echk * 8;
     const int n = n0 + nl;
     const bool ncol_ok = n < p.N;
-    const bool nfull = n + 7 < p.N;
-    const bool vec_c = nfull && (p.ldc % CE == 0) && (((uintptr_t)p.C) & 15) == 0;
-    const bool vec_add = nfull && p.addend && (p.ld_add % CE == 0) && (((uintptr_t)p.addend) & 15) == 0;
-    const int bn_mode = p.bn_mode;
+    // Epilogue features by ROLE, resolved at compile time (the generic epilogue is ~6000 instructions of mostly untaken
+    // branches, and the short-K launches are instruction-issue bound in it): conv launches (roles 0, 1) always move whole
+    // 16-byte chunks (N % 8 == 0, aligned rows: checked by the launcher), only the data gradient has the BN modes, only the
+    // forward / Linear roles have bias and ReLU.
+    constexpr bool VEC_ONLY = ROLE != 2, HAS_BN = ROLE == 1, HAS_AFFINE = ROLE != 1;
+    const bool nfull = VEC_ONLY ? ncol_ok : n + 7 < p.N;
+    const bool vec_c = VEC_ONLY ? ncol_ok : nfull && (p.ldc % CE == 0) && (((uintptr_t)p.C) & 15) == 0;
+    const bool vec_add = VEC_ONLY ? (ncol_ok && p.addend != nullptr) : nfull && p.addend && (p.ld_add % CE == 0) && (((uintptr_t)p.addend) & 15) == 0;
+    constexpr int bn_mode = HAS_BN ? BNM : 0;
+    const float* const e_bias = HAS_AFFINE ? p.bias : nullptr;
+    const int e_relu = HAS_AFFINE ? p.relu : 0;
     // Data-gradient launches with short K are bound by the epilogue's operand stream (residual gradient, y, a_out: up to
     // three reads and one write per output element against K/N-th of that for the GEMM operands).  One step at a time
     // keeps ~1-3 KB per wave in flight; here the operands of the next DEPTH steps are requested ahead (the first DEPTH
     // before the K loop even starts), 16 B per lane and operand, into registers that are recycled step by step.
-    constexpr bool PIPE = (ROLE == 1) && (CE == 8) && EPI_PIPE;
+    constexpr bool PIPE = (ROLE == 1) && (CE == 8);
     constexpr int DEPTH = PIPE ? (NSTEP < 4 ? NSTEP : 4) : 1;
     u32x4 qd[DEPTH], qy[DEPTH], qa[DEPTH];
     auto step_row = [&](int t) -> long { return out_row(wave_m * WM + (t / NPASS) * 16 + (t % NPASS) * RPP + erow); };
@@ -393,13 +404,13 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
     for (int j = 0; j < 8; ++j) {
         cs[j] = 0.f; cq[j] = 0.f; cmean[j] = 0.f; cinv[j] = 0.f; csc[j] = 0.f; csh[j] = 0.f; cbias[j] = 0.f;
         if (n + j < p.N) {
-            if (p.bias) cbias[j] = p.bias[n + j];
+            if (e_bias) cbias[j] = e_bias[n + j];
             if (bn_mode) { cmean[j] = p.bn_mean[n + j]; cinv[j] = p.bn_invstd[n + j]; }
             if (bn_mode == 2) { csc[j] = p.bn_scale[n + j]; csh[j] = p.bn_shift[n + j]; }
         }
     }
     auto load8 = [&](const T* base, long off, bool vec, float* out) {
-        if (vec) {
+        if (VEC_ONLY || vec) {
             if (CE == 8) { chunk_to_f<T>(ld16(base + off), out); }
             else { chunk_to_f<T>(ld16(base + off), out); chunk_to_f<T>(ld16(base + off + 4), out + 4); }
         } else {
@@ -437,7 +448,7 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { cs[j] += v[j]; cq[j] += v[j] * v[j]; }
                 }
-                if (p.bias) {
+                if (e_bias) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += cbias[j];
                 }
@@ -467,12 +478,12 @@ __global__ __launch_bounds__(128 * WAVES_M) void nt_kernel(const NTArgs<T> p) {
                         v[j] = dz;
                     }
                 }
-                if (p.relu) {
+                if (e_relu) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
                 }
                 T* cp = p.C + m * p.ldc + n;
-                if (vec_c) {
+                if (VEC_ONLY || vec_c) {
                     if (CE == 8) { *(u32x4*)cp = f_to_chunk<T>(v); }
                     else { *(u32x4*)cp = f_to_chunk<T>(v); *(u32x4*)(cp + 4) = f_to_chunk<T>(v + 4); }
                 } else {
@@ -816,10 +827,17 @@ extern thread_local char g_last_kernel[96];
 
 template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE> static int launch_nt_role(NTArgs<T>& a, hipStream_t s, long nwg) {
     snprintf(g_last_kernel, sizeof(g_last_kernel), "nt_kernel<%s,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", WAVES_M, BN, KCH, MODE, NST, ROLE);
-    // RPE_NO_EPI_PIPE=1: data-gradient epilogue without the operand prefetch (A/B experiments)
-    static const bool no_pipe = getenv("RPE_NO_EPI_PIPE") != nullptr;
-    if (ROLE == 1 && no_pipe) hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, false>), dim3((unsigned)nwg), dim3(128 * WAVES_M), 0, s, a);
-    else hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, true>), dim3((unsigned)nwg), dim3(128 * WAVES_M), 0, s, a);
+    const dim3 grid((unsigned)nwg), block(128 * WAVES_M);
+    if (ROLE == 1) {
+        switch (a.bn_mode) {
+            case 1: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 1 : 0>), grid, block, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 2 : 0>), grid, block, 0, s, a); break;
+            case 3: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 3 : 0>), grid, block, 0, s, a); break;
+            default: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, 0>), grid, block, 0, s, a); break;
+        }
+    } else {
+        hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, 0>), grid, block, 0, s, a);
+    }
     RPE_CHECK_LAUNCH();
     return 0;
 }

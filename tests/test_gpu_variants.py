@@ -16,7 +16,6 @@ VARIANTS = [
     {"RPE_NT_BIG": "1"},      # 256-row / 8-wave NT tiles for M >= 4096, K >= 1024
     {"RPE_NT_BK64": "1"},     # 128-byte K rows + 2-slot ring for every K
     {"RPE_NT_NOBK64": "1"},   # ... and for none
-    {"RPE_NO_EPI_PIPE": "1"}, # data-gradient epilogue without the operand prefetch ring
     {"RPE_TN_REG": "1"},      # register staging instead of the LDS-DMA ring in the weight-gradient kernel
     {"RPE_NO_PARITY": "1"},   # stride-2 data gradient without the parity-class decomposition
     {"RPE_TN_WGS": "64"},     # few, long split-M slices in the weight gradient
