@@ -54,6 +54,7 @@ static int conv_fwd_t(const rpe_conv_desc* d, const void* x, const void* w, void
     a.lda = d->in_c; a.ldb = a.K; a.ldc = d->out_c;
     a.stats_part = stats;
     a.bias = bias; a.addend = (const T*)addend; a.ld_add = d->out_c; a.relu = relu;
+    if (bias || addend || relu) { a.role = 3; a.stats_part = nullptr; }   // inference epilogue (no batch statistics)
     if (is_dense(d)) return launch_nt<T>(a, MODE_DENSE, s);
     Gather& g = a.g;
     g.H = d->in_h; g.W = d->in_w; g.C = d->in_c; g.Ho = Ho; g.Wo = Wo; g.R = d->kh; g.S = d->kw;
@@ -135,6 +136,7 @@ static int stem_fwd_t(const void* x4, const void* w, void* y, float* stats, cons
     a.lda = 4; a.ldb = 256; a.ldc = 64;
     a.stats_part = stats;
     a.bias = bias; a.relu = relu;
+    if (bias || relu) { a.role = 3; a.stats_part = nullptr; }
     return launch_nt<T>(a, MODE_STEM, s);
 }
 

@@ -48,7 +48,8 @@ template <typename T> struct NTArgs {
     const T* bn_a;       // BN(+residual)+ReLU output, [M][ldc] (mode 1)
     const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
     int tiles_m, tiles_n;
-    int role;            // 0 conv forward, 1 conv data-gradient, 2 Linear (kernel symbol tag for profiles)
+    int role;            // 0 conv forward (training), 1 conv data gradient, 2 Linear, 3 conv forward (inference: bias/addend/ReLU):
+                         // selects the epilogue variant compiled into the kernel and tags its symbol in profiles
     long a_elems;        // elements of the tensor behind A (conv modes; 0 = dense, derived from M and lda)
     unsigned a_bytes, b_bytes;   // buffer-descriptor extents of A and Bw (filled by the launcher, < 2 GiB each)
 };

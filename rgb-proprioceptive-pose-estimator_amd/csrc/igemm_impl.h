@@ -297,10 +297,13 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
     // branches, and the short-K launches are instruction-issue bound in it): conv launches (roles 0, 1) always move whole
     // 16-byte chunks (N % 8 == 0, aligned rows: checked by the launcher), only the data gradient has the BN modes, only the
     // forward / Linear roles have bias and ReLU.
-    constexpr bool VEC_ONLY = ROLE != 2, HAS_BN = ROLE == 1, HAS_AFFINE = ROLE != 1;
+    // Roles: 0 conv forward in training (batch-statistics partial sums only), 1 conv data gradient (addend, BN modes),
+    // 2 Linear (bias / addend / ReLU, any alignment), 3 conv forward in inference (bias = BN shift, addend = identity, ReLU).
+    constexpr bool VEC_ONLY = ROLE != 2, HAS_BN = ROLE == 1, HAS_AFFINE = ROLE >= 2, HAS_ADDEND = ROLE != 0, HAS_FWD_STATS = ROLE == 0;
     const bool nfull = VEC_ONLY ? ncol_ok : n + 7 < p.N;
     const bool vec_c = VEC_ONLY ? ncol_ok : nfull && (p.ldc % CE == 0) && (((uintptr_t)p.C) & 15) == 0;
-    const bool vec_add = VEC_ONLY ? (ncol_ok && p.addend != nullptr) : nfull && p.addend && (p.ld_add % CE == 0) && (((uintptr_t)p.addend) & 15) == 0;
+    const T* const e_addend = HAS_ADDEND ? p.addend : nullptr;
+    const bool vec_add = VEC_ONLY ? (ncol_ok && e_addend != nullptr) : nfull && e_addend && (p.ld_add % CE == 0) && (((uintptr_t)e_addend) & 15) == 0;
     constexpr int bn_mode = HAS_BN ? BNM : 0;
     const float* const e_bias = HAS_AFFINE ? p.bias : nullptr;
     const int e_relu = HAS_AFFINE ? p.relu : 0;
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
         const long m = step_row(t);
         const int sl = t % DEPTH;
         if (m < 0 || !ncol_ok) return;
-        if (vec_add) qd[sl] = ld16(p.addend + m * p.ld_add + n);
+        if (vec_add) qd[sl] = ld16(e_addend + m * p.ld_add + n);
         if (bn_mode && vec_c) {
             qy[sl] = ld16(p.bn_y + m * p.ldc + n);
             if (bn_mode == 1) qa[sl] = ld16(p.bn_a + m * p.ldc + n);
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
                 v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
             }
             if (m >= 0 && ncol_ok) {
-                if (p.stats_part && !bn_mode) {
+                if (HAS_FWD_STATS && p.stats_part) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { cs[j] += v[j]; cq[j] += v[j] * v[j]; }
                 }
@@ -452,10 +455,10 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += cbias[j];
                 }
-                if (p.addend) {
+                if (e_addend) {
                     float ad[8];
                     if (PIPE && vec_add) chunk_to_f<T>(qd[sl], ad);
-                    else load8(p.addend, m * p.ld_add + n, vec_add, ad);
+                    else load8(e_addend, m * p.ld_add + n, vec_add, ad);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += ad[j];
                 }
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
             if (PIPE && t + DEPTH < NSTEP) issue(t + DEPTH);   // recycle this step's operand registers
         }
     }
-    if (p.stats_part) {
+    if ((HAS_FWD_STATS || HAS_BN) && p.stats_part) {
         // column partials: lanes with the same chunk differ in erow -> butterfly over the row bits, then pairs of 64-row
         // waves via LDS: the partial-sum buffer is always indexed by 128-row tiles (rpe_conv_stats_tiles)
 #pragma unroll
@@ -850,6 +853,7 @@ template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST = 3> stati
     if (nwg <= 0 || nwg > 0x7fffffffL) return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: bad grid");
     if (a.role == 1) return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 1>(a, s, nwg);
     if (a.role == 2) return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 2>(a, s, nwg);
+    if (a.role == 3) return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 3>(a, s, nwg);
     return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 0>(a, s, nwg);
 }
 
