@@ -829,7 +829,8 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
 extern thread_local char g_last_kernel[96];
 
 template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE> static int launch_nt_role(NTArgs<T>& a, hipStream_t s, long nwg) {
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "nt_kernel<%s,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", WAVES_M, BN, KCH, MODE, NST, ROLE);
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "nt_kernel<%s,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", WAVES_M, BN, KCH, MODE, NST, ROLE,
+             ROLE == 1 ? a.bn_mode : 0);
     const dim3 grid((unsigned)nwg), block(128 * WAVES_M);
     if (ROLE == 1) {
         switch (a.bn_mode) {

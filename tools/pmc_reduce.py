@@ -48,10 +48,7 @@ def symbol(name):
     if base in ("nt_kernel", "tn_kernel"):
         targs = targs.replace("__hip_bfloat16", "bf16").replace("__bf16", "bf16").replace("float", "f32").replace(" ", "").replace("true", "1").replace("false", "0")
         targs = re.sub(r"\(rpe::[A-Za-z]+\)", "", targs)
-        parts = targs[1:-1].split(",")
-        if base == "nt_kernel" and len(parts) == 8:
-            parts = parts[:7]   # the epilogue-prefetch flag is not part of the name bench.py reports
-        return base + "<" + ",".join(parts) + ">"
+        return base + "<" + targs[1:-1] + ">"
     return base
 
 
