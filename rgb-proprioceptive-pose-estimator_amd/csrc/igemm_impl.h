@@ -77,6 +77,9 @@ __device__ __forceinline__ u32x4 stem_chunk(const T* x, long img_base, int hb, i
     return v;
 }
 
+struct TagFirst { static constexpr bool value = true; };   // first K step of a tile: accumulators start from zero
+struct TagNext { static constexpr bool value = false; };
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // -----------------------------------------------------------------------------------------------
@@ -331,14 +334,11 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
         for (int t = 0; t < DEPTH; ++t) issue(t);
     }
 
-    f32x4 acc[FN][FM];
-#pragma unroll
-    for (int a = 0; a < FN; ++a)
-#pragma unroll
-        for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[FN][FM];   // started by the first K step's MFMAs from an inline-constant zero (no 64-register clear per tile)
 
     const int fr = lane & 15, fc = lane >> 4;
-    auto compute = [&](int st) {
+    auto compute = [&](int st, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         const u32x4* base = lds + st * STAGE;
 #pragma unroll
         for (int ks = 0; ks < KCH / 4; ++ks) {
@@ -350,9 +350,18 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
 #pragma unroll
             for (int a = 0; a < FN; ++a)
 #pragma unroll
-                for (int b = 0; b < FM; ++b) Mma<T>::run(wf[a], af[b], acc[a][b]);
+                for (int b = 0; b < FM; ++b) {
+                    if (FIRST && ks == 0) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    Mma<T>::run(wf[a], af[b], acc[a][b]);
+                }
         }
     };
+    if (nk <= 0) {   // (parity classes of a strided 1x1 data gradient have no tap at all: the tile is the epilogue's addend only)
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+            for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     if (DMA) {
         // 3-slot ring, tiles kt+1 and kt+2 in flight while tile kt is multiplied.  A tile is NI LDS-DMA instructions per
         // wave; vmcnt counts them in issue order, so "all but the newest NI landed" == tile kt+1 is complete.  The raw
@@ -372,29 +381,33 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
         }
         __builtin_amdgcn_s_barrier();
         int st = 0;
-        for (int kt = 0; kt < nk; ++kt) {
+        auto k_step = [&](int kt, auto first_tag) {
             const bool pre = kt + PF < nk;
             if (pre) { advance_k(); int s2 = st + PF; if (s2 >= NSTAGE) s2 -= NSTAGE; dma_tile(s2); }
-            compute(st);
+            compute(st, first_tag);
             // tile kt+1 must be complete; tiles kt+2 .. may still be in flight
             int newer = nk - 2 - kt;               // tiles issued after kt+1
             if (newer > PF - 1) newer = PF - 1;
             if (newer >= 4) wait_vmcnt<4 * NI>(); else if (newer == 3) wait_vmcnt<3 * NI>(); else if (newer == 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             if (++st == NSTAGE) st = 0;
-        }
+        };
+        if (nk > 0) k_step(0, TagFirst{});
+        for (int kt = 1; kt < nk; ++kt) k_step(kt, TagNext{});
     } else {
         load_tile();
         store_tile(0);
         __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
+        auto k_step = [&](int kt, auto first_tag) {
             const int cur = kt & 1;
             const bool more = kt + 1 < nk;
             if (more) { advance_k(); load_tile(); }
-            compute(cur);
+            compute(cur, first_tag);
             if (more) store_tile(cur ^ 1);
             __syncthreads();
-        }
+        };
+        if (nk > 0) k_step(0, TagFirst{});
+        for (int kt = 1; kt < nk; ++kt) k_step(kt, TagNext{});
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
@@ -498,32 +511,27 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
         }
     }
     if ((HAS_FWD_STATS || HAS_BN) && p.stats_part) {
-        // column partials: lanes with the same chunk differ in erow -> butterfly over the row bits, then pairs of 64-row
-        // waves via LDS: the partial-sum buffer is always indexed by 128-row tiles (rpe_conv_stats_tiles)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#pragma unroll
-            for (int o = CPW; o < 64; o <<= 1) { cs[j] += __shfl_xor(cs[j], o); cq[j] += __shfl_xor(cq[j], o); }
-        }
+        // column partials: every lane parks its 8 (sum, sum-of-products) pairs in LDS, then one thread per (128-row half,
+        // column, statistic) adds the 2 x RPP row groups in a fixed order (a shuffle butterfly cost 48 ds_bpermute + 48 adds
+        // per lane; these launches are instruction bound).  The partial-sum buffer is always indexed by 128-row tiles
+        // (rpe_conv_stats_tiles).
         __syncthreads();  // every wave is done reading its staging rows
-        float* red = (float*)lds;  // [WAVES_M][BN][2]
-        if (erow == 0) {
+        float* red = (float*)lds;  // [WAVES_M][RPP][BN][2]
+        {
+            float* dst = red + ((wave_m * RPP + erow) * BN + nl) * 2;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                red[(wave_m * BN + nl + j) * 2 + 0] = cs[j];
-                red[(wave_m * BN + nl + j) * 2 + 1] = cq[j];
-            }
+            for (int j = 0; j < 8; j += 2) *(f32x4*)(dst + 2 * j) = f32x4{cs[j], cq[j], cs[j + 1], cq[j + 1]};
         }
         __syncthreads();
-        for (int i = tid; i < (WAVES_M / 2) * BN; i += NTHR) {
-            const int h = i / BN, c = i - h * BN;
+        for (int i = tid; i < (WAVES_M / 2) * BN * 2; i += NTHR) {
+            const int h = i / (BN * 2), cw = i - h * (BN * 2), c = cw >> 1, which = cw & 1;
             long t128 = (long)tile_m * (WAVES_M / 2) + h;
             if (MODE == MODE_CONV && g.parity) t128 = (long)cls * ((g.rows_q + 127) / 128) + m0 / 128 + h;
             if (n0 + c < p.N && m0 + h * 128 < row_lim) {
-                const float s_ = red[((2 * h) * BN + c) * 2] + red[((2 * h + 1) * BN + c) * 2];
-                const float q_ = red[((2 * h) * BN + c) * 2 + 1] + red[((2 * h + 1) * BN + c) * 2 + 1];
-                p.stats_part[(t128 * 2 + 0) * p.N + n0 + c] = s_;
-                p.stats_part[(t128 * 2 + 1) * p.N + n0 + c] = q_;
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < 2 * RPP; ++k) t += red[(2 * h * RPP + k) * BN * 2 + cw];
+                p.stats_part[(t128 * 2 + which) * p.N + n0 + c] = t;
             }
         }
     }
