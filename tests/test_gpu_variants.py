@@ -31,3 +31,23 @@ def test_kernel_variant_parity(env):
     tail = (r.stdout or "")[-3000:] + (r.stderr or "")[-1000:]
     assert r.returncode == 0, "variant %r failed:\n%s" % (env, tail)
     assert " passed" in r.stdout
+
+
+# schedule / fusion switches of the trunk engine: one golden train step per model family must still match the reference
+ENGINE_VARIANTS = [
+    {"RPE_NO_OVERLAP": "1"},        # everything on one stream
+    {"RPE_NO_FWD_OVERLAP": "1"},    # projection-shortcut branch on the main stream
+    {"RPE_STEM_UNFUSED": "1"},      # dense early-feature gradient + separate pool / BN backward passes for the stem
+]
+
+
+@pytest.mark.parametrize("env", ENGINE_VARIANTS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_engine_variant_parity(env):
+    child_env = dict(os.environ)
+    child_env.update(env)
+    cmd = [sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_models.py"), "-q", "-x", "-p", "no:cacheprovider", "-k",
+           "test_model_fp32_matches_reference_and_oracle and (no or tdo_v2)"]
+    r = subprocess.run(cmd, env=child_env, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=900)
+    tail = (r.stdout or "")[-3000:] + (r.stderr or "")[-1000:]
+    assert r.returncode == 0, "variant %r failed:\n%s" % (env, tail)
+    assert " passed" in r.stdout
