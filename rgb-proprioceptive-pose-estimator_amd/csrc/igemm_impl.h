@@ -421,7 +421,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
         cs[j] = 0.f; cq[j] = 0.f; cmean[j] = 0.f; cinv[j] = 0.f; csc[j] = 0.f; csh[j] = 0.f; cbias[j] = 0.f;
         if (n + j < p.N) {
             if (e_bias) cbias[j] = e_bias[n + j];
-            if (bn_mode) { cmean[j] = p.bn_mean[n + j]; cinv[j] = p.bn_invstd[n + j]; }
+            if (bn_mode) { cinv[j] = p.bn_invstd[n + j]; cmean[j] = -p.bn_mean[n + j] * cinv[j]; }   // xhat = y*inv + (-mean*inv): one fma
             if (bn_mode == 2) { csc[j] = p.bn_scale[n + j]; csh[j] = p.bn_shift[n + j]; }
         }
     }
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
                         const bool on = bn_mode == 1 ? (aa[j] > 0.f) : (bn_mode == 2 ? (fmaf(yy[j], csc[j], csh[j]) > 0.f) : true);
                         const float dz = on ? v[j] : 0.f;
                         cs[j] += dz;
-                        cq[j] += dz * (yy[j] - cmean[j]) * cinv[j];
+                        cq[j] = fmaf(dz, fmaf(yy[j], cinv[j], cmean[j]), cq[j]);
                         v[j] = dz;
                     }
                 }
