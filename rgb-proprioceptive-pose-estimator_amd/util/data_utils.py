@@ -96,3 +96,76 @@ class SyntheticEpisodeDataset(Dataset):
         x1 = tm(d["true_other"]) if self.is_two_arm else None
         obj = tm(d["true_obj"]) if self.obj_name is not None else None
         return img, depth, tm(d["measurement_self"]), tm(d["true_self"]), x1, obj
+
+
+class FramePrefetcher:
+    """Host -> device staging of raw simulator frames, double buffered.
+
+    replaces: the per-tensor synchronous pageable `.cuda()` of util/learn_utils.py:130-138 fed by the CPU transform
+    (util/data_utils.py:48-54).  `batches` yields tuples of CPU tensors; uint8 frame tensors stay uint8 -- 50 MB instead of
+    154 MB of fp32 per 256 frames -- and are cropped / normalised on the device by the trunk (`rpe_stage_frames_u8`).  Every
+    tensor goes through a pinned staging buffer and an asynchronous copy on a side stream into one of `depth` device slots;
+    the consumer's stream waits for that copy only, so batch k+1 crosses PCIe while batch k trains.
+
+        for frames, x0bar, target in FramePrefetcher(loader, device):
+            loss = criterion(model(frames, None, x0bar), target)
+    """
+
+    def __init__(self, batches, device="cuda", depth=2):
+        self.batches, self.device, self.depth = batches, torch.device(device), max(2, int(depth))
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._pinned = [None] * self.depth   # per slot: list of pinned host buffers
+        self._dev = [None] * self.depth      # per slot: list of device buffers
+        self._ready = [None] * self.depth    # per slot: copy-finished event
+        self._free = [None] * self.depth     # per slot: consumer-finished event (the slot may be overwritten after it)
+
+    def _stage(self, slot, batch):
+        items = list(batch) if isinstance(batch, (tuple, list)) else [batch]
+        if self._dev[slot] is None or len(self._dev[slot]) != len(items) or any(
+                (d is None) != (t is None) or (t is not None and (d.shape != t.shape or d.dtype != t.dtype or
+                                                                   ((self._pinned[slot][i] is None) != t.is_pinned())))
+                for i, (d, t) in enumerate(zip(self._dev[slot], items))):
+            self._pinned[slot] = [None if (t is None or t.is_pinned()) else torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in items]
+            self._dev[slot] = [None if t is None else torch.empty(t.shape, dtype=t.dtype, device=self.device) for t in items]
+        if self._free[slot] is not None:
+            self.stream.wait_event(self._free[slot])      # the previous consumer of this slot is done with it
+        src = []
+        for p, t in zip(self._pinned[slot], items):
+            if t is None or t.is_pinned():
+                src.append(t)                               # already page-locked (DataLoader(pin_memory=True)): DMA straight from it
+            else:
+                p.copy_(t)                                  # host memcpy into the pinned buffer (on the caller's thread: keep
+                src.append(p)                               # loaders pinning, or this copy is what the GPU waits for)
+        self._src_keep = getattr(self, "_src_keep", [None] * self.depth)
+        self._src_keep[slot] = src                          # sources stay alive until the slot is staged again
+        with torch.cuda.stream(self.stream):
+            for d, p in zip(self._dev[slot], src):
+                if p is not None:
+                    d.copy_(p, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._ready[slot] = ev
+
+    def __iter__(self):
+        it = iter(self.batches)
+        slot, pending = 0, []
+        try:
+            for _ in range(self.depth - 1):
+                self._stage(slot, next(it))
+                pending.append(slot)
+                slot = (slot + 1) % self.depth
+        except StopIteration:
+            pass
+        while pending:
+            cur = pending.pop(0)
+            try:
+                self._stage(slot, next(it))
+                pending.append(slot)
+                slot = (slot + 1) % self.depth
+            except StopIteration:
+                pass
+            torch.cuda.current_stream(self.device).wait_event(self._ready[cur])
+            yield tuple(self._dev[cur])
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self.device))
+            self._free[cur] = done
