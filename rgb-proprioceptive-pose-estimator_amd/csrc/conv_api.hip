@@ -132,7 +132,7 @@ static int stem_fwd_t(const void* x4, const void* w, void* y, float* stats, cons
     memset(&a, 0, sizeof(a));
     stem_gather(a.g, H, W);
     a.A = (const T*)x4; a.Bw = (const T*)w; a.C = (T*)y;
-    a.M = B * a.g.Ho * a.g.Wo; a.N = 64; a.K = 256;
+    a.M = B * a.g.Ho * a.g.Wo; a.N = 64; a.K = 224;   // 7 real kernel rows x (8 taps x 4 channels); the 8th, all-zero row of the packed weight is skipped
     a.lda = 4; a.ldb = 256; a.ldc = 64;
     a.stats_part = stats;
     a.bias = bias; a.relu = relu;
@@ -146,7 +146,7 @@ static int stem_wgrad_t(const void* x4, const void* dy, float* dw_packed, int B,
     memset(&a, 0, sizeof(a));
     stem_gather(a.g, H, W);
     a.P = (const T*)dy; a.Q = (const T*)x4; a.D = dw_packed;
-    a.M = B * a.g.Ho * a.g.Wo; a.I = 64; a.J = 256;
+    a.M = B * a.g.Ho * a.g.Wo; a.I = 64; a.J = 224;   // (the 8th kernel row of the packed layout stays zero)
     a.ldp = 64; a.ldq = 4; a.ldd = 256;
     return launch_tn<T>(a, MODE_STEM, s);
 }
