@@ -1,16 +1,17 @@
-// MFMA implicit-GEMM kernels for gfx950 (CDNA4, wave64).
+// MFMA implicit-GEMM kernels for gfx950 (CDNA4, wave64): templates + configuration choice.  Instantiated per element type and
+// staging mode in igemm_nt_*.hip / igemm_tn_*.hip (parallel translation units); argument checks and dispatch in igemm.hip.
 //
-//   nt_kernel : C[M][N] = gather(A)[M][K] * W[N][K]^T  (+bias, +addend, relu, BN partial stats)
+//   nt_kernel : C[M][N] = gather(A)[M][K] * W[N][K]^T  (+bias, +addend, relu, BN partial stats, fused BN backward)
 //               conv forward, conv data-gradient, Linear forward / data-gradient.
 //   tn_kernel : D[I][J] += sum_m P[m][I] * gather(Q)[m][J]   (fp32 atomics)
 //               conv weight-gradient, Linear weight-gradient.
 //
 // Layout: activations NHWC (channels contiguous), weights [N][K] with K = (r, s, c) contiguous.
-// Both operands are staged global -> registers -> LDS in 16-byte chunks (4 chunks = one
-// MFMA K-step per row: 32 bf16 or 16 f32), double buffered, one barrier per K-step.
-// The weight tile is the MFMA "A" operand and the activation tile the "B" operand, so the
-// accumulator registers of a lane run along N (channels): the epilogue stores 4 consecutive
-// channels per lane straight to NHWC memory (8 B bf16 / 16 B f32) without an LDS transpose.
+// Operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds through raw buffer descriptors: 32-bit lane offsets, the
+// hardware range check supplies the zeros of padding taps and tails) into a 2..3-slot ring, one raw s_barrier per K step;
+// only the 7x7 stem (two 8-byte pixels per chunk with separate bounds) stages through registers.
+// The weight tile is the MFMA "A" operand and the activation tile the "B" operand, so the accumulator registers of a lane run
+// along N (channels); the epilogue passes them once through LDS so that every lane owns 8 consecutive channels of one row.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -51,9 +52,6 @@ template <> struct Mma<float> {
     }
 };
 
-// 16 bytes of zeros in device memory: the LDS-DMA source for padding taps and tile tails
-__device__ __attribute__((aligned(16))) const unsigned rpe_zero16[4] = {0u, 0u, 0u, 0u};
-
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *(const u32x4*)p; }
 __device__ __forceinline__ u32x4 zero16() { u32x4 z = {0u, 0u, 0u, 0u}; return z; }
 
@@ -84,11 +82,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 // -----------------------------------------------------------------------------------------------
 // NT kernel.  Tile BM x BN = (64*WAVES_M) x BN, 2*WAVES_M waves of 64 x (BN/2), K-step = KCH 16-byte chunks per row.
-//   small config  <2, 128|64, 4>: 128-row tile, 64-B rows   (heads, stem, tiny problems)
-//   large config  <4, 128|64, 8>: 256-row tile, 128-B rows  (conv trunk): 2x the FLOPs per byte pulled from L2 into LDS
-//   and every DMA instruction moves whole 128-B lines -- at 128x128x32 the kernel sat at ~16 B/clk/CU of L2->LDS traffic.
+//   <2, 128|64, 4, ., 3>: 128-row tile, 64-B K rows, 3-slot ring  (K < 1024, stem)
+//   <2, 128|64, 8, ., 2>: 128-row tile, 128-B K rows, 2-slot ring (K >= 1024: half the barriers per FLOP)
+//   <1, 64, 4, ., 3>    : 64x64 tile, 2 waves                     (few-row Linear layers)
+//   <4, 128|64, 8, ., 3>: 256-row tile, 8 waves                   (experiment, RPE_NT_BIG)
 // -----------------------------------------------------------------------------------------------
-// ROLE only tells the symbols apart in profiles: 0 conv forward, 1 conv data-gradient, 2 Linear.
+// ROLE selects the epilogue compiled into the kernel (see the epilogue): 0 conv forward in training, 1 conv data gradient,
+// 2 Linear, 3 conv forward in inference.
 // BNM: the data gradient's fused BN-backward mode (NTArgs::bn_mode), a template parameter so that each launch carries one
 // epilogue variant only (role 1; 0 elsewhere).
 // (second launch-bound = minimum waves per SIMD: with the mode a constant hipcc hoisted the epilogue loads of mode 2 into 252
@@ -136,10 +136,10 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
         const unsigned ww = rem - hh * g.div_w.d;
         return ((long)b * (2 * g.Ho) + (2 * hh + ph)) * (2 * g.Wo) + (2 * ww + pw);
     };
-    // Staging.  DMA path (dense / conv): global_load_lds_dwordx4 writes 64 lanes x 16 B = RPI rows x KCH slots straight
+    // Staging.  DMA path (dense / conv): one buffer_load_dwordx4 ... lds writes 64 lanes x 16 B = RPI rows x KCH slots straight
     // into LDS (no VGPR round trip, no ds_write).  The LDS image is lane-linear, so the slot swizzle is applied on the
-    // SOURCE side: the lane that fills slot s of row r fetches logical chunk s ^ f(r).  Padding taps / tails fetch from a
-    // 16-byte zero page.  Stem path (two 8-byte pixels per chunk with separate bounds) keeps register staging.
+    // SOURCE side: the lane that fills slot s of row r fetches logical chunk s ^ f(r).  Padding taps / tails use an offset
+    // beyond the descriptor's range.  Stem path (two 8-byte pixels per chunk with separate bounds) keeps register staging.
     int a_row[AR], a_chunk[AR], b_row[BR], b_chunk[BR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
