@@ -26,8 +26,9 @@ class FusedAdam(torch.optim.Optimizer):
                                "(or call model._materialize) before the first step")
         if arena is not self._arena:
             self._arena = arena
-            self._m = torch.zeros_like(arena.flat)
-            self._v = torch.zeros_like(arena.flat)
+            loaded = self._m is not None and self._m.numel() == arena.flat.numel()   # moments restored by load_state_dict
+            self._m = self._m.to(arena.flat.device) if loaded else torch.zeros_like(arena.flat)
+            self._v = self._v.to(arena.flat.device) if loaded else torch.zeros_like(arena.flat)
         return arena
 
     def zero_grad(self, set_to_none=True):
@@ -46,8 +47,14 @@ class FusedAdam(torch.optim.Optimizer):
         return None
 
     def state_dict(self):
+        """Flat first / second moments in arena order (= model.parameters() order, 16-byte padded segments) + the step count.
+        The reference saves no optimizer state (util/learn_utils.py:211-241); this is what a resumable checkpoint adds."""
         return {"step": self._step, "m": self._m, "v": self._v, "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
-        self._step = sd["step"]
-        self._m, self._v = sd["m"], sd["v"]
+        self._step = int(sd["step"])
+        self._m = None if sd["m"] is None else sd["m"].clone()
+        self._v = None if sd["v"] is None else sd["v"].clone()
+        self._arena = None   # re-attached (and the moments moved to its device) at the next step
+        for g, sg in zip(self.param_groups, sd.get("param_groups", [])):
+            g.update({k: v for k, v in sg.items() if k != "params"})

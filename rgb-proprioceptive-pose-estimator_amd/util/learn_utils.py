@@ -58,8 +58,10 @@ def train_step(model, batch, criterion, optimizer, train_obj_pose, phase="train"
 
 
 def train(model, dataset, criterion, optimizer, num_epochs, num_train_episodes_per_epoch, num_val_episodes_per_epoch, params, device,
-          save_path='default', save_model=True, logging=True):
-    """See the module docstring.  Returns (model with the best validation weights, best validation loss)."""
+          save_path='default', save_model=True, logging=True, *, save_optimizer=False):
+    """See the module docstring.  Returns (model with the best validation weights, best validation loss).
+    save_optimizer (addition; the reference saves weights only): also write `<save_path>.optim` with the optimizer state of the
+    best-validation epoch so that a run can be resumed (`optimizer.load_state_dict(torch.load(path))`)."""
     train_obj_pose = hasattr(model, "object_name")
     dt_string = datetime.now().strftime("%d-%m-%Y_%H-%M-%S")
     since = time.time()
@@ -125,6 +127,8 @@ def train(model, dataset, criterion, optimizer, num_epochs, num_train_episodes_p
                         save_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "log", "runs", fname)
                     os.makedirs(os.path.dirname(os.path.abspath(save_path)), exist_ok=True)
                     torch.save(model.state_dict(), save_path)
+                    if save_optimizer:
+                        torch.save(optimizer.state_dict(), save_path + ".optim")
     if logging and rank == 0:
         time_elapsed = time.time() - since
         print('-' * 10)
