@@ -75,12 +75,14 @@ int rpe_conv2d_dgrad(const rpe_conv_desc* d, int dtype, const void* dy, const vo
 /* Data gradient with the BatchNorm-backward reduction of the PRODUCING layer fused into the epilogue:
  * dz[B][H][W][in_c] = (conv_transpose(dy, w) + addend) * [ReLU mask of that layer's output], and per-128-row-tile partial
  * sums (sum dz, sum dz*xhat) -> bn->stats_part [tiles][2][in_c], consumed by rpe_bn_backward_from_dz.
- * mask: a_out != NULL: a_out > 0;  else scale/shift != NULL: y*scale+shift > 0 (BN+ReLU without residual);  else none. */
+ * mask: a_mask != NULL: its bits;  else a_out != NULL: a_out > 0;  else scale/shift != NULL: y*scale+shift > 0 (BN+ReLU
+ * without residual);  else none. */
 typedef struct {
     const void* y;       /* raw conv output the BN normalised, same shape as dz */
     const void* a_out;   /* BN(+residual)+ReLU output, or NULL */
     const float *mean, *invstd, *scale, *shift;
     float* stats_part;
+    const unsigned char* a_mask; /* or: the packed ReLU mask rpe_bn_apply_mask wrote, [rows][in_c/8] bytes (bit j = channel 8k+j > 0) */
 } rpe_bn_bwd_epilogue;
 /* rows of bn->stats_part the fused data gradient writes (stride-2 layers enumerate rows per parity class) */
 long rpe_conv2d_dgrad_stats_tiles(const rpe_conv_desc* d);
@@ -140,6 +142,10 @@ int rpe_bn_eval_affine(int C, const float* gamma, const float* beta, const float
 /* out = relu?(y*scale + shift (+ residual)) */
 int rpe_bn_apply(int dtype, const void* y, const void* residual, void* out, const float* scale, const float* shift, long rows, int C,
                  int relu, void* stream);
+/* the same, also writing the ReLU mask as one byte per 8 channels ([rows][C/8], bit j = out[8k+j] > 0): the backward reads it
+ * (1/16 of the bytes of `out`) instead of `out` to mask the gradient (rpe_bn_bwd_epilogue.a_mask).  C % 8 == 0. */
+int rpe_bn_apply_mask(int dtype, const void* y, const void* residual, void* out, const float* scale, const float* shift, long rows, int C,
+                      unsigned char* relu_mask, void* stream);
 /* dz = dA * (a_out > 0) (a_out null: no ReLU); dgamma, dbeta; dy = BN backward of dz; dz_out (nullable) = dz.
  * part: >= 2*1024*C floats of scratch; c1c2: 2*C floats of scratch; dpart: as for rpe_bn_finalize. */
 int rpe_bn_backward(int dtype, const void* dA, const void* a_out, const void* y, const float* mean, const float* invstd,

@@ -24,7 +24,7 @@ class RpeError(RuntimeError):
 
 
 class BnBwdEpilogue(Structure):
-    _fields_ = [(n, c_void_p) for n in ("y", "a_out", "mean", "invstd", "scale", "shift", "stats_part")]
+    _fields_ = [(n, c_void_p) for n in ("y", "a_out", "mean", "invstd", "scale", "shift", "stats_part", "a_mask")]
 
 
 class ConvDesc(Structure):
@@ -59,6 +59,7 @@ _SPEC = {
     "rpe_bn_finalize": (I, [P, I, I, L, P, P, P, P, P, F, F, P, P, P, P, P, P]),
     "rpe_bn_eval_affine": (I, [I, P, P, P, P, F, P, P, P]),
     "rpe_bn_apply": (I, [I, P, P, P, P, P, L, I, I, P]),
+    "rpe_bn_apply_mask": (I, [I, P, P, P, P, P, L, I, P, P]),
     "rpe_bn_backward": (I, [I, P, P, P, P, P, P, P, P, P, P, L, I, P, L, P, P, P]),
     "rpe_maxpool3x3s2_fwd": (I, [I, P, P, P, I, I, I, I, P]),
     "rpe_maxpool3x3s2_bwd": (I, [I, P, P, P, P, I, I, I, I, P]),

@@ -78,8 +78,9 @@ static int conv_dgrad_t(const rpe_conv_desc* d, const void* dy, const void* w_cr
     a.role = 1;
     if (bn) {
         if (!bn->y || !bn->mean || !bn->invstd || !bn->stats_part) return rpe_set_error(RPE_ERR_SHAPE, "conv2d_dgrad_bn: y, mean, invstd, stats_part are required");
-        a.bn_mode = bn->a_out ? 1 : (bn->scale && bn->shift ? 2 : 3);
-        a.bn_y = (const T*)bn->y; a.bn_a = (const T*)bn->a_out;
+        a.bn_mode = bn->a_mask ? 4 : bn->a_out ? 1 : (bn->scale && bn->shift ? 2 : 3);
+        if (bn->a_mask && (d->in_c % 8)) return rpe_set_error(RPE_ERR_SHAPE, "conv2d_dgrad_bn: a_mask needs in_c % 8 == 0");
+        a.bn_y = (const T*)bn->y; a.bn_a = (const T*)bn->a_out; a.bn_mask = bn->a_mask;
         a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bn_scale = bn->scale; a.bn_shift = bn->shift;
         a.stats_part = bn->stats_part;
     }

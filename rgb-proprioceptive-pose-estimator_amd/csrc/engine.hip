@@ -37,6 +37,7 @@ struct ConvL {
 struct Block {
     int c1, c2, c3, cd;  // conv indices (cd = -1: identity shortcut)
     void* dz = nullptr;  // backward: ReLU-masked gradient at the block output (kept as the shortcut gradient)
+    unsigned char* relu_mask = nullptr;  // bf16: packed ReLU mask of the block output (1 bit per element), written by its bn_apply
 };
 
 struct Named {
@@ -235,7 +236,11 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
     want(e, (void**)&e->fc_wt, 2048L * e->latent_pad * 4);
     want(e, &e->early_grad, st.rows * 64 * es);
     for (int i = 0; i < 2; ++i) want(e, &e->G[i], max_act * es);
-    for (auto& b : e->blocks) { const ConvL& c3 = e->convs[b.c3]; want(e, &b.dz, c3.rows * c3.d.out_c * es); }
+    for (auto& b : e->blocks) {
+        const ConvL& c3 = e->convs[b.c3];
+        want(e, &b.dz, c3.rows * c3.d.out_c * es);
+        if (dtype == RPE_BF16) want(e, (void**)&b.relu_mask, c3.rows * c3.d.out_c / 8);
+    }
     want(e, &e->d_pool, (long)batch * (e->convs[0].Ho / 2) * (e->convs[0].Wo / 2) * 64 * es);
     want(e, (void**)&e->stats_part, e->stats_floats * 4);
     want(e, (void**)&e->stats_part2, e->stats_floats * 4);
@@ -464,7 +469,8 @@ static int ensure_side(rpe_resnet50* e) {
     return 0;
 }
 
-static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residual, int relu, void* stream, bool second_set = false) {
+static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residual, int relu, void* stream, bool second_set = false,
+                   unsigned char* relu_mask = nullptr) {
     const bool train = e->train_mode != 0;
     float* stats = second_set ? e->stats_part2 : e->stats_part;
     double* dpart = second_set ? e->dpart2 : e->dpart;
@@ -482,7 +488,8 @@ static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residua
     float* rv = e->running[2 * c.bn_i + 1];
     PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_finalize(stats, (int)rpe_conv_stats_tiles(c.rows), c.d.out_c, c.rows, e->params[c.p_g], e->params[c.p_b], rm, rv,
                         e->nbt[c.bn_i], 0.1f, 1e-5f, c.scale, c.shift, c.mean, c.invstd, dpart, stream));
-    PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_apply(e->dtype, c.y, residual, c.a, c.scale, c.shift, c.rows, c.d.out_c, relu, stream));
+    if (relu_mask && relu) PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_apply_mask(e->dtype, c.y, residual, c.a, c.scale, c.shift, c.rows, c.d.out_c, relu_mask, stream));
+    else PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_apply(e->dtype, c.y, residual, c.a, c.scale, c.shift, c.rows, c.d.out_c, relu, stream));
     return 0;
 }
 
@@ -522,7 +529,8 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
         TRY(conv_bn(e, c2, c1.a, nullptr, 1, stream));
         if (b.cd >= 0 && !ds_done) { ConvL& cd = e->convs[b.cd]; TRY(conv_bn(e, cd, x, nullptr, 0, stream)); idn = cd.a; }
         if (ds_done) HIPTRY(hipStreamWaitEvent((hipStream_t)stream, ds_done, 0));
-        TRY(conv_bn(e, c3, c2.a, idn, 1, stream));
+        static const bool use_mask = getenv("RPE_NO_RELU_MASK") == nullptr;
+        TRY(conv_bn(e, c3, c2.a, idn, 1, stream, false, use_mask ? b.relu_mask : nullptr));   // (relu_mask is null for fp32 engines)
         x = c3.a;
     }
     ConvL& last = e->convs[e->blocks.back().c3];
@@ -556,17 +564,19 @@ static int bn_back(rpe_resnet50* e, ConvL& c, const void* dA, int relu, void* dy
 
 // data gradient of conv `c` with the BN-backward reduction of layer `bnl` (the layer producing c's input) fused in.
 // mask_mode 1: ReLU mask from bnl.a (residual block output); 2: mask recomputed from bnl.y, scale, shift.
-static int dgrad_fused(rpe_resnet50* e, ConvL& c, const void* dy, void* dz, const void* addend, ConvL* bnl, int mask_mode, void* stream) {
+static int dgrad_fused(rpe_resnet50* e, ConvL& c, const void* dy, void* dz, const void* addend, ConvL* bnl, int mask_mode, void* stream,
+                       const unsigned char* relu_mask = nullptr) {
     rpe_bn_bwd_epilogue ep;
     ep.y = bnl->y;
-    ep.a_out = mask_mode == 1 ? bnl->a : nullptr;
+    ep.a_mask = mask_mode == 1 ? relu_mask : nullptr;   // block outputs: 1 bit per element instead of re-reading a_out
+    ep.a_out = (mask_mode == 1 && !ep.a_mask) ? bnl->a : nullptr;
     ep.mean = bnl->mean; ep.invstd = bnl->invstd;
     ep.scale = mask_mode == 2 ? bnl->scale : nullptr;
     ep.shift = mask_mode == 2 ? bnl->shift : nullptr;
     ep.stats_part = e->stats_part;
     e->pending_flops = conv_flops(c);
     // reads dy; writes dz; the fused epilogue also reads y (and a_out for residual outputs) and the shortcut addend
-    e->pending_bytes = conv_out_bytes(e, c) + conv_in_bytes(e, c) * (2.0 + (mask_mode == 1 ? 1.0 : 0.0) + (addend ? 1.0 : 0.0));
+    e->pending_bytes = conv_out_bytes(e, c) + conv_in_bytes(e, c) * (2.0 + (mask_mode == 1 ? (ep.a_mask ? 1.0 / 16 : 1.0) : 0.0) + (addend ? 1.0 : 0.0));
     e->fused_tiles = (int)rpe_conv2d_dgrad_stats_tiles(&c.d);  // partial-sum rows this launch leaves behind
     PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad_bn(&c.d, e->dtype, dy, c.wd, dz, addend, &ep, stream));
     return 0;
@@ -672,7 +682,9 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
             shortcut = e->G[0];
         }
         if (bi > 0) {
-            TRY(dgrad_fused(e, c1, c1.dy, gD, shortcut, &e->convs[e->blocks[bi - 1].c3], 1, stream));  // dz3 of the previous block
+            static const bool use_mask = getenv("RPE_NO_RELU_MASK") == nullptr;
+            TRY(dgrad_fused(e, c1, c1.dy, gD, shortcut, &e->convs[e->blocks[bi - 1].c3], 1, stream,
+                            use_mask ? e->blocks[bi - 1].relu_mask : nullptr));  // dz3 of the previous block
         } else {
             PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&c1.d, e->dtype, c1.dy, c1.wd, gD, shortcut, stream));
         }

@@ -43,7 +43,8 @@ template <typename T> struct NTArgs {
                          //   bn_mode == 0: (sum acc, sum acc^2)  -> forward batch statistics
                          //   bn_mode != 0: (sum dz, sum dz*xhat) -> fused BatchNorm-backward reduction
     // fused BN backward on the data-gradient output: C = dz = (acc + addend) * [relu mask]
-    int bn_mode;         // 0 off; 1 mask = bn_a > 0; 2 mask = bn_y*bn_scale + bn_shift > 0; 3 no mask
+    int bn_mode;         // 0 off; 1 mask = bn_a > 0; 2 mask = bn_y*bn_scale + bn_shift > 0; 3 no mask; 4 mask = bits of bn_mask
+    const unsigned char* bn_mask;   // [M][ldc/8] bytes (mode 4)
     const T* bn_y;       // raw conv output the BN normalised, [M][ldc]
     const T* bn_a;       // BN(+residual)+ReLU output, [M][ldc] (mode 1)
     const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;

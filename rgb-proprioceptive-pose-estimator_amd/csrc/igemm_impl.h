@@ -327,6 +327,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
         if (bn_mode && vec_c) {
             qy[sl] = ld16(p.bn_y + m * p.ldc + n);
             if (bn_mode == 1) qa[sl] = ld16(p.bn_a + m * p.ldc + n);
+            if (bn_mode == 4) qa[sl].x = p.bn_mask[(m * p.ldc + n) >> 3];   // one byte: the ReLU bits of this lane's 8 channels
         }
     };
     if (PIPE) {
@@ -478,16 +479,21 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
                 if (bn_mode) {
                     // v = dA (gradient wrt the BN output after ReLU).  dz = dA * [a_out > 0]; partial sums of dz and dz*xhat.
                     float yy[8], aa[8];
+                    unsigned mbits = 0;
                     if (PIPE && vec_c) {
                         chunk_to_f<T>(qy[sl], yy);
                         if (bn_mode == 1) chunk_to_f<T>(qa[sl], aa);
+                        if (bn_mode == 4) mbits = qa[sl].x;
                     } else {
                         load8(p.bn_y, m * p.ldc + n, vec_c, yy);
                         if (bn_mode == 1) load8(p.bn_a, m * p.ldc + n, vec_c, aa);
+                        if (bn_mode == 4) mbits = p.bn_mask[(m * p.ldc + n) >> 3];
                     }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const bool on = bn_mode == 1 ? (aa[j] > 0.f) : (bn_mode == 2 ? (fmaf(yy[j], csc[j], csh[j]) > 0.f) : true);
+                        const bool on = bn_mode == 1 ? (aa[j] > 0.f)
+                                        : bn_mode == 2 ? (fmaf(yy[j], csc[j], csh[j]) > 0.f)
+                                        : bn_mode == 4 ? ((mbits >> j) & 1u) != 0 : true;
                         const float dz = on ? v[j] : 0.f;
                         cs[j] += dz;
                         cq[j] = fmaf(dz, fmaf(yy[j], cinv[j], cmean[j]), cq[j]);
@@ -845,6 +851,7 @@ template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE>
             case 1: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 1 : 0>), grid, block, 0, s, a); break;
             case 2: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 2 : 0>), grid, block, 0, s, a); break;
             case 3: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 3 : 0>), grid, block, 0, s, a); break;
+            case 4: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 4 : 0>), grid, block, 0, s, a); break;
             default: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, 0>), grid, block, 0, s, a); break;
         }
     } else {

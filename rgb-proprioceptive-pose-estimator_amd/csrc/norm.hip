@@ -152,7 +152,7 @@ template <bool NT> __device__ inline void st16(void* p, const u32x4& v) {
 template <typename T, int UNR, bool NT>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ out,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
-                                                      long nchunks, int C, int relu) {
+                                                      long nchunks, int C, int relu, unsigned char* __restrict__ mask) {
     constexpr int CE = Elem<T>::kChunk;
     const int cpr = C / CE;
     const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -178,13 +178,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
             float v[CE], r[CE];
             chunk_to_f<T>(vy[u], v);
             if (res) chunk_to_f<T>(vr[u], r);
+            unsigned bits = 0;
 #pragma unroll
             for (int e = 0; e < CE; ++e) {
                 float t = fmaf(v[e], sc[e], sh[e]);  // same expression as the fused dgrad epilogue's mask
                 if (res) t += r[e];
                 v[e] = relu ? fmaxf(t, 0.f) : t;
+                bits |= (t > 0.f ? 1u : 0u) << e;
             }
             *(u32x4*)(out + j * CE) = f_to_chunk<T>(v);
+            if (CE == 8 && mask) mask[j] = (unsigned char)bits;   // one byte per 8-channel chunk (16-bit element types only)
         }
     }
 }
@@ -656,7 +659,8 @@ static int reduce_finalize(const float* part, int tiles, int C, double* dpart, c
 }
 
 template <typename T>
-int bn_apply_launch(const void* y, const void* res, void* out, const float* scale, const float* shift, long M, int C, int relu, hipStream_t s) {
+int bn_apply_launch(const void* y, const void* res, void* out, const float* scale, const float* shift, long M, int C, int relu, unsigned char* mask,
+                    hipStream_t s) {
     constexpr int CE = Elem<T>::kChunk;
     if (C % CE) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply: C must be a multiple of the 16-byte chunk");
     const long n = M * C / CE;
@@ -664,7 +668,8 @@ int bn_apply_launch(const void* y, const void* res, void* out, const float* scal
     const EwCfg cfg = ew_cfg();
     const long g = ew_grid_rows(n, cpr, cfg);
     if ((g * 256) % cpr) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply: C/chunk must divide grid*256 (power-of-two channel counts)");
-#define RPE_BN_APPLY(U, N) hipLaunchKernelGGL((bn_apply_kernel<T, U, N>), dim3((unsigned)g), dim3(256), 0, s, (const T*)y, (const T*)res, (T*)out, scale, shift, n, C, relu)
+    if (mask && sizeof(T) != 2) return rpe_set_error(RPE_ERR_DTYPE, "bn_apply_mask: the packed ReLU mask is written for 16-bit element types only");
+#define RPE_BN_APPLY(U, N) hipLaunchKernelGGL((bn_apply_kernel<T, U, N>), dim3((unsigned)g), dim3(256), 0, s, (const T*)y, (const T*)res, (T*)out, scale, shift, n, C, relu, mask)
     if (cfg.nt) { if (cfg.unr == 1) RPE_BN_APPLY(1, true); else if (cfg.unr == 2) RPE_BN_APPLY(2, true); else RPE_BN_APPLY(4, true); }
     else { if (cfg.unr == 1) RPE_BN_APPLY(1, false); else if (cfg.unr == 2) RPE_BN_APPLY(2, false); else RPE_BN_APPLY(4, false); }
 #undef RPE_BN_APPLY
@@ -770,9 +775,16 @@ int rpe_bn_eval_affine(int C, const float* gamma, const float* beta, const float
 
 int rpe_bn_apply(int dtype, const void* y, const void* residual, void* out, const float* scale, const float* shift, long rows, int C,
                  int relu, void* stream) {
-    if (dtype == RPE_F32) return bn_apply_launch<float>(y, residual, out, scale, shift, rows, C, relu, (hipStream_t)stream);
-    if (dtype == RPE_BF16) return bn_apply_launch<bf16>(y, residual, out, scale, shift, rows, C, relu, (hipStream_t)stream);
+    if (dtype == RPE_F32) return bn_apply_launch<float>(y, residual, out, scale, shift, rows, C, relu, nullptr, (hipStream_t)stream);
+    if (dtype == RPE_BF16) return bn_apply_launch<bf16>(y, residual, out, scale, shift, rows, C, relu, nullptr, (hipStream_t)stream);
     return rpe_set_error(RPE_ERR_DTYPE, "bn_apply: unsupported dtype");
+}
+
+int rpe_bn_apply_mask(int dtype, const void* y, const void* residual, void* out, const float* scale, const float* shift, long rows, int C,
+                      unsigned char* relu_mask, void* stream) {
+    if (!relu_mask || (C % 8)) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply_mask: mask buffer and C % 8 == 0 required");
+    if (dtype == RPE_BF16) return bn_apply_launch<bf16>(y, residual, out, scale, shift, rows, C, 1, relu_mask, (hipStream_t)stream);
+    return rpe_set_error(RPE_ERR_DTYPE, "bn_apply_mask: bf16 only");
 }
 
 int rpe_bn_backward(int dtype, const void* dA, const void* a_out, const void* y, const float* mean, const float* invstd,

@@ -91,7 +91,7 @@ def conv2d_dgrad(dy, w_crsk, x_shape, stride, pad, addend=None):
     return dx
 
 
-def conv2d_dgrad_bn(dy, w_crsk, x_shape, stride, pad, y, mean, invstd, a_out=None, scale=None, shift=None, addend=None):
+def conv2d_dgrad_bn(dy, w_crsk, x_shape, stride, pad, y, mean, invstd, a_out=None, scale=None, shift=None, addend=None, a_mask=None):
     """Data gradient with the producing layer's ReLU mask and BN-backward partial sums fused into the epilogue.
     Returns (dz [B,H,W,Ci], stats partials [tiles,2,Ci])."""
     _chk(dy, "dy"), _chk(w_crsk, "w"), _chk(y, "y")
@@ -99,7 +99,7 @@ def conv2d_dgrad_bn(dy, w_crsk, x_shape, stride, pad, y, mean, invstd, a_out=Non
     d = conv_desc(x_shape, co, k, stride, pad)
     dz = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device)
     st = torch.empty((lib.rpe_conv2d_dgrad_stats_tiles(ctypes.byref(d)), 2, ci), dtype=torch.float32, device=dy.device)
-    ep = BnBwdEpilogue(*(None if t is None else t.data_ptr() for t in (y, a_out, mean, invstd, scale, shift, st)))
+    ep = BnBwdEpilogue(*(None if t is None else t.data_ptr() for t in (y, a_out, mean, invstd, scale, shift, st, a_mask)))
     lib.rpe_conv2d_dgrad_bn(ctypes.byref(d), dtype_code(dy), _p(dy), _p(w_crsk), _p(dz), _p(addend), ctypes.byref(ep), _stream())
     return dz, st
 
@@ -183,6 +183,15 @@ def bn_apply(y, scale, shift, residual=None, relu=True):
     c = y.shape[-1]
     lib.rpe_bn_apply(dtype_code(y), _p(_chk(y, "y")), _p(residual), _p(out), _p(scale), _p(shift), y.numel() // c, c, int(relu), _stream())
     return out
+
+
+def bn_apply_mask(y, scale, shift, residual=None):
+    """relu(y*scale + shift (+ residual)) and its packed ReLU mask (1 byte per 8 channels); 16-bit element types only."""
+    out = torch.empty_like(y)
+    c = y.shape[-1]
+    mask = torch.empty(y.numel() // 8, dtype=torch.uint8, device=y.device)
+    lib.rpe_bn_apply_mask(dtype_code(y), _p(_chk(y, "y")), _p(residual), _p(out), _p(scale), _p(shift), y.numel() // c, c, _p(mask), _stream())
+    return out, mask
 
 
 def bn_backward(dA, a_out, y, mean, invstd, gamma, want_dz=False):

@@ -143,7 +143,7 @@ def test_conv_wgrad(dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("mask_mode", [1, 2])
+@pytest.mark.parametrize("mask_mode", [1, 2, 4])
 @pytest.mark.parametrize("cfg", [(2, 14, 64, 64, 3, 1, 1), (2, 14, 256, 512, 1, 2, 0), (3, 8, 128, 256, 1, 1, 0), (8, 24, 128, 128, 3, 1, 1),
                                  (6, 30, 64, 1024, 1, 1, 0)])
 def test_dgrad_with_fused_bn_backward(dtype, mask_mode, cfg):
@@ -152,7 +152,9 @@ def test_dgrad_with_fused_bn_backward(dtype, mask_mode, cfg):
     g = torch.Generator().manual_seed(sum(cfg) + mask_mode)
     # the producing layer: y_prev -> BN (+res) -> ReLU = a_prev, which is this conv's input
     y_prev = q(torch.randn(b, ci, h, h, generator=g) * 1.5 + 0.3, dtype).requires_grad_(True)
-    res = q(torch.randn(b, ci, h, h, generator=g), dtype) if mask_mode == 1 else None
+    if mask_mode == 4 and dtype == torch.float32:
+        pytest.skip("the packed ReLU mask exists for 16-bit activations only")
+    res = q(torch.randn(b, ci, h, h, generator=g), dtype) if mask_mode in (1, 4) else None
     gamma = (0.5 + torch.rand(ci, generator=g)).requires_grad_(True)
     beta = (torch.rand(ci, generator=g) - 0.5).requires_grad_(True)
     z = F.batch_norm(y_prev, None, None, gamma, beta, True, 0.1, 1e-5)
@@ -171,11 +173,17 @@ def test_dgrad_with_fused_bn_backward(dtype, mask_mode, cfg):
     scale = gamma.detach() * invstd
     shift = beta.detach() - mean * scale
     yd = yn.to(dtype).to(DEV)
-    a_d = ops.bn_apply(yd, scale.to(DEV), shift.to(DEV), None if res is None else nhwc(res).to(dtype).to(DEV), relu=True)
+    resd = None if res is None else nhwc(res).to(dtype).to(DEV)
+    a_mask = None
+    if mask_mode == 4:   # packed ReLU mask written by the forward's bn_apply instead of re-reading a_out
+        a_d, a_mask = ops.bn_apply_mask(yd, scale.to(DEV), shift.to(DEV), resd)
+        assert torch.equal(a_d, ops.bn_apply(yd, scale.to(DEV), shift.to(DEV), resd, relu=True))
+    else:
+        a_d = ops.bn_apply(yd, scale.to(DEV), shift.to(DEV), resd, relu=True)
     w_crsk = w.permute(1, 2, 3, 0).contiguous().to(dtype).to(DEV)
     dz, st = ops.conv2d_dgrad_bn(nhwc(dyc).to(dtype).to(DEV), w_crsk, (b, h, h, ci), s, p, yd, mean.to(DEV), invstd.to(DEV),
                                  a_out=a_d if mask_mode == 1 else None, scale=scale.to(DEV) if mask_mode == 2 else None,
-                                 shift=shift.to(DEV) if mask_mode == 2 else None, addend=nhwc(add).to(dtype).to(DEV))
+                                 shift=shift.to(DEV) if mask_mode == 2 else None, addend=nhwc(add).to(dtype).to(DEV), a_mask=a_mask)
     dy, dg, db = ops.bn_backward_from_dz(dz, yd, mean.to(DEV), invstd.to(DEV), gamma.detach().to(DEV), st)
     t = 1e-4 if dtype == torch.float32 else 3e-2
     assert rel_err(nchw(dy), dy_ref) < t
