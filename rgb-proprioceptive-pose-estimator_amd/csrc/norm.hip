@@ -678,6 +678,24 @@ int bn_apply_launch(const void* y, const void* res, void* out, const float* scal
 }
 
 template <typename T>
+static int bn_apply_dz_launch(const void* dz, const void* y, const float* mean, const float* invstd, const float* gamma, const float* c1,
+                              const float* c2, void* dy, long M, int C, hipStream_t s) {
+    constexpr int CE = Elem<T>::kChunk;
+    const int cpr = C / CE;
+    const long n = M * C / CE;
+    // grid * 256 must be a multiple of chunks-per-row (cpr is a power of two <= 512 for every ResNet width)
+    const EwCfg cfg = ew_cfg();
+    const long g = ew_grid_rows(n, cpr, cfg);
+    if ((g * 256) % cpr) return rpe_set_error(RPE_ERR_SHAPE, "bn_bwd_from_dz: C/chunk must be a power of two");
+#define RPE_BN_DZ(U, N) hipLaunchKernelGGL((bn_bwd_apply_dz_kernel<T, U, N>), dim3((unsigned)g), dim3(256), 0, s, (const T*)dz, (const T*)y, mean, invstd, gamma, c1, c2, (T*)dy, n, C)
+    if (cfg.nt) { if (cfg.unr == 1) RPE_BN_DZ(1, true); else if (cfg.unr == 2) RPE_BN_DZ(2, true); else RPE_BN_DZ(4, true); }
+    else { if (cfg.unr == 1) RPE_BN_DZ(1, false); else if (cfg.unr == 2) RPE_BN_DZ(2, false); else RPE_BN_DZ(4, false); }
+#undef RPE_BN_DZ
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T>
 int bn_bwd_launch(const void* dA, const void* a_out, const void* y, const float* mean, const float* invstd, const float* gamma,
                   float* dgamma, float* dbeta, void* dy, void* dz_out, long M, int C, float* part, long part_floats, float* c1c2,
                   double* dpart, hipStream_t s) {
@@ -699,6 +717,8 @@ int bn_bwd_launch(const void* dA, const void* a_out, const void* y, const float*
     float* c1 = c1c2;
     float* c2 = c1c2 + C;
     if (int e = reduce_finalize(part, (int)nb, C, dpart, BnBwdFin{(double)M, dgamma, dbeta, c1, c2}, s)) return e;
+    // no ReLU in front and no dz wanted (projection-shortcut BNs): dz == dA, the streaming dz -> dy kernel does the third pass
+    if (!a_out && !dz_out && (256 % (C / CE) == 0 || (C / CE) % 256 == 0)) return bn_apply_dz_launch<T>(dA, y, mean, invstd, gamma, c1, c2, dy, M, C, s);
     const long n = M * C / CE;
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, s, (const T*)dA, (const T*)a_out, (const T*)y, mean, invstd, gamma,
                        (const float*)c1, (const float*)c2, (T*)dy, (T*)dz_out, n, C);
@@ -715,17 +735,7 @@ int bn_bwd_from_dz_launch(const void* dz, const void* y, const float* mean, cons
     float* c1 = c1c2;
     float* c2 = c1c2 + C;
     if (int e = reduce_finalize(stats_part, tiles, C, dpart, BnBwdFin{(double)M, dgamma, dbeta, c1, c2}, s)) return e;
-    const long n = M * C / CE;
-    // grid * 256 must be a multiple of chunks-per-row (cpr is a power of two <= 512 for every ResNet width)
-    const EwCfg cfg = ew_cfg();
-    const long g = ew_grid_rows(n, cpr, cfg);
-    if ((g * 256) % cpr) return rpe_set_error(RPE_ERR_SHAPE, "bn_bwd_from_dz: C/chunk must be a power of two");
-#define RPE_BN_DZ(U, N) hipLaunchKernelGGL((bn_bwd_apply_dz_kernel<T, U, N>), dim3((unsigned)g), dim3(256), 0, s, (const T*)dz, (const T*)y, mean, invstd, gamma, (const float*)c1, (const float*)c2, (T*)dy, n, C)
-    if (cfg.nt) { if (cfg.unr == 1) RPE_BN_DZ(1, true); else if (cfg.unr == 2) RPE_BN_DZ(2, true); else RPE_BN_DZ(4, true); }
-    else { if (cfg.unr == 1) RPE_BN_DZ(1, false); else if (cfg.unr == 2) RPE_BN_DZ(2, false); else RPE_BN_DZ(4, false); }
-#undef RPE_BN_DZ
-    RPE_CHECK_LAUNCH();
-    return 0;
+    return bn_apply_dz_launch<T>(dz, y, mean, invstd, gamma, c1, c2, dy, M, C, s);
 }
 
 template <typename T>
