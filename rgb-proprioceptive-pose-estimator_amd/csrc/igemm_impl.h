@@ -78,7 +78,13 @@ __device__ __forceinline__ u32x4 stem_chunk(const T* x, long img_base, int hb, i
 struct TagFirst { static constexpr bool value = true; };   // first K step of a tile: accumulators start from zero
 struct TagNext { static constexpr bool value = false; };
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// The wait in front of a ring barrier.  vmcnt(N): this wave's LDS-DMA pieces of the tile that is read next have landed (RAW).
+// lgkmcnt(0): this wave's ds_reads of the tile just multiplied have RETURNED, not merely been issued -- the slot they read is
+// re-filled by LDS-DMA right after the barrier (WAR).  hipcc leaves the last fragment reads of a K step in flight across
+// the barrier (their lgkmcnt sits in front of the MFMAs that follow it); with several workgroups per CU queueing on the
+// LDS while a second stream's kernel shares the CU such a read was occasionally served after the next tile's DMA write:
+// a few per cent error in one 8-channel slab of a weight gradient, a few times per hundred launches (tools/repro_check.py).
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
 // -----------------------------------------------------------------------------------------------
 // NT kernel.  Tile BM x BN = (64*WAVES_M) x BN, 2*WAVES_M waves of 64 x (BN/2), K-step = KCH 16-byte chunks per row.
