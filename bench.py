@@ -185,6 +185,9 @@ def main():
                 "algorithmic_mb_per_launch": round(dom["bytes"] / dom["launches"] / 1e6, 2),
                 "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 2),
                 "arithmetic_intensity": round(ai, 1), "tflops": round(tflops, 1), "gbs": round(gbs, 1),
+                # weight-gradient launches run on the engine's second stream beside the data-gradient / BN chain of the caller's
+                # stream: their duration (and the chain's) is measured while the two share HBM and the CUs
+                "stream": "second (beside the data-gradient chain)" if dom["kernel"].startswith("tn_kernel") else "caller's",
                 "kernels": sorted(({"kernel": k["kernel"], "launches_per_step": k["launches"] // n_prof, "ms_per_step": round(k["ms"] / n_prof, 3),
                                     "tflops": round(k["flops"] / 1e12 / (k["ms"] / 1e3), 1) if k["flops"] else None,
                                     "gbs": round(k["bytes"] / 1e9 / (k["ms"] / 1e3), 1) if k["bytes"] else None} for k in syms),
