@@ -252,6 +252,11 @@ int rpe_resnet50_bind(rpe_resnet50_t* e, void* workspace, long workspace_bytes, 
                       float* const* running_host, long long* const* num_batches_host);
 /* re-pack compute-dtype copies of the weights (call after every optimizer step / load_state_dict) */
 int rpe_resnet50_pack_weights(rpe_resnet50_t* e, void* stream);
+/* The fp32 masters or the BN running statistics bound to this engine were changed by someone else (an optimizer step or a
+ * training forward that ran through ANOTHER engine object bound to the same tensors, load_state_dict): every cached weight
+ * copy -- the compute-dtype training copies and the BN-folded inference copies -- is rebuilt by the next forward.
+ * replaces: nothing in the reference (torch modules read their parameters in place, util/model_utils.py:136-141). */
+int rpe_resnet50_weights_changed(rpe_resnet50_t* e);
 /* img: (B,3,H,W) fp32 NCHW.  features: fp32 [B][ld_features] (first latent_dim columns written).
  * training != 0: batch statistics + running-stat update and everything backward needs is kept. */
 int rpe_resnet50_forward(rpe_resnet50_t* e, const float* img_nchw, float* features, long ld_features, int training, void* stream);

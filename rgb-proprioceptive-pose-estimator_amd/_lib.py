@@ -87,6 +87,7 @@ _SPEC = {
     "rpe_resnet50_param_numel": (L, [P, I]),
     "rpe_resnet50_bind": (I, [P, P, L, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
     "rpe_resnet50_pack_weights": (I, [P, P]),
+    "rpe_resnet50_weights_changed": (I, [P]),
     "rpe_resnet50_forward": (I, [P, P, P, L, I, P]),
     "rpe_resnet50_forward_u8": (I, [P, P, I, I, POINTER(c_float), POINTER(c_float), P, L, I, P]),
     "rpe_resnet50_early_feature": (c_void_p, [P]),

@@ -426,6 +426,12 @@ extern "C" int rpe_resnet50_pack_weights(rpe_resnet50_t* e, void* stream) {
     return 0;
 }
 
+extern "C" int rpe_resnet50_weights_changed(rpe_resnet50_t* e) {
+    if (!e) return rpe_set_error(RPE_ERR_STATE, "resnet50_weights_changed: null engine");
+    e->pack_state = 0;
+    return 0;
+}
+
 // algorithmic HBM bytes: every operand tensor read or written exactly once (weights amortised over the batch)
 static double conv_in_bytes(const rpe_resnet50* e, const ConvL& c) { return (double)c.d.batch * c.d.in_h * c.d.in_w * c.d.in_c * e->esz; }
 static double conv_out_bytes(const rpe_resnet50* e, const ConvL& c) { return (double)c.rows * c.d.out_c * e->esz; }

@@ -272,8 +272,13 @@ __global__ __launch_bounds__(256) void pose_loss_kernel(const float* __restrict_
             if (-h3 >= 0.f) gh[3] -= 1.f;  // torch.clamp(min=0) passes the gradient at the boundary
         }
         // d qhat / d q = (I - qhat qhat^T) / |q|
-        const float hd = gh[0] * h0 + gh[1] * h1 + gh[2] * h2 + gh[3] * h3;
-        g[3] = (gh[0] - h0 * hd) / mag; g[4] = (gh[1] - h1 * hd) / mag; g[5] = (gh[2] - h2 * hd) / mag; g[6] = (gh[3] - h3 * hd) / mag;
+        // (mode 0, "position": the normalised quaternion is not part of the reference's graph -- models/losses.py:124-126 --
+        // so its gradient is exactly zero, also for an all-zero predicted quaternion where the Jacobian below is 0/0)
+        g[3] = g[4] = g[5] = g[6] = 0.f;
+        if (mode == 1) {
+            const float hd = gh[0] * h0 + gh[1] * h1 + gh[2] * h2 + gh[3] * h3;
+            g[3] = (gh[0] - h0 * hd) / mag; g[4] = (gh[1] - h1 * hd) / mag; g[5] = (gh[2] - h2 * hd) / mag; g[6] = (gh[3] - h3 * hd) / mag;
+        }
         if (grad) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) grad[i * 7 + k] = scale * g[k];

@@ -62,8 +62,10 @@ class ResNet50Trunk(nn.Module):
         self.crop_hw = (224, 224)
         self.norm_mean = (0.485, 0.456, 0.406)
         self.norm_std = (0.229, 0.224, 0.225)
-        self._plans = {}      # (B, H, W, dtype, latent) -> _Plan
+        self._plans = {}      # (B, H, W, dtype, latent, device) -> _Plan, most recently used last
+        self.max_plans = 3    # each plan owns a multi-GB workspace: the train plan plus the latest eval / rollout shapes stay
         self._active = None
+        self._wver = 0        # bumped whenever the fp32 masters or the BN running statistics may have moved
 
     # -- plumbing ---------------------------------------------------------------------------------
     def _ordered(self):
@@ -98,17 +100,22 @@ class ResNet50Trunk(nn.Module):
 
     def _plan(self, batch, h, w):
         key = (batch, h, w, self.compute_dtype, self.fc.out_features, self.fc.weight.device)
-        plan = self._plans.get(key)
+        plan = self._plans.pop(key, None)
         if plan is None:
+            while len(self._plans) >= max(1, self.max_plans):   # evict the least recently used plan (frees its workspace)
+                old_key = next(iter(self._plans))
+                if self._plans[old_key] is self._active:
+                    self._active = None
+                del self._plans[old_key]
             plan = _Plan(self, batch, h, w)
-            self._plans[key] = plan
+        self._plans[key] = plan
         plan.rebind_if_needed()
         return plan
 
     def weights_changed(self):
-        """Call after an optimizer step or load_state_dict: compute-dtype weight copies are stale."""
-        for p in self._plans.values():
-            p.packed = False
+        """Call after an optimizer step or load_state_dict: every plan's cached weight copies (compute-dtype copies for
+        training, BN-folded copies for inference) are stale.  Training forwards call it themselves."""
+        self._wver += 1
 
     # -- compute ----------------------------------------------------------------------------------
     def run(self, img, features, training):
@@ -126,11 +133,15 @@ class ResNet50Trunk(nn.Module):
             assert c == 3 and img.dtype == torch.float32 and img.is_contiguous()
         plan = self._plan(b, h, w)
         s = ops._stream()
-        if training or not plan.packed:
-            # training: the optimizer moved the fp32 masters since the last step -> refresh the
-            # compute-dtype / transposed copies (53 tiny kernels, ~0.2 GB of traffic)
+        if training:
+            # the optimizer moved the fp32 masters since the last step -> refresh the compute-dtype / transposed copies
+            # (one packing launch, ~0.2 GB of traffic)
             lib.rpe_resnet50_pack_weights(plan.handle, s)
-            plan.packed = True
+        elif plan.wver != self._wver:
+            # inference on a plan whose BN-folded copies were built before the masters / running statistics last moved --
+            # possibly through ANOTHER plan (train() runs train and val phases at different batch sizes): rebuild them
+            lib.rpe_resnet50_weights_changed(plan.handle)
+        plan.wver = self._wver
         if frames:
             F3 = ctypes.c_float * 3
             lib.rpe_resnet50_forward_u8(plan.handle, ops._p(img), hs, ws, F3(*self.norm_mean), F3(*self.norm_std), ops._p(features),
@@ -138,6 +149,8 @@ class ResNet50Trunk(nn.Module):
         else:
             lib.rpe_resnet50_forward(plan.handle, ops._p(img), ops._p(features), features.stride(0), int(training), s)
         self._active = plan
+        if training:
+            self._wver += 1   # running statistics moved now; the masters will with the optimizer step that follows
         return plan
 
     def forward(self, img):
@@ -161,7 +174,7 @@ class _Plan:
         nbytes = lib.rpe_resnet50_workspace_bytes(hp)
         self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=trunk.fc.weight.device)
         self._ptr_sig = None
-        self.packed = False
+        self.wver = None      # trunk._wver the engine's cached weight copies were built at
         self.grad_views = None
 
     def __del__(self):
@@ -193,7 +206,7 @@ class _Plan:
         off = (-base) % 256
         lib.rpe_resnet50_bind(self.handle, ctypes.c_void_p(base + off), self.workspace.numel() - off, pa, ga, ra, na)
         self._ptr_sig = sig
-        self.packed = False
+        self.wver = None
 
     # early feature relu(bn1(conv1 x)) as an NHWC tensor aliasing the workspace
     def early_feature(self):

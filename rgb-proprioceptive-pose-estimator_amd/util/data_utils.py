@@ -129,6 +129,11 @@ class FramePrefetcher:
             self._dev[slot] = [None if t is None else torch.empty(t.shape, dtype=t.dtype, device=self.device) for t in items]
         if self._free[slot] is not None:
             self.stream.wait_event(self._free[slot])      # the previous consumer of this slot is done with it
+        # The slot's pinned staging buffers are the SOURCE of its previous asynchronous H2D copy, which may not even have
+        # started yet (it queues behind `_free[slot]` on the copy stream while the training thread runs ahead of the GPU):
+        # the host must not overwrite them before that copy has finished.
+        if self._ready[slot] is not None and any(p is not None for p in self._pinned[slot]):
+            self._ready[slot].synchronize()
         src = []
         for p, t in zip(self._pinned[slot], items):
             if t is None or t.is_pinned():

@@ -165,3 +165,84 @@ def test_gradients_repeat_across_passes():
         grads.append(model._arena.grad.detach().clone())
     for g in grads[1:]:
         assert ((g - grads[0]).norm() / grads[0].norm()).item() < 1e-5
+
+
+def test_frame_prefetcher_without_host_syncs():
+    """The consumer never synchronises the host (as the training loop: train_step returns device scalars) and every batch
+    is followed by a long kernel, so the host runs several batches ahead: a reused pinned staging buffer must not be
+    overwritten before the asynchronous copy out of it has run (pageable host tensors take the staged path)."""
+    from rgb_proprioceptive_pose_estimator_amd.util.data_utils import FramePrefetcher
+
+    g = torch.Generator().manual_seed(1)
+    host = [(torch.randint(0, 256, (8, 128, 128, 3), generator=g, dtype=torch.uint8), torch.randn(8, 7, generator=g)) for _ in range(12)]
+    busy = torch.randn(4096, 4096, device="cuda")
+    sums = torch.zeros(len(host), 2, dtype=torch.float64, device="cuda")
+    for i, (frames, x0bar) in enumerate(FramePrefetcher(iter(host), "cuda", depth=2)):
+        for _ in range(6):
+            busy = torch.tanh(busy @ busy * 1e-3)          # ~10 ms of device work queued per batch, no host sync
+        sums[i, 0] = frames.double().sum()
+        sums[i, 1] = x0bar.double().sum()
+    got = sums.cpu()
+    for i, (f, x) in enumerate(host):
+        assert got[i, 0].item() == f.double().sum().item()
+        assert abs(got[i, 1].item() - x.double().sum().item()) < 1e-9
+
+
+def test_eval_plan_sees_weights_trained_on_another_plan():
+    """train() runs its train and val phases at different batch sizes = different trunk plans.  The val plan caches BN-folded
+    weight copies; they must be rebuilt after every optimizer step / running-statistics update that went through the train
+    plan.  Checked against a freshly built model loaded with the same state_dict."""
+    from rgb_proprioceptive_pose_estimator_amd import models as M
+    from rgb_proprioceptive_pose_estimator_amd.optim import FusedAdam
+    from rgb_proprioceptive_pose_estimator_amd.util.data_utils import synthetic_batch
+
+    def make():
+        return M.NaiveObjectStateEstimator("cube", [32], 50, 32, False, (9,), False, False, False, compute_dtype=torch.float32)
+
+    torch.manual_seed(2)
+    model = make().cuda()
+    opt = FusedAdam(model.parameters(), lr=1e-2)
+    crit = M.PoseDistanceLoss("l2", 1.0, 0.5, 1e-4, "pose")
+    tb, vb = synthetic_batch((6,), 3), synthetic_batch((2,), 4)
+
+    def train_once():
+        model.train()
+        opt.zero_grad()
+        crit(model(tb["img"], None, tb["x0bar"]), tb["obj"]).backward()
+        opt.step()
+
+    def eval_out(m):
+        m.eval()
+        with torch.no_grad():
+            return m(vb["img"], None, vb["x0bar"]).clone()
+
+    def fresh_out():
+        m2 = make()
+        m2.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        return eval_out(m2.cuda())
+
+    train_once()
+    a0 = eval_out(model)                       # builds the eval plan's folded copies
+    assert torch.allclose(a0, fresh_out(), rtol=1e-4, atol=1e-5)
+    train_once()                               # weights + running statistics move through the TRAIN plan only
+    a1 = eval_out(model)
+    assert torch.allclose(a1, fresh_out(), rtol=1e-4, atol=1e-5)
+    assert (a1 - a0).abs().max() > 1e-4        # the step was visible at all
+    assert len(model.trunk._plans) == 2
+
+
+def test_plan_cache_is_bounded():
+    from rgb_proprioceptive_pose_estimator_amd import models as M
+    from rgb_proprioceptive_pose_estimator_amd.util.data_utils import synthetic_batch
+
+    torch.manual_seed(0)
+    model = M.NaiveObjectStateEstimator("cube", [32], 50, 32, False, (9,), False, False, False, compute_dtype=torch.bfloat16).cuda().eval()
+    outs = {}
+    with torch.no_grad():
+        for n in (1, 2, 3, 4, 5, 1):
+            b = synthetic_batch((n,), 7)
+            o = model(b["img"], None, b["x0bar"])
+            if n in outs:
+                assert torch.equal(o, outs[n])   # an evicted and rebuilt plan computes the same thing
+            outs[n] = o.clone()
+    assert len(model.trunk._plans) <= model.trunk.max_plans
