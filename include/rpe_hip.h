@@ -17,7 +17,7 @@
  *  - `stream` is a hipStream_t passed as void*.  Calls only enqueue work; no entry
  *    point synchronises, allocates or frees device memory (hipGraph-capturable).
  *  - Activations of the conv trunk are NHWC ([B][H][W][C], C contiguous) in the
- *    compute dtype (RPE_F32 or RPE_BF16; accumulation is always fp32).  Head tensors
+ *    compute dtype (RPE_F32, RPE_BF16 or RPE_F16; accumulation is always fp32).  Head tensors
  *    (features, MLP / LSTM, loss) are fp32 with a leading dimension `ld`.
  *  - Operands must be 16-byte aligned and channel counts / leading dimensions
  *    multiples of the 16-byte chunk (4 fp32 / 8 bf16) unless stated otherwise.
@@ -33,7 +33,7 @@ extern "C" {
 
 #define RPE_ABI_VERSION 1
 
-enum { RPE_F32 = 0, RPE_BF16 = 1 };
+enum { RPE_F32 = 0, RPE_BF16 = 1, RPE_F16 = 2 };   /* RPE_F16: IEEE half activations / weight copies (BASELINE config C5), fp32 accumulate */
 enum {
     RPE_OK = 0,
     RPE_ERR_SHAPE = 1,     /* bad dimension / unsupported configuration */
@@ -224,6 +224,17 @@ int rpe_pose_loss(const float* pred, const float* truth, long n, int metric, int
  * util/learn_utils.py:179) over one flat parameter / gradient / moment buffer. */
 int rpe_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2, double eps, int step,
                   void* stream);
+
+/* Dynamic loss scaling for the RPE_F16 compute path (BASELINE config C5; the reference trains in fp32 and has no counterpart:
+ * util/learn_utils.py:152-179 is the loop these three calls slot into, between loss.backward() and optimizer.step()).
+ * state: 8 device floats {scale, 1/scale, found_inf, skip, finite-step streak, optimizer steps taken, -, -}; nothing is read
+ * back by the host.  unscale: grads *= 1/scale, found_inf |= any non-finite.  update: found_inf -> scale *= backoff, skip = 1;
+ * else steps += 1, and every `growth_interval` finite steps scale *= growth.  adam_step_amp: rpe_adam_step whose step count and
+ * skip decision are read from `state` on the device. */
+int rpe_amp_unscale(float* grads, long n, float* state, void* stream);
+int rpe_amp_update(float* state, float growth_factor, float backoff_factor, int growth_interval, void* stream);
+int rpe_adam_step_amp(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2, double eps, const float* state,
+                      void* stream);
 
 /* ------------------------------------------------------------------ ResNet-50 trunk engine */
 /* One object = one (batch, dtype) plan for the whole torchvision-shaped ResNet-50 body:

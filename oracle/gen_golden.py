@@ -164,6 +164,56 @@ def run_case(kind):
     print(kind, "loss", rec["loss_s1"], rec["loss_s2"], "pos/ori err", rec["pos_err_s1"], rec["ori_err_s1"])
 
 
+# BASELINE.json configs[0] at its own size: NaiveObjectStateEstimator('cube', [1024, 256, 64], 50, 512, ...), 32 images of 224x224
+# (scripts/train_no.sbatch:68-82 hyper-parameters; models/naive.py:298-352 forward).  One pristine eval forward and ONE train
+# step: outputs, loss, val metrics, a digest of every gradient, small gradients whole and a strided sample of the large ones.
+C1 = (dict(latent_dim=512, hidden=[1024, 256, 64], use_depth=False, no_proprioception=False), (32,), 21, 201)
+SAMPLE_STRIDE, SAMPLE_MAX = 997, 4096
+
+
+def run_c1():
+    cfg, lead, wseed, dseed = C1
+    torch.manual_seed(0)
+    model = build("no", cfg)
+    sd = po.make_state("no", cfg, wseed)
+    ref_keys = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    assert ref_keys == [(k, tuple(s)) for k, s in po.model_keys("no", cfg)], "state_dict key table mismatch (C1)"
+    load_values(model, "no", sd)
+    crit = PoseDistanceLoss(**LOSS_CFG)
+    val = PoseDistanceLoss(mode="val")
+    rec = {"keys": np.array([k for k, _ in ref_keys])}
+    model.eval()
+    with torch.no_grad():
+        b = po.synth_batch(lead, dseed + 9)
+        rec["pre_eval_out0"] = model(b["img"], torch.empty(*b["img"].shape), b["x0bar"]).numpy()
+    model.train()
+    b = po.synth_batch(lead, dseed + 1)
+    out = model(b["img"], torch.empty(*b["img"].shape), b["x0bar"])
+    loss = crit(out, b["obj"])
+    pos_err, ori_err = val(out, b["obj"])
+    loss.backward()
+    rec["out0_s1"] = out.detach().numpy()
+    rec["loss_s1"], rec["pos_err_s1"], rec["ori_err_s1"] = np.array(loss.item()), np.array(float(pos_err)), np.array(float(ori_err))
+    gnames, gdig = [], []
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        gnames.append(name)
+        gdig.append(digest(p.grad))
+        g = p.grad.detach().flatten()
+        if g.numel() <= 4096:
+            rec["grad::" + name] = g.numpy().copy()
+        else:
+            rec["gsample::" + name] = g[::SAMPLE_STRIDE][:SAMPLE_MAX].numpy().copy()
+    rec["grad_keys_s1"], rec["grad_digest_s1"] = np.array(gnames), np.stack(gdig)
+    fin = model.state_dict()   # BN running statistics after the one training forward
+    for k, _ in ref_keys:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            rec["final::" + k] = fin[k].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "model_no_c1.npz"), **rec)
+    print("no_c1 loss", rec["loss_s1"], "pos/ori err", rec["pos_err_s1"], rec["ori_err_s1"])
+
+
 def run_loss():
     g = torch.Generator().manual_seed(7)
     rec = {}
@@ -194,9 +244,11 @@ def run_loss():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["loss"] + list(CASES)
+    which = sys.argv[1:] or ["loss"] + list(CASES) + ["c1"]
     for w in which:
         if w == "loss":
             run_loss()
+        elif w == "c1":
+            run_c1()
         else:
             run_case(w)

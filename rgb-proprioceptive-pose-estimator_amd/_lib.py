@@ -15,7 +15,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_lon
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librpe_hip.so")
 
-RPE_F32, RPE_BF16 = 0, 1
+RPE_F32, RPE_BF16, RPE_F16 = 0, 1, 2
 ABI_VERSION = 1
 
 
@@ -80,6 +80,9 @@ _SPEC = {
     "rpe_lstm_cell_bwd": (I, [P, P, P, P, P, P, I, I, P]),
     "rpe_pose_loss": (I, [P, P, L, I, I, F, F, F, P, P, P]),
     "rpe_adam_step": (I, [P, P, P, P, L, D, D, D, D, I, P]),
+    "rpe_amp_unscale": (I, [P, L, P, P]),
+    "rpe_amp_update": (I, [P, F, F, I, P]),
+    "rpe_adam_step_amp": (I, [P, P, P, P, L, D, D, D, D, P, P]),
     "rpe_resnet50_create": (I, [POINTER(c_void_p), I, I, I, I, I]),
     "rpe_resnet50_destroy": (None, [P]),
     "rpe_resnet50_workspace_bytes": (L, [P]),

@@ -10,6 +10,9 @@ namespace rpe {
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -24,14 +27,23 @@ template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int kChunk = 4;  // elements per 16-byte chunk
     static constexpr int kDtype = RPE_F32;
+    static constexpr const char* kName = "f32";
     __device__ static inline float to_f(float v) { return v; }
     __device__ static inline float from_f(float v) { return v; }
 };
 template <> struct Elem<bf16> {
     static constexpr int kChunk = 8;
     static constexpr int kDtype = RPE_BF16;
+    static constexpr const char* kName = "bf16";
     __device__ static inline float to_f(bf16 v) { return (float)v; }
     __device__ static inline bf16 from_f(float v) { return (bf16)v; }
+};
+template <> struct Elem<f16> {   // IEEE half: the reduced-precision type of BASELINE config C5 (needs loss scaling: amp.py)
+    static constexpr int kChunk = 8;
+    static constexpr int kDtype = RPE_F16;
+    static constexpr const char* kName = "f16";
+    __device__ static inline float to_f(f16 v) { return (float)v; }
+    __device__ static inline f16 from_f(float v) { return (f16)v; }
 };
 
 // 16 bytes of T viewed as raw dwords (used for staging through registers / LDS)
@@ -52,6 +64,20 @@ template <> __device__ inline void chunk_to_f<bf16>(const u32x4& c, float* f) {
     f[4] = __uint_as_float(c.z << 16); f[5] = __uint_as_float(c.z & 0xffff0000u);
     f[6] = __uint_as_float(c.w << 16); f[7] = __uint_as_float(c.w & 0xffff0000u);
 }
+template <> __device__ inline void chunk_to_f<f16>(const u32x4& c, float* f) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    const unsigned w[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2_ v = __builtin_convertvector(__builtin_bit_cast(f16x2, w[i]), f32x2_);
+        f[2 * i] = v.x; f[2 * i + 1] = v.y;
+    }
+}
+__device__ inline unsigned pack_f16x2(float lo, float hi) {   // round-to-nearest-even (not the rtz pack instruction)
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    const f32x2_ v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
 __device__ inline unsigned pack_bf16x2(float lo, float hi) {
     // one v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserving); the element-wise cast + shift + or form compiled to four
     // instructions per pair, a visible share of the instruction-bound epilogues and streaming kernels
@@ -60,6 +86,11 @@ __device__ inline unsigned pack_bf16x2(float lo, float hi) {
     const f32x2_ v = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_));
 }
+// two floats -> one dword of two 16-bit elements of T
+template <typename T> __device__ inline unsigned pack2(float lo, float hi);
+template <> __device__ inline unsigned pack2<bf16>(float lo, float hi) { return pack_bf16x2(lo, hi); }
+template <> __device__ inline unsigned pack2<f16>(float lo, float hi) { return pack_f16x2(lo, hi); }
+template <> __device__ inline unsigned pack2<float>(float lo, float) { return __float_as_uint(lo); }   // (unused; keeps templates uniform)
 template <typename T> __device__ inline u32x4 f_to_chunk(const float* f);
 template <> __device__ inline u32x4 f_to_chunk<float>(const float* f) {
     u32x4 c; c.x = __float_as_uint(f[0]); c.y = __float_as_uint(f[1]); c.z = __float_as_uint(f[2]); c.w = __float_as_uint(f[3]);
@@ -67,6 +98,11 @@ template <> __device__ inline u32x4 f_to_chunk<float>(const float* f) {
 }
 template <> __device__ inline u32x4 f_to_chunk<bf16>(const float* f) {
     u32x4 c; c.x = pack_bf16x2(f[0], f[1]); c.y = pack_bf16x2(f[2], f[3]); c.z = pack_bf16x2(f[4], f[5]); c.w = pack_bf16x2(f[6], f[7]);
+    return c;
+}
+
+template <> __device__ inline u32x4 f_to_chunk<f16>(const float* f) {
+    u32x4 c; c.x = pack_f16x2(f[0], f[1]); c.y = pack_f16x2(f[2], f[3]); c.z = pack_f16x2(f[4], f[5]); c.w = pack_f16x2(f[6], f[7]);
     return c;
 }
 

@@ -177,6 +177,7 @@ static int linear_wgrad_t(const void* dy, int lddy, const void* x, int ldx, floa
     do {                                                                  \
         if ((dtype) == RPE_F32) return fn<float>(__VA_ARGS__);            \
         if ((dtype) == RPE_BF16) return fn<bf16>(__VA_ARGS__);            \
+        if ((dtype) == RPE_F16) return fn<f16>(__VA_ARGS__);            \
         return rpe_set_error(RPE_ERR_DTYPE, #fn ": unsupported dtype");   \
     } while (0)
 

@@ -37,7 +37,7 @@ struct ConvL {
 struct Block {
     int c1, c2, c3, cd;  // conv indices (cd = -1: identity shortcut)
     void* dz = nullptr;  // backward: ReLU-masked gradient at the block output (kept as the shortcut gradient)
-    unsigned char* relu_mask = nullptr;  // bf16: packed ReLU mask of the block output (1 bit per element), written by its bn_apply
+    unsigned char* relu_mask = nullptr;  // 16-bit element types: packed ReLU mask of the block output (1 bit per element), written by its bn_apply
 };
 
 struct Named {
@@ -173,7 +173,7 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
     if (!out) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_create: null out");
     if (batch <= 0 || latent_dim <= 0) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_create: bad batch/latent");
     if (height < 32 || width < 32 || (height % 32) || (width % 32)) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_create: H, W must be multiples of 32");
-    if (dtype != RPE_F32 && dtype != RPE_BF16) return rpe_set_error(RPE_ERR_DTYPE, "resnet50_create: dtype must be RPE_F32 or RPE_BF16");
+    if (dtype != RPE_F32 && dtype != RPE_BF16 && dtype != RPE_F16) return rpe_set_error(RPE_ERR_DTYPE, "resnet50_create: dtype must be RPE_F32, RPE_BF16 or RPE_F16");
     rpe_resnet50* e = new rpe_resnet50();
     e->B = batch; e->H = height; e->W = width; e->dtype = dtype; e->latent = latent_dim;
     e->esz = dtype == RPE_F32 ? 4 : 2;
@@ -239,7 +239,7 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
     for (auto& b : e->blocks) {
         const ConvL& c3 = e->convs[b.c3];
         want(e, &b.dz, c3.rows * c3.d.out_c * es);
-        if (dtype == RPE_BF16) want(e, (void**)&b.relu_mask, c3.rows * c3.d.out_c / 8);
+        if (dtype != RPE_F32) want(e, (void**)&b.relu_mask, c3.rows * c3.d.out_c / 8);
     }
     want(e, &e->d_pool, (long)batch * (e->convs[0].Ho / 2) * (e->convs[0].Wo / 2) * 64 * es);
     want(e, (void**)&e->stats_part, e->stats_floats * 4);

@@ -334,6 +334,60 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Dynamic loss scaling for the fp16 compute path (config C5).  All state lives in one device array so that a train step
+// never synchronises the host:  st[0] scale, st[1] 1/scale, st[2] found_inf (set by the unscale pass), st[3] skip (this
+// step's decision, read by the Adam kernel), st[4] consecutive finite steps, st[5] optimizer steps taken.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void amp_unscale_kernel(float* __restrict__ g, long n, float* __restrict__ st) {
+    const float inv = st[1];
+    bool bad = false;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 v = ((f32x4*)g)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] *= inv; bad |= !(fabsf(v[k]) <= 3.4028234e38f); }   // inf or NaN
+        ((f32x4*)g)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = (n4 << 2) + threadIdx.x;
+        const float v = g[i] * inv;
+        g[i] = v;
+        bad |= !(fabsf(v) <= 3.4028234e38f);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) st[2] = 1.f;   // same value from every writer: a plain store is enough
+}
+
+__global__ void amp_update_kernel(float* __restrict__ st, float growth, float backoff, int interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (st[2] != 0.f) {
+        st[0] = fmaxf(st[0] * backoff, 1.f); st[1] = 1.f / st[0];
+        st[3] = 1.f; st[4] = 0.f;
+    } else {
+        st[3] = 0.f; st[5] += 1.f;
+        const float t = st[4] + 1.f;
+        if (t >= (float)interval) { st[0] = fminf(st[0] * growth, 16777216.f); st[1] = 1.f / st[0]; st[4] = 0.f; }
+        else st[4] = t;
+    }
+    st[2] = 0.f;
+}
+
+// Adam whose step count and skip decision live on the device (same update rule as adam_kernel)
+__global__ __launch_bounds__(256) void adam_amp_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                      long n, float lr, double b1, double b2, float eps, const float* __restrict__ st) {
+    if (st[3] != 0.f) return;   // non-finite gradients this step: parameters and moments stay as they are
+    const double step = (double)st[5];
+    const float bc1 = (float)(1.0 - pow(b1, step)), bc2_sqrt = (float)sqrt(1.0 - pow(b2, step));
+    const float omb1 = (float)(1.0 - b1), omb2 = (float)(1.0 - b2), fb2 = (float)b2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * omb1;
+        const float vi = v[i] * fb2 + gi * gi * omb2;
+        m[i] = mi; v[i] = vi;
+        p[i] -= (lr / bc1) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight packing / small utilities
 // ---------------------------------------------------------------------------------------------
 // w: [Co][R][S][Ci] fp32 (channels_last storage of an OIHW parameter)
@@ -356,6 +410,10 @@ template <typename T> __device__ inline void store4(T* o, float a, float b, floa
 template <> __device__ inline void store4<float>(float* o, float a, float b, float c, float d) { *(f32x4*)o = f32x4{a, b, c, d}; }
 template <> __device__ inline void store4<bf16>(bf16* o, float a, float b, float c, float d) {
     u32x2 v; v.x = pack_bf16x2(a, b); v.y = pack_bf16x2(c, d);
+    *(u32x2*)o = v;
+}
+template <> __device__ inline void store4<f16>(f16* o, float a, float b, float c, float d) {
+    u32x2 v; v.x = pack_f16x2(a, b); v.y = pack_f16x2(c, d);
     *(u32x2*)o = v;
 }
 
@@ -504,6 +562,7 @@ int rpe_aux_head_fwd(int dtype, const void* a1, const float* w, const float* bia
     const long total = (long)B * (H / 2) * (W / 2);
     if (dtype == RPE_F32) hipLaunchKernelGGL((aux_fwd_kernel<float>), dim3(ew_grid(total, 16)), dim3(256), 0, (hipStream_t)stream, (const float*)a1, w, bias, depth_feat, out, ld_out, raw, idx, B, H, W);
     else if (dtype == RPE_BF16) hipLaunchKernelGGL((aux_fwd_kernel<bf16>), dim3(ew_grid(total, 32)), dim3(256), 0, (hipStream_t)stream, (const bf16*)a1, w, bias, depth_feat, out, ld_out, raw, idx, B, H, W);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((aux_fwd_kernel<f16>), dim3(ew_grid(total, 32)), dim3(256), 0, (hipStream_t)stream, (const f16*)a1, w, bias, depth_feat, out, ld_out, raw, idx, B, H, W);
     else return rpe_set_error(RPE_ERR_DTYPE, "aux_head: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;
@@ -514,6 +573,7 @@ int rpe_aux_head_bwd(int dtype, const float* dout, long ld_dout, const void* a1,
     const long total = (long)B * (H / 2) * (W / 2);
     if (dtype == RPE_F32) hipLaunchKernelGGL((aux_bwd_kernel<float>), dim3(ew_grid(total, 16 * 8)), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, (const float*)a1, w, depth_feat, raw, idx, (float*)d_a1, dw, dbias, d_depth_feat, B, H, W);
     else if (dtype == RPE_BF16) hipLaunchKernelGGL((aux_bwd_kernel<bf16>), dim3(ew_grid(total, 32 * 8)), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, (const bf16*)a1, w, depth_feat, raw, idx, (bf16*)d_a1, dw, dbias, d_depth_feat, B, H, W);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((aux_bwd_kernel<f16>), dim3(ew_grid(total, 32 * 8)), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, (const f16*)a1, w, depth_feat, raw, idx, (f16*)d_a1, dw, dbias, d_depth_feat, B, H, W);
     else return rpe_set_error(RPE_ERR_DTYPE, "aux_head: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;
@@ -569,10 +629,35 @@ int rpe_adam_step(float* p, const float* g, float* m, float* v, long n, double l
     return 0;
 }
 
+int rpe_amp_unscale(float* grads, long n, float* state, void* stream) {
+    if (n <= 0) return 0;
+    if (!grads || !state || (((uintptr_t)grads) & 15)) return rpe_set_error(RPE_ERR_ALIGN, "amp_unscale: gradient buffer must be 16-byte aligned");
+    hipLaunchKernelGGL(amp_unscale_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, grads, n, state);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_amp_update(float* state, float growth_factor, float backoff_factor, int growth_interval, void* stream) {
+    if (!state || growth_interval <= 0) return rpe_set_error(RPE_ERR_SHAPE, "amp_update: bad arguments");
+    hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, growth_factor, backoff_factor, growth_interval);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_adam_step_amp(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2, double eps, const float* state,
+                      void* stream) {
+    if (n <= 0) return 0;
+    if (!state) return rpe_set_error(RPE_ERR_SHAPE, "adam_step_amp: null state");
+    hipLaunchKernelGGL(adam_amp_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)lr, beta1, beta2, (float)eps, state);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
 int rpe_pack_conv_weight(int dtype, const float* w_krsc, void* w_fwd, void* w_dgrad, int Co, int R, int S, int Ci, void* stream) {
     const long n = (long)Co * R * S * Ci;
     if (dtype == RPE_F32) hipLaunchKernelGGL((pack_conv_weight_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, w_krsc, (float*)w_fwd, (float*)w_dgrad, Co, R * S, Ci);
     else if (dtype == RPE_BF16) hipLaunchKernelGGL((pack_conv_weight_kernel<bf16>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, w_krsc, (bf16*)w_fwd, (bf16*)w_dgrad, Co, R * S, Ci);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((pack_conv_weight_kernel<f16>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, w_krsc, (f16*)w_fwd, (f16*)w_dgrad, Co, R * S, Ci);
     else return rpe_set_error(RPE_ERR_DTYPE, "pack_conv_weight: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;
@@ -583,6 +668,7 @@ int rpe_pack_conv_weights_multi(int dtype, const rpe_pack_desc* table_dev, int n
     const int grid = (int)((total + 4095) / 4096 < 8192 ? (total + 4095) / 4096 : 8192);
     if (dtype == RPE_F32) hipLaunchKernelGGL((pack_conv_weights_multi_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, table_dev, nlayers, total);
     else if (dtype == RPE_BF16) hipLaunchKernelGGL((pack_conv_weights_multi_kernel<bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, table_dev, nlayers, total);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((pack_conv_weights_multi_kernel<f16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, table_dev, nlayers, total);
     else return rpe_set_error(RPE_ERR_DTYPE, "pack_conv_weights_multi: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;
@@ -591,6 +677,7 @@ int rpe_pack_conv_weights_multi(int dtype, const rpe_pack_desc* table_dev, int n
 int rpe_pack_stem_weight(int dtype, const float* w_oihw, const float* scale, void* out, void* stream) {
     if (dtype == RPE_F32) hipLaunchKernelGGL((pack_stem_weight_kernel<float>), dim3(64), dim3(256), 0, (hipStream_t)stream, w_oihw, scale, (float*)out);
     else if (dtype == RPE_BF16) hipLaunchKernelGGL((pack_stem_weight_kernel<bf16>), dim3(64), dim3(256), 0, (hipStream_t)stream, w_oihw, scale, (bf16*)out);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((pack_stem_weight_kernel<f16>), dim3(64), dim3(256), 0, (hipStream_t)stream, w_oihw, scale, (f16*)out);
     else return rpe_set_error(RPE_ERR_DTYPE, "pack_stem_weight: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;

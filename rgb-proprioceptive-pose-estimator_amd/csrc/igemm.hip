@@ -38,6 +38,7 @@ template <typename T> int launch_nt(NTArgs<T>& a, int mode, hipStream_t s) {
 }
 template int launch_nt<float>(NTArgs<float>&, int, hipStream_t);
 template int launch_nt<bf16>(NTArgs<bf16>&, int, hipStream_t);
+template int launch_nt<f16>(NTArgs<f16>&, int, hipStream_t);
 
 }  // namespace rpe
 

@@ -41,6 +41,11 @@ template <> struct Mma<bf16> {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
     }
 };
+template <> struct Mma<f16> {
+    __device__ static __forceinline__ void run(const u32x4& w, const u32x4& a, f32x4& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
+    }
+};
 template <> struct Mma<float> {
     // lane (row = l&15, g = l>>4) holds k = 4g..4g+3 of its row; step kk multiplies component kk
     // of both operands, i.e. the K order inside a 16-wide step is permuted identically on both sides.
@@ -778,7 +783,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
             for (int a = 0; a < FI; ++a)
 #pragma unroll
                 for (int b = 0; b < FJ; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pf[a]), __builtin_bit_cast(bf16x8, qf[b]), acc[a][b], 0, 0, 0);
+                    Mma<T>::run(pf[a], qf[b], acc[a][b]);
         } else {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -849,7 +854,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
 extern thread_local char g_last_kernel[96];
 
 template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE> static int launch_nt_role(NTArgs<T>& a, hipStream_t s, long nwg) {
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "nt_kernel<%s,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", WAVES_M, BN, KCH, MODE, NST, ROLE,
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "nt_kernel<%s,%d,%d,%d,%d,%d,%d,%d>", Elem<T>::kName, WAVES_M, BN, KCH, MODE, NST, ROLE,
              ROLE == 1 ? a.bn_mode : 0);
     const dim3 grid((unsigned)nwg), block(128 * WAVES_M);
     if (ROLE == 1) {
@@ -943,7 +948,7 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
     if (dma && (pb <= 0 || qb <= 0 || pb >= (1L << 31) || qb >= (1L << 31)))
         return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: an operand of 2 GiB or more (split the batch)");
     a.p_bytes = (unsigned)pb; a.q_bytes = (unsigned)qb;
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "tn_kernel<%s,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", BI, BJ, MODE, dma ? 1 : 0);
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "tn_kernel<%s,%d,%d,%d,%d>", Elem<T>::kName, BI, BJ, MODE, dma ? 1 : 0);
     if (dma) hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, false>), dim3((unsigned)nwg), dim3(256), 0, s, a);
     RPE_CHECK_LAUNCH();

@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restr
         if (sizeof(T) == 4) {
             *(f32x4*)(out + i * 4) = f32x4{r, g, bl, 0.f};
         } else {
-            u32x2 t; t.x = pack_bf16x2(r, g); t.y = pack_bf16x2(bl, 0.f);
+            u32x2 t; t.x = pack2<T>(r, g); t.y = pack2<T>(bl, 0.f);
             *(u32x2*)(out + i * 4) = t;
         }
     }
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256) void frames_u8_to_nhwc4_kernel(const unsigned 
         if (sizeof(T) == 4) {
             *(f32x4*)(out + i * 4) = f32x4{r, g, bl, 0.f};
         } else {
-            u32x2 v; v.x = pack_bf16x2(r, g); v.y = pack_bf16x2(bl, 0.f);
+            u32x2 v; v.x = pack2<T>(r, g); v.y = pack2<T>(bl, 0.f);
             *(u32x2*)(out + i * 4) = v;
         }
     }
@@ -787,6 +787,7 @@ int rpe_bn_apply(int dtype, const void* y, const void* residual, void* out, cons
                  int relu, void* stream) {
     if (dtype == RPE_F32) return bn_apply_launch<float>(y, residual, out, scale, shift, rows, C, relu, nullptr, (hipStream_t)stream);
     if (dtype == RPE_BF16) return bn_apply_launch<bf16>(y, residual, out, scale, shift, rows, C, relu, nullptr, (hipStream_t)stream);
+    if (dtype == RPE_F16) return bn_apply_launch<f16>(y, residual, out, scale, shift, rows, C, relu, nullptr, (hipStream_t)stream);
     return rpe_set_error(RPE_ERR_DTYPE, "bn_apply: unsupported dtype");
 }
 
@@ -794,7 +795,8 @@ int rpe_bn_apply_mask(int dtype, const void* y, const void* residual, void* out,
                       unsigned char* relu_mask, void* stream) {
     if (!relu_mask || (C % 8)) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply_mask: mask buffer and C % 8 == 0 required");
     if (dtype == RPE_BF16) return bn_apply_launch<bf16>(y, residual, out, scale, shift, rows, C, 1, relu_mask, (hipStream_t)stream);
-    return rpe_set_error(RPE_ERR_DTYPE, "bn_apply_mask: bf16 only");
+    if (dtype == RPE_F16) return bn_apply_launch<f16>(y, residual, out, scale, shift, rows, C, 1, relu_mask, (hipStream_t)stream);
+    return rpe_set_error(RPE_ERR_DTYPE, "bn_apply_mask: 16-bit element types only");
 }
 
 int rpe_bn_backward(int dtype, const void* dA, const void* a_out, const void* y, const float* mean, const float* invstd,
@@ -804,6 +806,8 @@ int rpe_bn_backward(int dtype, const void* dA, const void* a_out, const void* y,
         return bn_bwd_launch<float>(dA, a_out, y, mean, invstd, gamma, dgamma, dbeta, dy, dz_out, rows, C, part, part_floats, c1c2, dpart, (hipStream_t)stream);
     if (dtype == RPE_BF16)
         return bn_bwd_launch<bf16>(dA, a_out, y, mean, invstd, gamma, dgamma, dbeta, dy, dz_out, rows, C, part, part_floats, c1c2, dpart, (hipStream_t)stream);
+    if (dtype == RPE_F16)
+        return bn_bwd_launch<f16>(dA, a_out, y, mean, invstd, gamma, dgamma, dbeta, dy, dz_out, rows, C, part, part_floats, c1c2, dpart, (hipStream_t)stream);
     return rpe_set_error(RPE_ERR_DTYPE, "bn_backward: unsupported dtype");
 }
 
@@ -814,6 +818,8 @@ int rpe_bn_backward_from_dz(int dtype, const void* dz, const void* y, const floa
         return bn_bwd_from_dz_launch<float>(dz, y, mean, invstd, gamma, stats_part, tiles, dgamma, dbeta, dy, rows, C, c1c2, dpart, (hipStream_t)stream);
     if (dtype == RPE_BF16)
         return bn_bwd_from_dz_launch<bf16>(dz, y, mean, invstd, gamma, stats_part, tiles, dgamma, dbeta, dy, rows, C, c1c2, dpart, (hipStream_t)stream);
+    if (dtype == RPE_F16)
+        return bn_bwd_from_dz_launch<f16>(dz, y, mean, invstd, gamma, stats_part, tiles, dgamma, dbeta, dy, rows, C, c1c2, dpart, (hipStream_t)stream);
     return rpe_set_error(RPE_ERR_DTYPE, "bn_backward_from_dz: unsupported dtype");
 }
 
@@ -822,6 +828,7 @@ int rpe_maxpool3x3s2_fwd(int dtype, const void* x, void* out, unsigned char* idx
     const long n = (long)B * Ho * Wo * C;
     if (dtype == RPE_F32) hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)out, idx, B, H, W, C, Ho, Wo);
     else if (dtype == RPE_BF16) hipLaunchKernelGGL((maxpool_fwd_kernel<bf16>), dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out, idx, B, H, W, C, Ho, Wo);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((maxpool_fwd_kernel<f16>), dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)out, idx, B, H, W, C, Ho, Wo);
     else return rpe_set_error(RPE_ERR_DTYPE, "maxpool: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;
@@ -833,6 +840,7 @@ int rpe_maxpool3x3s2_bwd(int dtype, const void* dout, const unsigned char* idx, 
     const long n = (long)B * H * W * C;
     if (dtype == RPE_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)dout, idx, (const float*)addend, (float*)dx, B, H, W, C, Ho, Wo);
     else if (dtype == RPE_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16>), dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout, idx, (const bf16*)addend, (bf16*)dx, B, H, W, C, Ho, Wo);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((maxpool_bwd_kernel<f16>), dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const f16*)dout, idx, (const f16*)addend, (f16*)dx, B, H, W, C, Ho, Wo);
     else return rpe_set_error(RPE_ERR_DTYPE, "maxpool: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;
@@ -841,6 +849,7 @@ int rpe_maxpool3x3s2_bwd(int dtype, const void* dout, const unsigned char* idx, 
 int rpe_avgpool_fwd(int dtype, const void* x, float* out, int B, int HW, int C, void* stream) {
     if (dtype == RPE_F32) hipLaunchKernelGGL((avgpool_fwd_kernel<float>), dim3(ceil_div((long)B * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, out, B, HW, C);
     else if (dtype == RPE_BF16) hipLaunchKernelGGL((avgpool_fwd_kernel<bf16>), dim3(ceil_div((long)B * C / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, out, B, HW, C);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((avgpool_fwd_kernel<f16>), dim3(ceil_div((long)B * C / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, out, B, HW, C);
     else return rpe_set_error(RPE_ERR_DTYPE, "avgpool: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;
@@ -850,6 +859,7 @@ int rpe_avgpool_bwd(int dtype, const float* dout, void* dx, int B, int HW, int C
     const long n = (long)B * HW * C;
     if (dtype == RPE_F32) hipLaunchKernelGGL((avgpool_bwd_kernel<float>), dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, dout, (float*)dx, B, HW, C);
     else if (dtype == RPE_BF16) hipLaunchKernelGGL((avgpool_bwd_kernel<bf16>), dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, dout, (bf16*)dx, B, HW, C);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((avgpool_bwd_kernel<f16>), dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, dout, (f16*)dx, B, HW, C);
     else return rpe_set_error(RPE_ERR_DTYPE, "avgpool: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;
@@ -859,6 +869,7 @@ int rpe_stage_image_nhwc4(int dtype, const float* img_nchw, void* out, int B, in
     const long n = (long)B * H * W;
     if (dtype == RPE_F32) hipLaunchKernelGGL((nchw_to_nhwc4_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, img_nchw, (float*)out, B, H * W);
     else if (dtype == RPE_BF16) hipLaunchKernelGGL((nchw_to_nhwc4_kernel<bf16>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, img_nchw, (bf16*)out, B, H * W);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((nchw_to_nhwc4_kernel<f16>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, img_nchw, (f16*)out, B, H * W);
     else return rpe_set_error(RPE_ERR_DTYPE, "stage_image: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;
@@ -871,6 +882,7 @@ int rpe_stage_frames_u8(int dtype, const unsigned char* frames, void* out, int B
     const float i0 = 1.f / std3_host[0], i1 = 1.f / std3_host[1], i2 = 1.f / std3_host[2];
     if (dtype == RPE_F32) hipLaunchKernelGGL((frames_u8_to_nhwc4_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, frames, (float*)out, B, Hs, Ws, H, W, mean3_host[0], mean3_host[1], mean3_host[2], i0, i1, i2);
     else if (dtype == RPE_BF16) hipLaunchKernelGGL((frames_u8_to_nhwc4_kernel<bf16>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, frames, (bf16*)out, B, Hs, Ws, H, W, mean3_host[0], mean3_host[1], mean3_host[2], i0, i1, i2);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((frames_u8_to_nhwc4_kernel<f16>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, frames, (f16*)out, B, Hs, Ws, H, W, mean3_host[0], mean3_host[1], mean3_host[2], i0, i1, i2);
     else return rpe_set_error(RPE_ERR_DTYPE, "stage_frames_u8: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;
@@ -885,6 +897,7 @@ int rpe_stem_bwd(int dtype, const void* dpool, const unsigned char* pool_idx, co
     const StemAux ax{aux_dout, aux_ld, aux_depth_feat, aux_idx, aux_w};
     if (dtype == RPE_F32) return stem_bwd_launch<float>(dpool, pool_idx, ax, y, scale, shift, mean, invstd, gamma, dgamma, dbeta, dy, B, H, W, part, part_floats, c1c2, dpart, (hipStream_t)stream);
     if (dtype == RPE_BF16) return stem_bwd_launch<bf16>(dpool, pool_idx, ax, y, scale, shift, mean, invstd, gamma, dgamma, dbeta, dy, B, H, W, part, part_floats, c1c2, dpart, (hipStream_t)stream);
+    if (dtype == RPE_F16) return stem_bwd_launch<f16>(dpool, pool_idx, ax, y, scale, shift, mean, invstd, gamma, dgamma, dbeta, dy, B, H, W, part, part_floats, c1c2, dpart, (hipStream_t)stream);
     return rpe_set_error(RPE_ERR_DTYPE, "stem_bwd: unsupported dtype");
 }
 

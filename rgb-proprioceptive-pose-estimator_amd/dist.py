@@ -17,7 +17,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("RPE_DIST_FORCE_INIT")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -52,9 +52,10 @@ class GradSync:
         asynchronously while the earlier layers are still being differentiated; finish() waits for all of them.
     """
 
-    def __init__(self, flat_grad, bucket_bytes=32 << 20, group=None):
+    def __init__(self, flat_grad, bucket_bytes=32 << 20, group=None, reduce_single=False):
         self.flat = flat_grad
         self.group = group
+        self.reduce_single = reduce_single   # issue the collectives even in a 1-rank group (RCCL bring-up test on one GPU)
         self.bucket = max(1, bucket_bytes // flat_grad.element_size())
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._works = []
@@ -66,7 +67,7 @@ class GradSync:
         return [(a, min(hi, a + self.bucket)) for a in range(lo, hi, self.bucket)]
 
     def reduce_range(self, lo, hi):
-        if self.world == 1 or hi <= lo:
+        if (self.world == 1 and not self.reduce_single) or hi <= lo:
             return
         for a, b in self.buckets(lo, hi):
             self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -76,7 +77,7 @@ class GradSync:
             w.wait()
         self._works = []
         if self._slices is not None and self._seen is not None:
-            if self.world > 1 and self._seen != set(self._slices):
+            if (self.world > 1 or self.reduce_single) and self._seen != set(self._slices):
                 raise RuntimeError("GradSync: stages %s were never reduced" % sorted(set(self._slices) - self._seen))
             self._seen = set()
 

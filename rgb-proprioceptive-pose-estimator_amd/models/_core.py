@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..amp import LossScaler
 from ..engine import ResNet50Trunk
 from ..headops import AuxHeadOp, new_rows
 from ..params import ParamArena
@@ -23,10 +24,11 @@ _DEFAULT_COMPUTE_DTYPE = torch.bfloat16
 
 
 def set_default_compute_dtype(dtype):
-    """torch.bfloat16 (fast path; fp32 accumulate + fp32 master weights) or torch.float32 (parity path)."""
+    """torch.bfloat16 (fast path; fp32 accumulate + fp32 master weights), torch.float16 (same, with dynamic loss
+    scaling: amp.py) or torch.float32 (parity path)."""
     global _DEFAULT_COMPUTE_DTYPE
-    if dtype not in (torch.float32, torch.bfloat16):
-        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+    if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise ValueError("compute dtype must be torch.float32, torch.bfloat16 or torch.float16")
     _DEFAULT_COMPUTE_DTYPE = dtype
 
 
@@ -78,6 +80,10 @@ class _ModelFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *d_outs):
         model = ctx.model
+        scaler = model.loss_scaler
+        if scaler is not None:   # fp16 compute: the whole backward signal carries the loss scale (amp.py)
+            sc = scaler.scale_tensor(next(d for d in d_outs if d is not None).device)
+            d_outs = [None if d is None else d * sc for d in d_outs]
         model._backward_impl(list(d_outs))
         model._arena.publish_grads()
         return None, None, None, None, None
@@ -91,6 +97,7 @@ class PoseModelBase(nn.Module):
     def _init_features(self, num_resnet_layers, latent_dim, feature_extract, use_pretrained, feature_layer_nums, use_depth,
                        wrap, register_heads, compute_dtype):
         self.compute_dtype = compute_dtype or default_compute_dtype()
+        self.loss_scaler = LossScaler() if self.compute_dtype == torch.float16 else None
         self.latent_dim = latent_dim
         self.use_depth = use_depth
         self.aux_latent_dim = 0
@@ -147,6 +154,7 @@ class PoseModelBase(nn.Module):
         self.trunk.ensure_layout()
         if self._arena is None or not self._arena.is_current():
             self._arena = ParamArena(self)
+        self._arena.loss_scaler = self.loss_scaler   # FusedAdam unscales / skips through it (amp.py)
         if self.aux_nets is not None and self._aux_op is None or (self._aux_op is not None and self._aux_op.conv_w.device != device):
             conv, inorm = self._aux_modules()
             if not self._heads_registered:

@@ -9,16 +9,16 @@ import ctypes
 
 import torch
 
-from ._lib import RPE_BF16, RPE_F32, BnBwdEpilogue, ConvDesc, lib
+from ._lib import RPE_BF16, RPE_F16, RPE_F32, BnBwdEpilogue, ConvDesc, lib
 
-_DT = {torch.float32: RPE_F32, torch.bfloat16: RPE_BF16}
+_DT = {torch.float32: RPE_F32, torch.bfloat16: RPE_BF16, torch.float16: RPE_F16}
 
 
 def dtype_code(t):
     try:
         return _DT[t if isinstance(t, torch.dtype) else t.dtype]
     except KeyError:
-        raise TypeError("unsupported compute dtype %r (fp32 or bf16)" % (t,))
+        raise TypeError("unsupported compute dtype %r (fp32, bf16 or fp16)" % (t,))
 
 
 def _p(t):

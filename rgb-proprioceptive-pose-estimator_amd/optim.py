@@ -6,6 +6,7 @@ identically zero (e.g. the unused depth head) do not move, matching torch's `gra
 import torch
 
 from . import ops
+from ._lib import lib
 from .params import arena_of
 
 
@@ -42,6 +43,16 @@ class FusedAdam(torch.optim.Optimizer):
         self._step += 1
         g = self.param_groups[0]
         b1, b2 = g["betas"]
+        scaler = getattr(arena, "loss_scaler", None)
+        if scaler is not None:
+            # fp16 compute (amp.py): unscale + finite check, scale update and the skip decision all stay on the device; the
+            # bias-correction step count is the device's count of steps actually taken (self._step counts calls)
+            st = scaler.unscale_and_update(arena.grad)
+            s = ops._stream()
+            for lo, hi in arena.trainable_segments():
+                lib.rpe_adam_step_amp(ops._p(arena.flat[lo:hi]), ops._p(arena.grad[lo:hi]), ops._p(self._m[lo:hi]), ops._p(self._v[lo:hi]), hi - lo,
+                                      g["lr"], b1, b2, g["eps"], ops._p(st), s)
+            return None
         for lo, hi in arena.trainable_segments():
             ops.adam_step(arena.flat[lo:hi], arena.grad[lo:hi], self._m[lo:hi], self._v[lo:hi], g["lr"], b1, b2, g["eps"], self._step)
         return None

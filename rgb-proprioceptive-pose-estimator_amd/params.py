@@ -32,6 +32,7 @@ class ParamArena:
             self.offsets.append(total)
             total += _pad4(p.numel())  # 16-byte aligned segments
         self.numel = total
+        self.loss_scaler = None   # set by fp16 models: gradients in `grad` carry its scale until the optimizer unscales them
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         for p, off in zip(params, self.offsets):

@@ -5,7 +5,7 @@ Keeps every flag of the reference's scripts/train_model.py:17-47 (names, types, 
 dispatch (:158-218), criterion dict (:100-105), Adam (:228) and train() call (:248-259).  The Robosuite environment
 the reference builds at import time (:84-97) is replaced by seeded synthetic Robosuite-shaped episodes; flags that only
 configure the simulator (--controller, --robots, --use_placement_initializer, --motion) are accepted and recorded.
-Added flags: --dtype {bf16,f32}, --optimizer {fused,torch}, --episodes_seed.
+Added flags: --dtype {bf16,f16,f32}, --optimizer {fused,torch}, --episodes_seed.
 
 Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 scripts/train_model.py ...`;
 episodes are sharded over ranks and gradients SUM-all-reduced over RCCL.
@@ -54,11 +54,15 @@ def build_parser():
     p.add_argument("--load_checkpoint", action="store_true", help="Whether to load prior trained model")
     p.add_argument("--checkpoint_model_path", type=str, default="../log/runs/model.pth", help="Path to checkpoint .pth file to load into model")
     # additions
-    p.add_argument("--dtype", choices=["bf16", "f32"], default="bf16", help="compute dtype of the conv trunk (fp32 accumulate either way)")
+    p.add_argument("--dtype", choices=["bf16", "f16", "f32"], default="bf16",
+                   help="compute dtype of the conv trunk (fp32 accumulate either way; f16 adds dynamic loss scaling and needs --optimizer fused)")
     p.add_argument("--optimizer", choices=["fused", "torch"], default="fused", help="FusedAdam (one HIP kernel) or torch.optim.Adam")
     p.add_argument("--episodes_seed", type=int, default=1234, help="seed of the synthetic episode generator")
     p.add_argument("--no_save", action="store_true", help="do not write the best-validation checkpoint")
     return p
+
+
+DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 
 
 def build_model(args, compute_dtype):
@@ -109,9 +113,11 @@ def main(argv=None):
     crit = lambda: PoseDistanceLoss(distance_metric=args.distance_metric, scale_factor=args.loss_scale_factor, alpha=args.alpha, mode=args.loss_mode)
     criterion = {"x0_loss": crit(), "x1_loss": crit(), "obj_loss": crit(), "val_loss": PoseDistanceLoss(mode="val")}
     torch.manual_seed(0)
-    model = build_model(args, torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    model = build_model(args, DTYPES[args.dtype])
     if args.load_checkpoint:
         model.load_state_dict(torch.load(args.checkpoint_model_path, map_location="cpu"))
+    if args.dtype == "f16" and args.optimizer != "fused":
+        raise SystemExit("--dtype f16 needs --optimizer fused: the loss-scale unscale / skip logic lives in FusedAdam.step (amp.py)")
     opt_cls = FusedAdam if args.optimizer == "fused" else torch.optim.Adam
     optimizer = opt_cls(model.parameters(), lr=args.lr)
     dataset = SyntheticEpisodeDataset(horizon=args.horizon, use_depth=args.use_depth, obj_name=args.obj_name, is_two_arm="TwoArm" in args.env,

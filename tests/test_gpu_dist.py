@@ -72,3 +72,60 @@ def test_staged_allreduce_two_ranks_one_gpu():
         assert ok, "stage slices do not tile the arena"
         assert err < 1e-4, "staged all-reduce differs from the one-shot reduction: %g" % err
         assert moved > 1e-3, "gradients were not reduced (staged == local)"
+
+
+def _rccl_worker(port, q):
+    # a fresh process that has not touched the GPU yet: RCCL ("nccl" on ROCm) with ONE rank -- the communicator is created and
+    # every bucket of the staged gradient reduction runs through ncclAllReduce on the device, which is what an N-GPU run
+    # does per rank (no 8-GPU node is available to this test)
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RPE_DIST_FORCE_INIT="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from rgb_proprioceptive_pose_estimator_amd import models as M
+    from rgb_proprioceptive_pose_estimator_amd.dist import GradSync, broadcast_parameters, init_from_env
+    from rgb_proprioceptive_pose_estimator_amd.optim import FusedAdam
+    from rgb_proprioceptive_pose_estimator_amd.util.data_utils import synthetic_batch
+    from rgb_proprioceptive_pose_estimator_amd.util.learn_utils import train_step
+
+    rank, world, local = init_from_env()          # backend chosen by dist.py: "nccl" when a GPU is visible
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.manual_seed(0)
+    model = M.NaiveObjectStateEstimator("cube", [32], 50, 32, False, (9,), False, False, False, compute_dtype=torch.bfloat16).cuda().train()
+    model._materialize(dev)
+    dist.broadcast(model._arena.flat, 0)          # RCCL broadcast (what broadcast_parameters issues for world > 1)
+    crit = M.PoseDistanceLoss("combined", 1.0, 0.5, 1e-4, "pose")
+    criterion = {"obj_loss": crit, "val_loss": M.PoseDistanceLoss(mode="val")}
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    b = synthetic_batch((4,), 5)
+    batch = (b["img"], None, b["x0bar"], b["x0"], None, b["obj"])
+    crit(model(b["img"], None, b["x0bar"]), b["obj"]).backward()
+    local_grad = model._arena.grad.clone()
+    sync = GradSync(model._arena.grad, bucket_bytes=8 << 20, reduce_single=True).attach(model)
+    n_calls = [0]
+    orig = sync.reduce_range
+
+    def counted(lo, hi):
+        n_calls[0] += len(sync.buckets(lo, hi)) if hi > lo else 0
+        return orig(lo, hi)
+
+    sync.reduce_range = counted
+    loss, _, _ = train_step(model, batch, criterion, opt, True, "train", sync)   # staged all-reduce under the backward, then Adam
+    torch.cuda.synchronize()
+    # a 1-rank SUM leaves the gradients as they are (up to fp32 atomic-order noise between two backward passes)
+    err = ((model._arena.grad - local_grad).norm() / local_grad.norm()).item()
+    q.put((dist.get_backend(), n_calls[0], err, bool(torch.isfinite(loss).item())))
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank_staged_step():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    backend, calls, err, finite = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert backend == "nccl" and calls >= 5 and finite
+    assert err < 1e-4
