@@ -244,6 +244,35 @@ def synth_batch(lead, seed, hw=224, with_depth=False):
 # ResNet-50 (functional).  `sd` maps key -> tensor; BN running stats are updated
 # in place in train mode, exactly as nn.BatchNorm2d does.
 # ----------------------------------------------------------------------------
+# Reduced-precision emulation (test yardstick only).  With EMULATE set to torch.bfloat16 / torch.float16, resnet50_forward
+# rounds what the HIP trunk keeps in that type -- the staged image, the conv weight copies, every raw conv output y and every
+# BN(+residual)(+ReLU) output a -- and, in the backward, the gradients flowing through the same points (straight-through
+# rounding).  16-bit gradients of this 50-layer train-mode-BN network at random initialisation are dominated by amplified
+# rounding noise (the BN backward subtracts the common-mode part of the gradient at every layer, the rounding noise stays);
+# the emulation tells a parity test how far ANY implementation with these storage types lands from the fp64 gradient.
+EMULATE = None
+
+
+class _RoundSTE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dt):
+        ctx.dt = dt
+        return x.to(dt).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dt).to(g.dtype), None
+
+
+def _q(x):
+    return x if EMULATE is None else _RoundSTE.apply(x, EMULATE)
+
+
+def _qw(w):
+    """compute-dtype copy of an fp32 master weight: rounded in the forward, the gradient reaches the master unrounded"""
+    return w if EMULATE is None else w + (w.to(EMULATE).to(w.dtype) - w).detach()
+
+
 def _bn(sd, name, x, train):
     rm, rv = sd[name + ".running_mean"], sd[name + ".running_var"]
     if train:
@@ -253,21 +282,22 @@ def _bn(sd, name, x, train):
 
 def resnet50_forward(sd, pre, x, train):
     """Returns (latent features (B, L), early feature relu(bn1(conv1 x)) (B,64,H/2,W/2))."""
-    y = F.conv2d(x, sd[pre + "conv1.weight"], None, 2, 3)
-    early = F.relu(_bn(sd, pre + "bn1", y, train))
+    x = x if EMULATE is None else x.to(EMULATE).to(x.dtype)
+    y = _q(F.conv2d(x, _qw(sd[pre + "conv1.weight"]), None, 2, 3))
+    early = _q(F.relu(_bn(sd, pre + "bn1", y, train)))
     y = F.max_pool2d(early, 3, 2, 1)
     for li, (planes, nblk, stride) in enumerate(STAGES, start=1):
         for b in range(nblk):
             p = "%slayer%d.%d" % (pre, li, b)
             s = stride if b == 0 else 1
-            o = F.relu(_bn(sd, p + ".bn1", F.conv2d(y, sd[p + ".conv1.weight"]), train))
-            o = F.relu(_bn(sd, p + ".bn2", F.conv2d(o, sd[p + ".conv2.weight"], None, s, 1), train))
-            o = _bn(sd, p + ".bn3", F.conv2d(o, sd[p + ".conv3.weight"]), train)
+            o = _q(F.relu(_bn(sd, p + ".bn1", _q(F.conv2d(y, _qw(sd[p + ".conv1.weight"]))), train)))
+            o = _q(F.relu(_bn(sd, p + ".bn2", _q(F.conv2d(o, _qw(sd[p + ".conv2.weight"]), None, s, 1)), train)))
+            o = _bn(sd, p + ".bn3", _q(F.conv2d(o, _qw(sd[p + ".conv3.weight"]))), train)
             if b == 0:
-                idn = _bn(sd, p + ".downsample.1", F.conv2d(y, sd[p + ".downsample.0.weight"], None, s), train)
+                idn = _q(_bn(sd, p + ".downsample.1", _q(F.conv2d(y, _qw(sd[p + ".downsample.0.weight"]), None, s)), train))
             else:
                 idn = y
-            y = F.relu(o + idn)
+            y = _q(F.relu(o + idn))
     y = F.adaptive_avg_pool2d(y, 1).flatten(1)
     return F.linear(y, sd[pre + "fc.weight"], sd[pre + "fc.bias"]), early
 
