@@ -90,6 +90,12 @@ int rpe_conv2d_dgrad_bn(const rpe_conv_desc* d, int dtype, const void* dy, const
                         const rpe_bn_bwd_epilogue* bn, void* stream);
 /* dw_krsc[out_c][kh][kw][in_c] (fp32) += x (*) dy.  Atomic accumulation: zero it first. */
 int rpe_conv2d_wgrad(const rpe_conv_desc* d, int dtype, const void* x, const void* dy, float* dw_krsc, void* stream);
+/* Deterministic form: dw_krsc = x (*) dy (OVERWRITTEN, no zeroing needed).  Every workgroup stores its fp32 tile into
+ * `workspace` (>= rpe_conv2d_wgrad_workspace_bytes(), 16-byte aligned, caller-owned, free again when the call's work has run)
+ * and a second launch sums the tiles in a fixed order: bitwise reproducible, no float atomics. */
+long rpe_conv2d_wgrad_workspace_bytes(const rpe_conv_desc* d, int dtype);
+int rpe_conv2d_wgrad_det(const rpe_conv_desc* d, int dtype, const void* x, const void* dy, float* dw_krsc, void* workspace, long workspace_bytes,
+                         void* stream);
 
 /* ResNet stem conv1 (3->64, 7x7 / 2, pad 3) on the NHWC4 image produced by
  * rpe_stage_image_nhwc4; w_packed = [64][8][8][4] from rpe_pack_stem_weight. */
@@ -97,6 +103,10 @@ int rpe_stem_conv_fwd(int dtype, const void* x4, const void* w_packed, void* y, 
 int rpe_stem_conv_fwd_affine(int dtype, const void* x4, const void* w_packed, void* out, const float* bias, int relu, int B, int H, int W,
                              void* stream);
 int rpe_stem_conv_wgrad(int dtype, const void* x4, const void* dy, float* dw_packed, int B, int H, int W, void* stream);
+/* deterministic form (see rpe_conv2d_wgrad_det): dw_packed is overwritten */
+long rpe_stem_conv_wgrad_workspace_bytes(int dtype, int B, int H, int W);
+int rpe_stem_conv_wgrad_det(int dtype, const void* x4, const void* dy, float* dw_packed, int B, int H, int W, void* workspace, long workspace_bytes,
+                            void* stream);
 
 /* weight layouts.  w_krsc_f32 is the fp32 master in channels_last storage. */
 int rpe_pack_conv_weight(int dtype, const float* w_krsc, void* w_fwd, void* w_dgrad, int Co, int R, int S, int Ci, void* stream);
@@ -200,6 +210,10 @@ int rpe_linear_fwd(int dtype, const void* x, int ldx, const void* w, int ldw, co
                    int relu, const void* addend, int ld_add, void* stream);
 /* dw[N][K] (fp32, ld lddw) += dy[M][N]^T x[M][K]  (atomic accumulation) */
 int rpe_linear_wgrad(int dtype, const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int M, int N, int K, void* stream);
+/* deterministic form (see rpe_conv2d_wgrad_det): dw = dy^T x, or dw += dy^T x when `accumulate` (one fixed-order add per element) */
+long rpe_linear_wgrad_workspace_bytes(int dtype, int M, int N, int K);
+int rpe_linear_wgrad_det(int dtype, const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int M, int N, int K, int accumulate,
+                         void* workspace, long workspace_bytes, void* stream);
 int rpe_transpose_f32(const float* in, float* out, int rows, int cols, int ldi, int ldo, void* stream);
 int rpe_relu_bwd(const float* out, const float* dy, float* dx, long n, void* stream);
 int rpe_colsum(const float* x, long rows, int cols, int ld, float* out, int accumulate, void* stream);

@@ -47,9 +47,13 @@ _SPEC = {
     "rpe_conv2d_dgrad_bn": (I, [PD, I, P, P, P, P, POINTER(BnBwdEpilogue), P]),
     "rpe_bn_backward_from_dz": (I, [I, P, P, P, P, P, P, I, P, P, P, L, I, P, P, P]),
     "rpe_conv2d_wgrad": (I, [PD, I, P, P, P, P]),
+    "rpe_conv2d_wgrad_workspace_bytes": (L, [PD, I]),
+    "rpe_conv2d_wgrad_det": (I, [PD, I, P, P, P, P, L, P]),
     "rpe_stem_conv_fwd": (I, [I, P, P, P, P, I, I, I, P]),
     "rpe_stem_conv_fwd_affine": (I, [I, P, P, P, P, I, I, I, I, P]),
     "rpe_stem_conv_wgrad": (I, [I, P, P, P, I, I, I, P]),
+    "rpe_stem_conv_wgrad_workspace_bytes": (L, [I, I, I, I]),
+    "rpe_stem_conv_wgrad_det": (I, [I, P, P, P, I, I, I, P, L, P]),
     "rpe_pack_conv_weight": (I, [I, P, P, P, I, I, I, I, P]),
     "rpe_pack_conv_weights_multi": (I, [I, P, I, L, P]),
     "rpe_pack_stem_weight": (I, [I, P, P, P, P]),
@@ -72,6 +76,8 @@ _SPEC = {
     "rpe_depth_head_bwd": (I, [P, P, L, P, P, P]),
     "rpe_linear_fwd": (I, [I, P, I, P, I, P, P, I, I, I, I, I, P, I, P]),
     "rpe_linear_wgrad": (I, [I, P, I, P, I, P, I, I, I, I, P]),
+    "rpe_linear_wgrad_workspace_bytes": (L, [I, I, I, I]),
+    "rpe_linear_wgrad_det": (I, [I, P, I, P, I, P, I, I, I, I, I, P, L, P]),
     "rpe_transpose_f32": (I, [P, P, I, I, I, I, P]),
     "rpe_relu_bwd": (I, [P, P, P, L, P]),
     "rpe_colsum": (I, [P, L, I, I, P, I, P]),

@@ -8,7 +8,7 @@
 
 namespace rpe {
 template <typename T> int launch_nt(NTArgs<T>& a, int mode, hipStream_t s);
-template <typename T> int launch_tn(TNArgs<T>& a, int mode, hipStream_t s);
+template <typename T> int launch_tn(TNArgs<T>& a, int mode, hipStream_t s, long* slab_query = nullptr);
 }  // namespace rpe
 using namespace rpe;
 
@@ -101,22 +101,24 @@ static int conv_dgrad_t(const rpe_conv_desc* d, const void* dy, const void* w_cr
     return launch_nt<T>(a, MODE_CONV, s);
 }
 
+// slab / slab_bytes: workspace of the deterministic form (null: atomic accumulation); slab_query: only report the bytes needed
 template <typename T>
-static int conv_wgrad_t(const rpe_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t s) {
+static int conv_wgrad_t(const rpe_conv_desc* d, const void* x, const void* dy, float* dw, void* slab, long slab_bytes, long* slab_query, hipStream_t s) {
     const int Ho = out_dim(d->in_h, d->kh, d->stride, d->pad), Wo = out_dim(d->in_w, d->kw, d->stride, d->pad);
     TNArgs<T> a;
     memset(&a, 0, sizeof(a));
     a.P = (const T*)dy; a.Q = (const T*)x; a.D = dw;
+    a.slab = (float*)slab; a.slab_bytes = slab_bytes;
     a.M = d->batch * Ho * Wo; a.I = d->out_c; a.J = d->kh * d->kw * d->in_c;
     a.ldp = d->out_c; a.ldq = d->in_c; a.ldd = a.J;
-    if (is_dense(d)) return launch_tn<T>(a, MODE_DENSE, s);
+    if (is_dense(d)) return launch_tn<T>(a, MODE_DENSE, s, slab_query);
     Gather& g = a.g;
     g.H = d->in_h; g.W = d->in_w; g.C = d->in_c; g.Ho = Ho; g.Wo = Wo; g.R = d->kh; g.S = d->kw;
     g.sn = d->stride; g.sd_shift = 0; g.base_h = -d->pad; g.base_w = -d->pad; g.tap_sign = 1;
     g.div_hw = make_fastdiv(Ho * Wo); g.div_w = make_fastdiv(Wo);
     g.img_stride = (long)d->in_h * d->in_w * d->in_c;
     a.q_elems = (long)d->batch * g.img_stride;
-    return launch_tn<T>(a, MODE_CONV, s);
+    return launch_tn<T>(a, MODE_CONV, s, slab_query);
 }
 
 static void stem_gather(Gather& g, int H, int W) {
@@ -142,14 +144,15 @@ static int stem_fwd_t(const void* x4, const void* w, void* y, float* stats, cons
 }
 
 template <typename T>
-static int stem_wgrad_t(const void* x4, const void* dy, float* dw_packed, int B, int H, int W, hipStream_t s) {
+static int stem_wgrad_t(const void* x4, const void* dy, float* dw_packed, int B, int H, int W, void* slab, long slab_bytes, long* slab_query, hipStream_t s) {
     TNArgs<T> a;
     memset(&a, 0, sizeof(a));
     stem_gather(a.g, H, W);
     a.P = (const T*)dy; a.Q = (const T*)x4; a.D = dw_packed;
+    a.slab = (float*)slab; a.slab_bytes = slab_bytes;
     a.M = B * a.g.Ho * a.g.Wo; a.I = 64; a.J = 224;   // (the 8th kernel row of the packed layout stays zero)
     a.ldp = 64; a.ldq = 4; a.ldd = 256;
-    return launch_tn<T>(a, MODE_STEM, s);
+    return launch_tn<T>(a, MODE_STEM, s, slab_query);
 }
 
 template <typename T>
@@ -165,12 +168,14 @@ static int linear_fwd_t(const void* x, int ldx, const void* w, int ldw, const fl
 }
 
 template <typename T>
-static int linear_wgrad_t(const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int M, int N, int K, hipStream_t s) {
+static int linear_wgrad_t(const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int M, int N, int K, void* slab, long slab_bytes,
+                          int accumulate, long* slab_query, hipStream_t s) {
     TNArgs<T> a;
     memset(&a, 0, sizeof(a));
     a.P = (const T*)dy; a.Q = (const T*)x; a.D = dw;
+    a.slab = (float*)slab; a.slab_bytes = slab_bytes; a.accumulate = accumulate;
     a.M = M; a.I = N; a.J = K; a.ldp = lddy; a.ldq = ldx; a.ldd = lddw;
-    return launch_tn<T>(a, MODE_DENSE, s);
+    return launch_tn<T>(a, MODE_DENSE, s, slab_query);
 }
 
 #define DISPATCH(dtype, fn, ...)                                          \
@@ -224,7 +229,28 @@ int rpe_conv2d_dgrad_bn(const rpe_conv_desc* d, int dtype, const void* dy, const
 
 int rpe_conv2d_wgrad(const rpe_conv_desc* d, int dtype, const void* x, const void* dy, float* dw_krsc, void* stream) {
     if (int e = check_desc(d)) return e;
-    DISPATCH(dtype, conv_wgrad_t, d, x, dy, dw_krsc, (hipStream_t)stream);
+    DISPATCH(dtype, conv_wgrad_t, d, x, dy, dw_krsc, nullptr, 0L, nullptr, (hipStream_t)stream);
+}
+
+static int wgrad_ws_query(const rpe_conv_desc* d, int dtype, long* bytes) {
+    DISPATCH(dtype, conv_wgrad_t, d, nullptr, nullptr, nullptr, nullptr, 0L, bytes, nullptr);
+}
+
+long rpe_conv2d_wgrad_workspace_bytes(const rpe_conv_desc* d, int dtype) {
+    if (check_desc(d)) return -1;
+    long bytes = 0;
+    if (wgrad_ws_query(d, dtype, &bytes)) return -1;
+    return bytes;
+}
+
+int rpe_conv2d_wgrad_det(const rpe_conv_desc* d, int dtype, const void* x, const void* dy, float* dw_krsc, void* workspace, long workspace_bytes,
+                         void* stream) {
+    if (int e = check_desc(d)) return e;
+    if (!workspace) return rpe_set_error(RPE_ERR_WORKSPACE, "conv2d_wgrad_det: null workspace");
+    long need = 0;
+    if (int e = wgrad_ws_query(d, dtype, &need)) return e;
+    if (workspace_bytes < need) return rpe_set_error(RPE_ERR_WORKSPACE, "conv2d_wgrad_det: workspace smaller than rpe_conv2d_wgrad_workspace_bytes()");
+    DISPATCH(dtype, conv_wgrad_t, d, x, dy, dw_krsc, workspace, workspace_bytes, nullptr, (hipStream_t)stream);
 }
 
 int rpe_stem_conv_fwd(int dtype, const void* x4, const void* w_packed, void* y, float* stats_part, int B, int H, int W, void* stream) {
@@ -240,7 +266,24 @@ int rpe_stem_conv_fwd_affine(int dtype, const void* x4, const void* w_packed, vo
 
 int rpe_stem_conv_wgrad(int dtype, const void* x4, const void* dy, float* dw_packed, int B, int H, int W, void* stream) {
     if (B <= 0 || H < 7 || W < 7) return rpe_set_error(RPE_ERR_SHAPE, "stem_conv: bad shape");
-    DISPATCH(dtype, stem_wgrad_t, x4, dy, dw_packed, B, H, W, (hipStream_t)stream);
+    DISPATCH(dtype, stem_wgrad_t, x4, dy, dw_packed, B, H, W, nullptr, 0L, nullptr, (hipStream_t)stream);
+}
+
+static int stem_ws_query(int dtype, int B, int H, int W, long* bytes) { DISPATCH(dtype, stem_wgrad_t, nullptr, nullptr, nullptr, B, H, W, nullptr, 0L, bytes, nullptr); }
+
+long rpe_stem_conv_wgrad_workspace_bytes(int dtype, int B, int H, int W) {
+    long bytes = 0;
+    if (B <= 0 || H < 7 || W < 7 || stem_ws_query(dtype, B, H, W, &bytes)) return -1;
+    return bytes;
+}
+
+int rpe_stem_conv_wgrad_det(int dtype, const void* x4, const void* dy, float* dw_packed, int B, int H, int W, void* workspace, long workspace_bytes,
+                            void* stream) {
+    if (B <= 0 || H < 7 || W < 7) return rpe_set_error(RPE_ERR_SHAPE, "stem_conv: bad shape");
+    long need = 0;
+    if (int e = stem_ws_query(dtype, B, H, W, &need)) return e;
+    if (!workspace || workspace_bytes < need) return rpe_set_error(RPE_ERR_WORKSPACE, "stem_conv_wgrad_det: workspace smaller than rpe_stem_conv_wgrad_workspace_bytes()");
+    DISPATCH(dtype, stem_wgrad_t, x4, dy, dw_packed, B, H, W, workspace, workspace_bytes, nullptr, (hipStream_t)stream);
 }
 
 int rpe_linear_fwd(int dtype, const void* x, int ldx, const void* w, int ldw, const float* bias, void* y, int ldy, int M, int N, int K,
@@ -249,7 +292,25 @@ int rpe_linear_fwd(int dtype, const void* x, int ldx, const void* w, int ldw, co
 }
 
 int rpe_linear_wgrad(int dtype, const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int M, int N, int K, void* stream) {
-    DISPATCH(dtype, linear_wgrad_t, dy, lddy, x, ldx, dw, lddw, M, N, K, (hipStream_t)stream);
+    DISPATCH(dtype, linear_wgrad_t, dy, lddy, x, ldx, dw, lddw, M, N, K, nullptr, 0L, 1, nullptr, (hipStream_t)stream);
+}
+
+static int linear_ws_query(int dtype, int M, int N, int K, long* bytes) {
+    DISPATCH(dtype, linear_wgrad_t, nullptr, N, nullptr, K, nullptr, K, M, N, K, nullptr, 0L, 0, bytes, nullptr);
+}
+
+long rpe_linear_wgrad_workspace_bytes(int dtype, int M, int N, int K) {
+    long bytes = 0;
+    if (M <= 0 || N <= 0 || K <= 0 || linear_ws_query(dtype, M, N, K, &bytes)) return -1;
+    return bytes;
+}
+
+int rpe_linear_wgrad_det(int dtype, const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int M, int N, int K, int accumulate,
+                         void* workspace, long workspace_bytes, void* stream) {
+    long need = 0;
+    if (int e = linear_ws_query(dtype, M, N, K, &need)) return e;
+    if (!workspace || workspace_bytes < need) return rpe_set_error(RPE_ERR_WORKSPACE, "linear_wgrad_det: workspace smaller than rpe_linear_wgrad_workspace_bytes()");
+    DISPATCH(dtype, linear_wgrad_t, dy, lddy, x, ldx, dw, lddw, M, N, K, workspace, workspace_bytes, accumulate, nullptr, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -86,6 +86,10 @@ struct rpe_resnet50 {
     // aux-head gradient in compact form for the fused stem backward (rpe_resnet50_set_aux_grad)
     const float* aux_dout = nullptr; long aux_ld = 0; const float* aux_df = nullptr; const unsigned char* aux_idx = nullptr; const float* aux_w = nullptr;
     float* stem_dw = nullptr;    // [64][8][8][4]
+    void* main_slab = nullptr;   // the same for the two weight gradients that run on the caller's stream (stem conv, fc)
+    long main_slab_bytes = 0;
+    void* wg_slab = nullptr;     // per-workgroup fp32 tiles of the deterministic weight-gradient form (one launch at a time: side stream order)
+    long wg_slab_bytes = 0;
     std::vector<Named> named;
     int train_mode = 0;
     int fused_tiles = 0;
@@ -250,6 +254,17 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
     want(e, (void**)&e->dpart, RPE_BN_DPART_DOUBLES(2048) * 8);
     want(e, (void**)&e->dpart2, RPE_BN_DPART_DOUBLES(2048) * 8);
     want(e, (void**)&e->stem_dw, 64L * 256 * 4);
+    if (!getenv("RPE_WGRAD_ATOMIC")) {
+        for (size_t i = 1; i < e->convs.size(); ++i) {
+            const long b = rpe_conv2d_wgrad_workspace_bytes(&e->convs[i].d, dtype);
+            if (b > e->wg_slab_bytes) e->wg_slab_bytes = b;
+        }
+        if (e->wg_slab_bytes > 0) want(e, &e->wg_slab, e->wg_slab_bytes);
+        e->main_slab_bytes = rpe_stem_conv_wgrad_workspace_bytes(dtype, batch, height, width);
+        const long fcb = rpe_linear_wgrad_workspace_bytes(RPE_F32, batch, latent_dim, 2048);
+        if (fcb > e->main_slab_bytes) e->main_slab_bytes = fcb;
+        if (e->main_slab_bytes > 0) want(e, &e->main_slab, e->main_slab_bytes);
+    }
     want(e, (void**)&e->pack_tab, 64L * sizeof(rpe_pack_desc));
     want(e, (void**)&e->pack_tab_fold, 64L * sizeof(rpe_pack_desc));
     for (auto& c : e->convs) {
@@ -606,9 +621,13 @@ static int wgrad(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, void*
         HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
         run = e->side;
     }
-    if (!e->gspan_lo) HIPTRY(hipMemsetAsync(dw, 0, (size_t)e->pnumel[c.p_w] * 4, run));
     e->pending_flops = conv_flops(c);
     e->pending_bytes = conv_in_bytes(e, c) + conv_out_bytes(e, c);
+    if (e->wg_slab) {   // deterministic: per-workgroup slabs + fixed-order sum, overwrites dw (launches on `run` are ordered: one slab buffer)
+        PROF(e, RPE_PROF_CONV_WGRAD, run, rpe_conv2d_wgrad_det(&c.d, e->dtype, x, dy, dw, e->wg_slab, e->wg_slab_bytes, run));
+        return 0;
+    }
+    if (!e->gspan_lo) HIPTRY(hipMemsetAsync(dw, 0, (size_t)e->pnumel[c.p_w] * 4, run));
     PROF(e, RPE_PROF_CONV_WGRAD, run, rpe_conv2d_wgrad(&c.d, e->dtype, x, dy, dw, run));
     return 0;
 }
@@ -635,8 +654,12 @@ extern "C" int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_fea
     if (e->gspan_lo) HIPTRY(hipMemsetAsync(e->gspan_lo, 0, e->gspan_bytes, s));
     // fc
     float* dWfc = e->grads[np - 2];
-    if (!e->gspan_lo) HIPTRY(hipMemsetAsync(dWfc, 0, (size_t)e->latent * 2048 * 4, s));
-    TRY(rpe_linear_wgrad(RPE_F32, d_features, (int)ld_d_features, e->pooled, 2048, dWfc, 2048, e->B, e->latent, 2048, stream));
+    if (e->main_slab) {
+        TRY(rpe_linear_wgrad_det(RPE_F32, d_features, (int)ld_d_features, e->pooled, 2048, dWfc, 2048, e->B, e->latent, 2048, 0, e->main_slab, e->main_slab_bytes, stream));
+    } else {
+        if (!e->gspan_lo) HIPTRY(hipMemsetAsync(dWfc, 0, (size_t)e->latent * 2048 * 4, s));
+        TRY(rpe_linear_wgrad(RPE_F32, d_features, (int)ld_d_features, e->pooled, 2048, dWfc, 2048, e->B, e->latent, 2048, stream));
+    }
     TRY(rpe_colsum(d_features, e->B, e->latent, (int)ld_d_features, e->grads[np - 1], 0, stream));
     // d_pooled[B][2048] = d_features[B][latent] * Wfc[latent][2048]  ==  NT with weight fc_wt [2048][latent_pad].
     // K runs to latent_pad: the extra columns of d_features (whatever the caller keeps there) meet zero weights.
@@ -720,8 +743,9 @@ extern "C" int rpe_resnet50_backward_end(rpe_resnet50_t* e, int use_d_early, voi
                                                       e->bwd_part, e->bwd_part_floats, e->c1c2, e->dpart, stream));
     }
     e->aux_dout = nullptr;
-    if (hipError_t he = hipMemsetAsync(e->stem_dw, 0, 64 * 256 * 4, s)) return rpe_set_error_hip(he, __FILE__, __LINE__);
-    PROF(e, RPE_PROF_CONV_WGRAD, stream, rpe_stem_conv_wgrad(e->dtype, e->x4, g1, e->stem_dw, e->B, e->H, e->W, stream));
+    if (hipError_t he = hipMemsetAsync(e->stem_dw, 0, 64 * 256 * 4, s)) return rpe_set_error_hip(he, __FILE__, __LINE__);   // (the 8th kernel row stays zero)
+    if (e->main_slab) PROF(e, RPE_PROF_CONV_WGRAD, stream, rpe_stem_conv_wgrad_det(e->dtype, e->x4, g1, e->stem_dw, e->B, e->H, e->W, e->main_slab, e->main_slab_bytes, stream));
+    else PROF(e, RPE_PROF_CONV_WGRAD, stream, rpe_stem_conv_wgrad(e->dtype, e->x4, g1, e->stem_dw, e->B, e->H, e->W, stream));
     TRY(rpe_unpack_stem_grad(e->stem_dw, e->grads[st.p_w], stream));
     TRY(join_side(e, s));
     e->bwd_next = -2;

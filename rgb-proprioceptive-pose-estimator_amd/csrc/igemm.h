@@ -58,7 +58,10 @@ template <typename T> struct NTArgs {
 template <typename T> struct TNArgs {
     const T* P;     // [M][ldp]   (dy / upstream gradient), columns i (Cout)
     const T* Q;     // im2col source (dense [M][ldq] or NHWC tensor described by g), columns j (K)
-    float* D;       // [I][ldd] fp32, accumulated with atomics: D[i][j] += sum_m P[m][i] * Q[m][j]
+    float* D;       // [I][ldd] fp32: D[i][j] += sum_m P[m][i] * Q[m][j] with atomics, or (slab mode) D[i][j] = that sum, overwritten
+    float* slab;    // optional workspace of >= slab_bytes (16-byte aligned): per-workgroup fp32 tiles, summed by tn_reduce_kernel in a
+    long slab_bytes;  // fixed order (deterministic, no float atomics); null -> atomic accumulation into D
+    int accumulate;   // slab mode: D += sum instead of D = sum
     int M, I, J;
     int ldp, ldq, ldd;
     Gather g;

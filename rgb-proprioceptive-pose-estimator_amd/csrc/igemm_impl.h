@@ -566,11 +566,16 @@ template <typename T, int CPR> __device__ __forceinline__ int tn_swz(int row) {
     return (((row >> 1) & 1) | ((row >> 2) & 2)) << 1;                          // 128-B rows (parity picks the half)
 }
 
-template <typename T, int BI, int BJ, int MODE, bool USE_DMA = true>
+// KSUB_: MFMA K sub-steps (32 bf16 / 16 f32 rows each) per staged tile; NSLOT: ring depth (NSLOT-1 tiles in flight behind a counted
+// vmcnt, as in nt_kernel -- the round-1 version kept ONE tile in flight and drained vmcnt to 0 every step: 1.2 TB/s on the
+// HBM-bound 1x1 layers); SLAB: every workgroup stores its fp32 tile to its own slab (plain 16-byte stores in fragment order) and
+// tn_reduce_kernel sums the slabs in a fixed order -- deterministic, and no float atomics (1.3 TB/s chip-wide, 23x write
+// amplification in round 1).
+template <typename T, int BI, int BJ, int MODE, bool USE_DMA = true, int KSUB_ = 2, int NSLOT = 2, bool SLAB = false>
 __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
     constexpr bool DMA = USE_DMA && MODE != MODE_STEM;  // LDS-DMA staging through buffer descriptors; stem: registers
     constexpr int CE = Elem<T>::kChunk, ES = (int)sizeof(T);
-    constexpr int KSUB = DMA ? 2 : 1;                  // MFMA K sub-steps (4 chunks = 32 bf16 / 16 f32 rows each) per staged tile
+    constexpr int KSUB = DMA ? KSUB_ : 1;              // MFMA K sub-steps (4 chunks = 32 bf16 / 16 f32 rows each) per staged tile
     constexpr int BMK = 4 * CE * KSUB;
     constexpr int WI = BI / 2, WJ = BJ / 2, FI = WI / 16, FJ = WJ / 16;
     constexpr int CPI = BI / CE, CPJ = BJ / CE;        // chunks per row
@@ -578,7 +583,8 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
     constexpr int NPI = (BMK + RPI - 1) / RPI, NPJ = (BMK + RPJ - 1) / RPJ;
     constexpr int PT = BMK * CPI, QT = BMK * CPJ;      // tile sizes in 16-byte units
     constexpr int STAGE = PT + QT;
-    constexpr int NSTAGE = 2;                          // DMA: 2-slot ring, the next tile in flight while this one is multiplied
+    constexpr int NSTAGE = DMA ? NSLOT : 2;            // DMA: ring of NSLOT slots, NSLOT-1 tiles in flight while one is multiplied
+    static_assert(NSLOT >= 2 && NSLOT <= 4, "ring depth 2..4");
     static_assert(BMK % RPI == 0 && BMK % RPJ == 0, "tile rows must split evenly over the passes");
     __shared__ u32x4 lds[NSTAGE * STAGE];
 
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
     const int i0 = tile_i * BI, j0 = tile_j * BJ;
     const int m_begin = split * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
-    if (m_begin >= m_end) return;
+    if (!SLAB && m_begin >= m_end) return;             // (slab mode: an empty split still owes its slab of zeros)
     const Gather& g = p.g;
 
     // thread -> (row, LDS slot) of pass i: row = tid / CP + i * RP, slot = tid % CP (64 consecutive chunks per wave: the
@@ -736,7 +742,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
 #pragma unroll
         for (int b = 0; b < FJ; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nsteps = (m_end - m_begin + BMK - 1) / BMK;
+    const int nsteps = m_end > m_begin ? (m_end - m_begin + BMK - 1) / BMK : 0;
     const int fg = lane >> 4, fl = lane & 15;
     auto compute = [&](int cur) {
         const char* pb = (const char*)(lds + cur * STAGE);
@@ -808,16 +814,29 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
         }
     };
     if (DMA) {
-        dma_tile(0);
-        wait_vmcnt<0>();
+        // Ring of NSTAGE slots: tiles st+1 .. st+PF are in flight while tile st is multiplied.  A tile is NI LDS-DMA
+        // instructions per wave; vmcnt counts them in issue order, so "all but the newest k*NI landed" == every tile up to
+        // st+PF-k is complete.  The raw s_barrier (not __syncthreads, which would drain vmcnt to 0) publishes tile st+1 to
+        // the other waves; the slot refilled in iteration st was last read in iteration st-1, i.e. before a barrier every wave
+        // has passed, with its ds_reads retired by the lgkmcnt(0) of wait_vmcnt (WAR, see there).
+        constexpr int NI = NPI + NPJ, PF = NSTAGE - 1;
+        auto wait_newer = [&](int newer) {
+            if (newer >= 3) wait_vmcnt<3 * NI>(); else if (newer == 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
+        };
+#pragma unroll
+        for (int t = 0; t < PF; ++t)
+            if (t < nsteps) dma_tile(t);
+        wait_newer((nsteps < PF ? nsteps : PF) - 1);
         __builtin_amdgcn_s_barrier();
         int slot = 0;
         for (int st = 0; st < nsteps; ++st) {
-            if (st + 1 < nsteps) dma_tile(slot ^ 1);   // (tiles are requested in row order; the slot's previous readers all passed the last barrier)
+            if (st + PF < nsteps) { int s2 = slot + PF; if (s2 >= NSTAGE) s2 -= NSTAGE; dma_tile(s2); }   // (tiles are requested in row order)
             compute(slot);
-            wait_vmcnt<0>();
+            int newer = nsteps - 2 - st;   // tiles issued after st+1
+            if (newer > PF - 1) newer = PF - 1;
+            wait_newer(newer);
             __builtin_amdgcn_s_barrier();
-            slot ^= 1;
+            if (++slot == NSTAGE) slot = 0;
         }
     } else {
         load_tile(m_begin);
@@ -832,6 +851,16 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
             __syncthreads();
         }
     }
+    if (SLAB) {
+        // fragment order: [split][tile][wave][a][b][lane] x 4 floats -- one 1-KB store per wave and fragment; tn_reduce_kernel
+        // knows the order
+        float* slab = p.slab + ((long)split * nt + t2) * (BI * BJ);
+#pragma unroll
+        for (int a = 0; a < FI; ++a)
+#pragma unroll
+            for (int b = 0; b < FJ; ++b) *(f32x4*)(slab + ((((wave * FI + a) * FJ + b) * 64 + lane) << 2)) = acc[a][b];
+        return;
+    }
     // D[i = ..+4*fg+reg][j = ..+fl]: for a fixed register 16 lanes add 64 contiguous bytes of one row
 #pragma unroll
     for (int a = 0; a < FI; ++a)
@@ -845,6 +874,30 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
                 if (i < p.I) atomicAdd(p.D + (long)i * p.ldd + j, acc[a][b][r]);
             }
         }
+}
+
+// Sums the per-split slabs of tn_kernel<.., SLAB = true> in split order and writes D (overwritten, or added to when `accumulate`).  One thread
+// per 16-byte fragment element group: the slab reads are 1 KB per wave and split, the D writes 64-byte row segments.
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ slab, float* __restrict__ D, int I, int J, int ldd, int tiles_j,
+                                                       int nt, int splits, int accumulate) {
+    constexpr int WI = BI / 2, WJ = BJ / 2, FI = WI / 16, FJ = WJ / 16, PER_TILE = BI * BJ / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)nt * PER_TILE) return;
+    const int tile = (int)(idx / PER_TILE), r = (int)(idx - (long)tile * PER_TILE);
+    const int lane = r & 63, frag = r >> 6;
+    const int b = frag % FJ, a = (frag / FJ) % FI, wave = frag / (FI * FJ);
+    const f32x4* src = (const f32x4*)slab + (long)tile * PER_TILE + r;
+    f32x4 sum = src[0];
+    for (int sp = 1; sp < splits; ++sp) { const f32x4 v = src[(long)sp * nt * PER_TILE]; sum += v; }
+    const int tile_j = tile % tiles_j, tile_i = tile / tiles_j;
+    const int j = tile_j * BJ + (wave & 1) * WJ + b * 16 + (lane & 15);
+    if (j >= J) return;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int i = tile_i * BI + (wave >> 1) * WI + a * 16 + 4 * (lane >> 4) + rr;
+        if (i < I) { float* d = D + (long)i * ldd + j; *d = accumulate ? *d + sum[rr] : sum[rr]; }
+    }
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -916,19 +969,15 @@ template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s) 
     }
 }
 
-template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<T>& a, hipStream_t s) {
-    // register staging (the stem, or RPE_TN_REG=1 for experiments) walks 4 chunks of rows per step, the LDS-DMA ring 8
-    static const bool reg = getenv("RPE_TN_REG") != nullptr;
-    const bool dma = MODE != MODE_STEM && !reg;
-    const int BMK = (dma ? 8 : 4) * Elem<T>::kChunk;
+// Split of M over workgroups for one tile configuration.  Atomic mode: every workgroup adds its whole BIxBJ fp32 tile with
+// atomics (64 KB at 128x128) at ~1.3 TB/s chip-wide -> ~512 workgroups of 128x128.  Slab mode: the same bytes are written once
+// with plain stores and read once by tn_reduce_kernel.
+template <typename T, int BI, int BJ, int MODE> static void plan_tn_cfg(TNArgs<T>& a, int BMK) {
     a.tiles_i = ceil_div(a.I, BI);
     a.tiles_j = ceil_div(a.J, BJ);
     const long tiles = (long)a.tiles_i * a.tiles_j;
-    // Every workgroup adds its whole BIxBJ fp32 tile with atomics (64 KB at 128x128), and float atomics run at ~1.3 TB/s
-    // chip-wide: 1536 workgroups = 100 MB = 77 us per launch, more than the GEMM itself.  ~2 workgroups per CU keeps the
-    // chip busy with a third of that traffic.
     static const long target_wgs = getenv("RPE_TN_WGS") ? atol(getenv("RPE_TN_WGS")) : 512;
-    // (scaled so the atomic bytes, not the workgroup count, stay constant across tile sizes)
+    // (scaled so the atomic / slab bytes, not the workgroup count, stay constant across tile sizes)
     const long wgs = target_wgs * (128 * 128) / (BI * BJ);
     // round DOWN when that still fills >= 70 % of the target: the target is what is resident at once (64 KB of LDS per
     // 128x128 workgroup = 2 per CU), and e.g. 144 tiles x 4 splits = 576 workgroups ran as a full round plus a 12 % round
@@ -942,42 +991,100 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
     rps = (rps + BMK - 1) / BMK * BMK;
     a.rows_per_split = (int)rps;
     a.splits = (int)((a.M + rps - 1) / rps);
-    const long nwg = tiles * a.splits;
+}
+
+// ring configuration of the DMA path (A/B switch for experiments: RPE_TN_RING = "ksub,nslot", e.g. "2,2" = the round-1 loop)
+static inline void tn_ring(int& ksub, int& nslot) {
+    static int k = 0, n = 0;
+    if (!k) {
+        k = 1; n = 4;
+        if (const char* e = getenv("RPE_TN_RING")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 1 || a == 2) && b >= 2 && b <= 4) { k = a; n = b; } }
+    }
+    ksub = k; nslot = n;
+}
+
+template <typename T, int BI, int BJ, int MODE, int KS, int NS> static int launch_tn_ring(TNArgs<T>& a, hipStream_t s, long nwg) {
+    if (a.slab) {
+        hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, true, KS, NS, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
+        RPE_CHECK_LAUNCH();
+        const long nt = (long)a.tiles_i * a.tiles_j, groups = nt * (BI * BJ / 4);
+        hipLaunchKernelGGL((tn_reduce_kernel<BI, BJ>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, a.slab, a.D, a.I, a.J, a.ldd, a.tiles_j,
+                           (int)nt, a.splits, a.accumulate);
+    } else {
+        hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, true, KS, NS, false>), dim3((unsigned)nwg), dim3(256), 0, s, a);
+    }
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+// slab_query: only report the slab bytes this problem needs (rpe_*_wgrad_workspace_bytes), launch nothing
+template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<T>& a, hipStream_t s, long* slab_query) {
+    // register staging (the stem, or RPE_TN_REG=1 for experiments) walks 4 chunks of rows per step, the LDS-DMA ring 4 or 8
+    static const bool reg = getenv("RPE_TN_REG") != nullptr;
+    const bool dma = MODE != MODE_STEM && !reg;
+    int ksub = 1, nslot = 2;
+    if (dma) tn_ring(ksub, nslot);
+    const int BMK = (dma ? 4 * ksub : 4) * Elem<T>::kChunk;
+    plan_tn_cfg<T, BI, BJ, MODE>(a, BMK);
+    const long nwg = (long)a.tiles_i * a.tiles_j * a.splits;
+    const long slab_bytes = nwg * (long)(BI * BJ) * 4;
+    if (slab_query) { *slab_query = slab_bytes; return 0; }
+    if (a.slab && a.slab_bytes < slab_bytes) a.slab = nullptr;   // too small a workspace: atomic accumulation
     // buffer-descriptor extents (DMA path): rows past M must fall outside them, padding uses offset 2^31
     const long pb = (long)a.M * a.ldp * (long)sizeof(T), qb = (MODE == MODE_DENSE ? (long)a.M * a.ldq : a.q_elems) * (long)sizeof(T);
     if (dma && (pb <= 0 || qb <= 0 || pb >= (1L << 31) || qb >= (1L << 31)))
         return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: an operand of 2 GiB or more (split the batch)");
     a.p_bytes = (unsigned)pb; a.q_bytes = (unsigned)qb;
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "tn_kernel<%s,%d,%d,%d,%d>", Elem<T>::kName, BI, BJ, MODE, dma ? 1 : 0);
-    if (dma) hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, false>), dim3((unsigned)nwg), dim3(256), 0, s, a);
-    RPE_CHECK_LAUNCH();
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "tn_kernel<%s,%d,%d,%d,%d,%d,%d,%d>", Elem<T>::kName, BI, BJ, MODE, dma ? 1 : 0, dma ? ksub : 1,
+             dma ? nslot : 2, a.slab ? 1 : 0);
+    if (!dma) {
+        if (a.slab) {
+            hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, false, 1, 2, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
+            RPE_CHECK_LAUNCH();
+            const long nt = (long)a.tiles_i * a.tiles_j, groups = nt * (BI * BJ / 4);
+            hipLaunchKernelGGL((tn_reduce_kernel<BI, BJ>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, a.slab, a.D, a.I, a.J, a.ldd,
+                               a.tiles_j, (int)nt, a.splits, a.accumulate);
+        } else {
+            hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, false, 1, 2, false>), dim3((unsigned)nwg), dim3(256), 0, s, a);
+        }
+        RPE_CHECK_LAUNCH();
+        return 0;
+    }
+    if constexpr (MODE != MODE_STEM) {
+        if (ksub == 2 && nslot == 2) return launch_tn_ring<T, BI, BJ, MODE, 2, 2>(a, s, nwg);
+        if (ksub == 2 && nslot == 3) return launch_tn_ring<T, BI, BJ, MODE, 2, 3>(a, s, nwg);
+        if (ksub == 1 && nslot == 3) return launch_tn_ring<T, BI, BJ, MODE, 1, 3>(a, s, nwg);
+        return launch_tn_ring<T, BI, BJ, MODE, 1, 4>(a, s, nwg);
+    }
     return 0;
 }
 
-template <typename T> int launch_tn(TNArgs<T>& a, int mode, hipStream_t s) {
+template <typename T> int launch_tn(TNArgs<T>& a, int mode, hipStream_t s, long* slab_query) {
     constexpr int CE = Elem<T>::kChunk;
     if (a.M <= 0 || a.I <= 0 || a.J <= 0) return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: empty problem");
-    if ((a.ldp % CE) || (((uintptr_t)a.P) & 15) || (((uintptr_t)a.Q) & 15))
-        return rpe_set_error(RPE_ERR_ALIGN, "igemm_tn: operands must be 16-byte aligned with ld a multiple of the 16-byte chunk");
-    if (mode == MODE_DENSE && (a.ldq % CE)) return rpe_set_error(RPE_ERR_ALIGN, "igemm_tn: dense ldq must be a chunk multiple");
-    if (mode == MODE_STEM) return launch_tn_cfg<T, 64, 64, MODE_STEM>(a, s);
+    if (!slab_query) {
+        if ((a.ldp % CE) || (((uintptr_t)a.P) & 15) || (((uintptr_t)a.Q) & 15))
+            return rpe_set_error(RPE_ERR_ALIGN, "igemm_tn: operands must be 16-byte aligned with ld a multiple of the 16-byte chunk");
+        if (mode == MODE_DENSE && (a.ldq % CE)) return rpe_set_error(RPE_ERR_ALIGN, "igemm_tn: dense ldq must be a chunk multiple");
+        if (a.slab && (((uintptr_t)a.slab) & 15)) return rpe_set_error(RPE_ERR_ALIGN, "igemm_tn: the slab workspace must be 16-byte aligned");
+    }
+    if (mode == MODE_STEM) return launch_tn_cfg<T, 64, 64, MODE_STEM>(a, s, slab_query);
     const bool wide_i = a.I > 64;
     if (mode == MODE_DENSE) {
         const bool wide_j = a.J > 64;
-        if (wide_i && wide_j) return launch_tn_cfg<T, 128, 128, MODE_DENSE>(a, s);
-        if (wide_j) return launch_tn_cfg<T, 64, 128, MODE_DENSE>(a, s);
-        if (wide_i) return launch_tn_cfg<T, 128, 64, MODE_DENSE>(a, s);
-        return launch_tn_cfg<T, 64, 64, MODE_DENSE>(a, s);
+        if (wide_i && wide_j) return launch_tn_cfg<T, 128, 128, MODE_DENSE>(a, s, slab_query);
+        if (wide_j) return launch_tn_cfg<T, 64, 128, MODE_DENSE>(a, s, slab_query);
+        if (wide_i) return launch_tn_cfg<T, 128, 64, MODE_DENSE>(a, s, slab_query);
+        return launch_tn_cfg<T, 64, 64, MODE_DENSE>(a, s, slab_query);
     }
     if (a.g.C % 64) return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: conv channels must be a multiple of 64");
     if (a.g.img_stride >= (1L << 24) || (long)a.g.H * a.g.W >= (1L << 24))
         return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: an image of 2^24 elements or more (offsets are built with 24-bit multiplies)");
     const bool wide_j = (a.g.C % 128) == 0;
-    if (wide_i && wide_j) return launch_tn_cfg<T, 128, 128, MODE_CONV>(a, s);
-    if (wide_j) return launch_tn_cfg<T, 64, 128, MODE_CONV>(a, s);
-    if (wide_i) return launch_tn_cfg<T, 128, 64, MODE_CONV>(a, s);
-    return launch_tn_cfg<T, 64, 64, MODE_CONV>(a, s);
+    if (wide_i && wide_j) return launch_tn_cfg<T, 128, 128, MODE_CONV>(a, s, slab_query);
+    if (wide_j) return launch_tn_cfg<T, 64, 128, MODE_CONV>(a, s, slab_query);
+    if (wide_i) return launch_tn_cfg<T, 128, 64, MODE_CONV>(a, s, slab_query);
+    return launch_tn_cfg<T, 64, 64, MODE_CONV>(a, s, slab_query);
 }
 
 }  // namespace rpe

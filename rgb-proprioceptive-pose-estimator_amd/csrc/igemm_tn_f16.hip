@@ -2,5 +2,5 @@
 #include "igemm_impl.h"
 
 namespace rpe {
-template int launch_tn<f16>(TNArgs<f16>&, int, hipStream_t);
+template int launch_tn<f16>(TNArgs<f16>&, int, hipStream_t, long*);
 }  // namespace rpe

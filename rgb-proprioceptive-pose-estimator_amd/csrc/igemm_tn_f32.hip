@@ -2,5 +2,5 @@
 #include "igemm_impl.h"
 
 namespace rpe {
-template int launch_tn<float>(TNArgs<float>&, int, hipStream_t);
+template int launch_tn<float>(TNArgs<float>&, int, hipStream_t, long*);
 }  // namespace rpe

@@ -117,11 +117,31 @@ def bn_backward_from_dz(dz, y, mean, invstd, gamma, stats_part):
     return dy, dgamma, dbeta
 
 
-def conv2d_wgrad(x, dy, k, stride, pad):
-    """-> dw [Co,kh,kw,Ci] fp32"""
+_SCRATCH = {}
+
+
+def scratch(nbytes, device):
+    """Per-device workspace for the deterministic weight-gradient calls (per-workgroup fp32 tiles, summed in a fixed order).
+    One buffer that only ever grows: consecutive calls on one stream are ordered, so they can share it -- and its address stays
+    fixed, which a captured hipGraph needs.  Use one stream per device for these ops (the models do)."""
+    key = (device.type, device.index)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _SCRATCH[key] = buf
+    return buf
+
+
+def conv2d_wgrad(x, dy, k, stride, pad, deterministic=True):
+    """-> dw [Co,kh,kw,Ci] fp32.  deterministic: slab + fixed-order sum (bitwise reproducible); else fp32 atomics."""
     _chk(x, "x"), _chk(dy, "dy")
     co = dy.shape[3]
     d = conv_desc(x.shape, co, k, stride, pad)
+    if deterministic:
+        dw = torch.empty((co, k, k, x.shape[3]), dtype=torch.float32, device=x.device)
+        ws = scratch(lib.rpe_conv2d_wgrad_workspace_bytes(ctypes.byref(d), dtype_code(x)), x.device)
+        lib.rpe_conv2d_wgrad_det(ctypes.byref(d), dtype_code(x), _p(x), _p(dy), _p(dw), _p(ws), ws.numel(), _stream())
+        return dw
     dw = torch.zeros((co, k, k, x.shape[3]), dtype=torch.float32, device=x.device)
     lib.rpe_conv2d_wgrad(ctypes.byref(d), dtype_code(x), _p(x), _p(dy), _p(dw), _stream())
     return dw
@@ -162,7 +182,8 @@ def stem_conv_fwd(x4, w_packed, want_stats=False):
 def stem_conv_wgrad(x4, dy):
     b, h, w, _ = x4.shape
     dwp = torch.zeros((64, 8, 8, 4), dtype=torch.float32, device=x4.device)
-    lib.rpe_stem_conv_wgrad(dtype_code(x4), _p(x4), _p(dy), _p(dwp), b, h, w, _stream())
+    ws = scratch(lib.rpe_stem_conv_wgrad_workspace_bytes(dtype_code(x4), b, h, w), x4.device)
+    lib.rpe_stem_conv_wgrad_det(dtype_code(x4), _p(x4), _p(dy), _p(dwp), b, h, w, _p(ws), ws.numel(), _stream())
     dw = torch.empty((64, 3, 7, 7), dtype=torch.float32, device=x4.device)
     lib.rpe_unpack_stem_grad(_p(dwp), _p(dw), _stream())
     return dw
@@ -251,11 +272,16 @@ def linear_fwd(x, w, bias=None, relu=False, addend=None, out=None, n=None, k=Non
     return out
 
 
-def linear_wgrad(dy, x, dw, n=None, k=None):
-    """dw[:N, :K] (fp32) += dy[M, :N]^T @ x[M, :K]  (atomic accumulation into dw)."""
+def linear_wgrad(dy, x, dw, n=None, k=None, deterministic=True):
+    """dw[:N, :K] (fp32) += dy[M, :N]^T @ x[M, :K].  deterministic: per-workgroup slabs summed in a fixed order, then ONE add
+    into dw per element (bitwise reproducible); else fp32 atomics."""
     m = x.shape[0]
     n = dy.shape[1] if n is None else n
     k = x.shape[1] if k is None else k
+    if deterministic:
+        ws = scratch(lib.rpe_linear_wgrad_workspace_bytes(dtype_code(x), m, n, k), x.device)
+        lib.rpe_linear_wgrad_det(dtype_code(x), _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw.stride(0), m, n, k, 1, _p(ws), ws.numel(), _stream())
+        return dw
     lib.rpe_linear_wgrad(dtype_code(x), _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw.stride(0), m, n, k, _stream())
     return dw
 

@@ -73,6 +73,11 @@ def test_linear_wgrad(dtype, m, n, k):
     ops.linear_wgrad(dy.to(dtype).to(DEV), x.to(dtype).to(DEV), dw, n=n, k=kp)
     ref = q(dy, dtype)[:, :n].t() @ q(x, dtype)
     assert rel_err(dw, ref) < tol(dtype)
+    ops.linear_wgrad(dy.to(dtype).to(DEV), x.to(dtype).to(DEV), dw, n=n, k=kp)        # accumulates: dw += ...
+    assert rel_err(dw, 2 * ref) < tol(dtype)
+    dwa = torch.zeros(n, kp, device=DEV)
+    ops.linear_wgrad(dy.to(dtype).to(DEV), x.to(dtype).to(DEV), dwa, n=n, k=kp, deterministic=False)
+    assert rel_err(dwa, ref) < tol(dtype)
 
 
 # ------------------------------------------------------------------ convolution
@@ -138,8 +143,27 @@ def test_conv_wgrad(dtype, cfg):
     y = F.conv2d(x, w, None, s, p)
     dy = q(torch.randn(y.shape, generator=torch.Generator().manual_seed(6)), dtype)
     (ref,) = torch.autograd.grad(y, w, dy)
-    dw = ops.conv2d_wgrad(nhwc(x).to(dtype).to(DEV), nhwc(dy).to(dtype).to(DEV), k, s, p)
+    xd, dyd = nhwc(x).to(dtype).to(DEV), nhwc(dy).to(dtype).to(DEV)
+    dw = ops.conv2d_wgrad(xd, dyd, k, s, p)                      # slab + fixed-order sum
     assert rel_err(dw.permute(0, 3, 1, 2), ref) < tol(dtype)
+    assert torch.equal(dw, ops.conv2d_wgrad(xd, dyd, k, s, p)), "the deterministic weight gradient is not bitwise reproducible"
+    dwa = ops.conv2d_wgrad(xd, dyd, k, s, p, deterministic=False)   # fp32 atomics
+    assert rel_err(dwa.permute(0, 3, 1, 2), ref) < tol(dtype)
+
+
+def test_conv_wgrad_many_splits_is_deterministic():
+    """A long reduction (many M splits per tile, the shape class of the layer1 1x1 weight gradients at bs256): slab mode must
+    reproduce itself bitwise and agree with the atomic mode to fp32 summation-order noise."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(8, 56, 56, 64, generator=g).bfloat16().to(DEV)
+    dy = torch.randn(8, 56, 56, 256, generator=g).bfloat16().to(DEV)
+    a = ops.conv2d_wgrad(x, dy, 1, 1, 0)
+    b = ops.conv2d_wgrad(x, dy, 1, 1, 0)
+    c = ops.conv2d_wgrad(x, dy, 1, 1, 0, deterministic=False)
+    assert torch.equal(a, b)
+    assert rel_err(a, c) < 1e-5
+    ref = dy.float().reshape(-1, 256).t() @ x.float().reshape(-1, 64)
+    assert rel_err(a.reshape(256, 64), ref) < 1e-4
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -142,10 +142,11 @@ def test_optimizer_state_checkpoint_resumes_exactly(tmp_path):
 
 
 def test_gradients_repeat_across_passes():
-    """Same weights, same batch, three forward+backward passes on the two-stream schedule: the flat gradient may differ by the
-    fp32 atomic order of the weight-gradient accumulation only (~3e-7 relative).  A ring-buffer hazard in the weight-gradient
-    kernel once showed here as 5e-4 .. 1e-1 (a stale 8-channel slab a few times per hundred launches) while every parity
-    test stayed green."""
+    """Same weights, same batch, four forward+backward passes on the two-stream schedule at a chip-filling size: the flat
+    gradient must be BITWISE identical from pass to pass -- every weight gradient is a fixed-order sum of per-workgroup slabs
+    (no float atomics) and the BN reductions are two-level with a fixed order.  (Round 1: a ring-buffer hazard in the
+    weight-gradient kernel showed here as 5e-4 .. 1e-1 -- a stale 8-channel slab a few times per hundred launches -- while every
+    parity test stayed green.)  Only the 66 parameters of the aux head are still accumulated with atomics (csrc/heads.hip)."""
     import contextlib
     import sys
 
@@ -162,9 +163,13 @@ def test_gradients_repeat_across_passes():
     for _ in range(4):
         crit(model(b["img"], None, b["x0bar"]), b["obj"]).backward()
         torch.cuda.synchronize()
-        grads.append(model._arena.grad.detach().clone())
+        grads.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
     for g in grads[1:]:
-        assert ((g - grads[0]).norm() / grads[0].norm()).item() < 1e-5
+        for n, t in g.items():
+            if "aux_nets" in n:
+                assert ((t - grads[0][n]).norm() / grads[0][n].norm().clamp_min(1e-30)).item() < 1e-5, n
+            else:
+                assert torch.equal(t, grads[0][n]), "gradient of %s differs between two passes over the same batch" % n
 
 
 def test_frame_prefetcher_without_host_syncs():
