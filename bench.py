@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CATS = ["conv_fwd", "conv_dgrad", "conv_wgrad", "bn_fwd", "bn_bwd", "other"]
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
@@ -45,24 +45,83 @@ def usable_cores():
     return max(1, n)
 
 
+C1_CFG = dict(latent_dim=512, hidden=[1024, 256, 64], use_depth=False, no_proprioception=False)
+LOSS_CFG = dict(metric="combined", scale=1.0, alpha=0.5, mode="pose")
+
+
 def cpu_baseline(seconds_budget=25.0):
-    """Oracle train step (fp32 torch-CPU ops) of the same model family: config C1 = 32 images, NO model."""
+    """Oracle train step (fp32 torch-CPU ops) of the same model family: config C1 = 32 images, NO model.  Also returns the
+    oracle's pose outputs of the FIRST step (pristine seeded weights) -- the reference side of `pose_parity`."""
     from oracle import pose_oracle as po
     torch.set_num_threads(usable_cores())
     log("[bench] cpu baseline on %d threads (os.cpu_count=%s, affinity=%d)" % (torch.get_num_threads(), os.cpu_count(), len(os.sched_getaffinity(0))))
-    cfg = dict(latent_dim=512, hidden=[1024, 256, 64], use_depth=False, no_proprioception=False)
-    sd = po.make_state("no", cfg, 0)
+    sd = po.make_state("no", C1_CFG, 0)
     batch = po.synth_batch((32,), 1234)
-    loss_cfg = dict(metric="combined", scale=1.0, alpha=0.5, mode="pose")
     opt = {}
-    po.train_step("no", cfg, sd, batch, loss_cfg, opt)  # warm-up
+    first = po.train_step("no", C1_CFG, sd, batch, LOSS_CFG, opt)  # warm-up; its outputs belong to the pristine weights
     n, t0 = 0, time.time()
     while n < 3 or (time.time() - t0 < seconds_budget and n < 8):
-        po.train_step("no", cfg, sd, batch, loss_cfg, opt)
+        po.train_step("no", C1_CFG, sd, batch, LOSS_CFG, opt)
         n += 1
     dt = (time.time() - t0) / n
     return {"value": round(32 / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d timed train steps (1 warm-up) of 32 images, fp32, NaiveObjectStateEstimator latent 512 hidden [1024,256,64], oracle/pose_oracle.py" % n}
+            "sample": "%d timed train steps (1 warm-up) of 32 images, fp32, NaiveObjectStateEstimator latent 512 hidden [1024,256,64], oracle/pose_oracle.py" % n}, first
+
+
+def pose_parity(ref, dtypes, dev):
+    """The second half of BASELINE.json's metric ("pose L2 vs CPU ref"): the HIP path and the CPU oracle on identical seeded
+    weights and inputs (config C1: 32 images, train-mode forward = step 1 of a run), per compute dtype.  Position L2 in the units
+    of the pose (metres), relative error over all 7 outputs against the largest reference magnitude."""
+    from oracle import pose_oracle as po
+    from rgb_proprioceptive_pose_estimator_amd import models as M
+    sd = po.make_state("no", C1_CFG, 0)
+    batch = po.synth_batch((32,), 1234)
+    want = ref["outputs"]
+    out = {}
+    for name, dtype in dtypes:
+        with contextlib.redirect_stdout(sys.stderr):
+            m = M.NaiveObjectStateEstimator("cube", [1024, 256, 64], 50, 512, False, (9,), False, False, False, compute_dtype=dtype)
+        m.load_state_dict(sd)
+        m.to(dev).train()
+        got = m(batch["img"].to(dev), None, batch["x0bar"].to(dev)).detach().float().cpu()
+        crit = M.PoseDistanceLoss(distance_metric="combined", scale_factor=1.0, alpha=0.5, mode="pose")
+        loss = float(crit(got.to(dev), batch["obj"].to(dev)).item())
+        l2 = (got[:, :3] - want[:, :3]).norm(dim=1)
+        out[name] = {"pos_l2_max": float(l2.max()), "pos_l2_mean": float(l2.mean()),
+                     "rel_err_max_7": float((got - want).abs().max() / want.abs().max()),
+                     "loss": loss, "loss_ref": float(ref["loss"].item())}
+        del m
+    torch.cuda.empty_cache()
+    return {"config": "C1: 32 images 224x224, NaiveObjectStateEstimator latent 512 hidden [1024,256,64], seeded weights + inputs, train-mode forward",
+            "reference": "oracle/pose_oracle.py (fp32 CPU restatement, pinned to the reference's vectors: tests/golden/model_no_c1.npz)",
+            "tolerance": {"f32": 1e-4, "bf16": 6.5e-2, "f16": 1.5e-2}, **out}
+
+
+def time_f32_path(dev, batch_size):
+    """Step time of the exact-fp32 compute path (the one that meets the 1e-4 pose bar), same workload, a few steps."""
+    from rgb_proprioceptive_pose_estimator_amd import models as M
+    from rgb_proprioceptive_pose_estimator_amd.optim import FusedAdam
+    from rgb_proprioceptive_pose_estimator_amd.util.data_utils import synthetic_batch
+    from rgb_proprioceptive_pose_estimator_amd.util.learn_utils import train_step
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(sys.stderr):
+        m = M.NaiveObjectStateEstimator("cube", [1024, 256, 64], 50, 512, False, (9,), False, False, False, compute_dtype=torch.float32)
+    m.to(dev).train()
+    criterion = {"obj_loss": M.PoseDistanceLoss(distance_metric="combined", scale_factor=1.0, alpha=0.5, mode="pose"), "val_loss": M.PoseDistanceLoss(mode="val")}
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    b = synthetic_batch((batch_size,), 1234, device=dev)
+    batch = (b["img"], None, b["x0bar"], b["x0"], None, b["obj"])
+    for _ in range(2):
+        train_step(m, batch, criterion, opt, True, "train", None)
+    torch.cuda.synchronize()
+    n, t0 = 5, time.perf_counter()
+    for _ in range(n):
+        train_step(m, batch, criterion, opt, True, "train", None)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    del m, opt
+    torch.cuda.empty_cache()
+    return {"ms_per_step": round(dt * 1e3, 2), "images_per_s": round(batch_size / dt, 1), "steps": n}
 
 
 def main():
@@ -71,7 +130,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -88,7 +147,7 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
 
     torch.manual_seed(0)
     with contextlib.redirect_stdout(sys.stderr):  # the constructor prints its feature width, as the reference does; stdout is the JSON line only
@@ -163,14 +222,13 @@ def main():
         name, cnt, tms, fl, by = line.split(";")
         syms.append({"kernel": name, "launches": int(cnt), "ms": float(tms), "flops": float(fl), "bytes": float(by)})
     lib.rpe_resnet50_profile(plan.handle, 0)
-    gemm = [k for k in syms if k["flops"] > 0]
-    dom = max(gemm, key=lambda k: k["ms"])
+    dom = max(syms, key=lambda k: k["ms"])   # over EVERY profiled symbol of the trunk plan (GEMMs, BN / pooling passes, packing)
     avg_ms = dom["ms"] / dom["launches"]
-    tflops = dom["flops"] / dom["launches"] / 1e12 / (avg_ms / 1e3)
+    tflops = dom["flops"] / dom["launches"] / 1e12 / (avg_ms / 1e3)   # (0 for a pure streaming kernel)
     gbs = dom["bytes"] / dom["launches"] / 1e9 / (avg_ms / 1e3)
     # which roof bounds this kernel: arithmetic intensity against the ridge peak_flops / peak_bytes
     ai = dom["flops"] / max(dom["bytes"], 1.0)
-    hbm_bound = ai < PEAK_TFLOPS[args.dtype] * 1e12 / (PEAK_HBM_GBS * 1e9)
+    hbm_bound = dom["flops"] <= 0 or ai < PEAK_TFLOPS[args.dtype] * 1e12 / (PEAK_HBM_GBS * 1e9)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic_pmc.json")
     if os.path.exists(tpath):  # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) of this same command, committed per round
@@ -211,7 +269,13 @@ def main():
         out["step_roofline"] = {"tflops_per_gpu": round(ips * 24.52e9 / 1e12, 2), "frac_mfma": round(ips * 24.52e9 / 1e12 / PEAK_TFLOPS[args.dtype], 4),
                                 "ideal_fused_gbs_per_gpu": round(ips * 152.9e6 / 1e9, 1), "frac_hbm": round(ips * 152.9e6 / 1e9 / PEAK_HBM_GBS, 4)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"], ref_first = cpu_baseline()
+            del model, opt
+            torch.cuda.empty_cache()
+            dts = [(args.dtype, dtype)] + ([("f32", torch.float32)] if args.dtype != "f32" else [])
+            out["pose_parity"] = pose_parity(ref_first, dts, dev)
+            if args.dtype != "f32":
+                out["f32_path"] = time_f32_path(dev, args.batch)
         print(json.dumps(out, allow_nan=False))
     if world > 1:
         dist.destroy_process_group()

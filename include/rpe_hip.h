@@ -88,6 +88,22 @@ typedef struct {
 long rpe_conv2d_dgrad_stats_tiles(const rpe_conv_desc* d);
 int rpe_conv2d_dgrad_bn(const rpe_conv_desc* d, int dtype, const void* dy, const void* w_crsk, void* dz, const void* addend,
                         const rpe_bn_bwd_epilogue* bn, void* stream);
+/* BatchNorm backward folded into the data gradient of the 1x1 / stride-1 conv in front of it (y = a_in W^T, z = BN(y)):
+ *   dx = dz (A o W) + a_in G + 1 b^T   with A = gamma invstd, G = W^T diag(C') W, b = W^T B'  (C', B' from the BN coefficients),
+ * so the data gradient reads dz and the conv's INPUT instead of a materialised dy = BN'(dz, y).
+ * rpe_bn_bwd_fold_conv1x1 builds w_kcat [in_c][out_c + in_c] (compute dtype) and bias [in_c] from the packed weights
+ * (w_fwd [out_c][in_c], w_dgrad [in_c][out_c]) and c1c2 (rpe_bn_backward_coeffs); rpe_conv1x1_dgrad_kcat is the GEMM
+ * (A operand = [dz | a_in], optional fused BN-backward epilogue of the layer BEHIND, as rpe_conv2d_dgrad_bn).
+ * replaces: autograd's BatchNorm2d backward + conv3 data gradient of a torchvision Bottleneck (util/model_utils.py:136). */
+long rpe_bn_bwd_fold_scratch_bytes(int dtype, int out_c, int in_c);
+int rpe_bn_bwd_fold_conv1x1(int dtype, int out_c, int in_c, const void* w_fwd, const void* w_dgrad, const float* gamma, const float* invstd,
+                            const float* mean, const float* c1c2, void* w_kcat, float* bias, void* scratch, long scratch_bytes, void* stream);
+int rpe_conv1x1_dgrad_kcat(const rpe_conv_desc* d, int dtype, const void* dz, const void* a_in, const void* w_kcat, const float* bias, void* dx,
+                           const rpe_bn_bwd_epilogue* bn, void* stream);
+/* the two halves of rpe_bn_backward_from_dz as separate calls (c1c2: [2][C] fp32 = mean(dz), mean(dz xhat)) */
+int rpe_bn_backward_coeffs(const float* stats_part, int tiles, int C, long rows, float* dgamma, float* dbeta, float* c1c2, double* dpart, void* stream);
+int rpe_bn_backward_apply_dz(int dtype, const void* dz, const void* y, const float* mean, const float* invstd, const float* gamma, const float* c1c2,
+                             void* dy, long rows, int C, void* stream);
 /* dw_krsc[out_c][kh][kw][in_c] (fp32) += x (*) dy.  Atomic accumulation: zero it first. */
 int rpe_conv2d_wgrad(const rpe_conv_desc* d, int dtype, const void* x, const void* dy, float* dw_krsc, void* stream);
 /* Deterministic form: dw_krsc = x (*) dy (OVERWRITTEN, no zeroing needed).  Every workgroup stores its fp32 tile into

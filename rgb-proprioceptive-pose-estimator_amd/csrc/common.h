@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/rpe_hip.h"
 
@@ -136,6 +137,11 @@ __device__ inline double wave_sum_d(double v) {
 }
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// name of the kernel (symbol, short form) the last C-ABI call of this thread launched: what rpe_last_kernel_name() returns and
+// the engine's per-symbol profile keys on (defined in igemm.hip)
+extern thread_local char g_last_kernel[96];
+inline void note_kernel(const char* name) { snprintf(g_last_kernel, sizeof(g_last_kernel), "%s", name); }
 
 }  // namespace rpe
 

@@ -121,6 +121,107 @@ static int conv_wgrad_t(const rpe_conv_desc* d, const void* x, const void* dy, f
     return launch_tn<T>(a, MODE_CONV, s, slab_query);
 }
 
+// ---------------------------------------------------------------------------------------------
+// BN backward folded into the data gradient of the 1x1 conv that produced the BN's input.
+//   y = a_in W^T (1x1, stride 1), z = BN(y);   dy = A o dz + B' + C' o y   per channel k of y, with
+//   A = gamma r, C' = -gamma r^2 c2, B' = -A c1 - C' mean   (r = invstd, c1 = mean(dz), c2 = mean(dz xhat))
+//   dx = dy W = dz (A o W) + a_in G + 1 b^T,   G = W^T diag(C') W  (Ci x Ci),   b = W^T B'
+// so the data gradient reads dz and the conv's (4x smaller) INPUT instead of a materialised dy: the streaming dz, y -> dy pass
+// leaves the critical path (it still feeds the weight gradient, on the side stream).
+// replaces: the BatchNorm2d backward + conv3 data gradient of a torchvision Bottleneck as torch autograd runs them
+// (util/model_utils.py:136 constructs the network; models/naive.py:316 is the call whose backward this is).
+// ---------------------------------------------------------------------------------------------
+// one wave per row.  rows [0, Ci): row n of the K-concatenated weight, wk[n][k] = A_k wd[n][k] (k < Co), and b[n];
+// rows [Ci, Ci + Co): row k of the G-GEMM operand pm[k][:] = C'_k wf[k][:]
+template <typename T>
+__global__ __launch_bounds__(64) void bn_fold_scale_kernel(const T* __restrict__ wd, const T* __restrict__ wf, const float* __restrict__ gamma,
+                                                          const float* __restrict__ invstd, const float* __restrict__ mean, const float* __restrict__ c1,
+                                                          const float* __restrict__ c2, T* __restrict__ wk, T* __restrict__ pm, float* __restrict__ bias,
+                                                          int Co, int Ci) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    if (row < Ci) {
+        float acc = 0.f;
+        for (int k = lane; k < Co; k += 64) {
+            const float a = gamma[k] * invstd[k];
+            const float cp = -a * invstd[k] * c2[k];
+            const float bp = -a * c1[k] - cp * mean[k];
+            const float w = Elem<T>::to_f(wd[(long)row * Co + k]);
+            wk[(long)row * (Co + Ci) + k] = Elem<T>::from_f(a * w);
+            acc = fmaf(bp, w, acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) bias[row] = acc;
+    } else {
+        const int k = row - Ci;
+        const float cp = -gamma[k] * invstd[k] * invstd[k] * c2[k];
+        for (int n = lane; n < Ci; n += 64) pm[(long)k * Ci + n] = Elem<T>::from_f(cp * Elem<T>::to_f(wf[(long)k * Ci + n]));
+    }
+}
+// wk[n][Co + n'] = G[n'][n]  (g is the TN GEMM result g[i][j] = sum_k pm[k][i] wf[k][j])
+template <typename T>
+__global__ __launch_bounds__(256) void bn_fold_g_kernel(const float* __restrict__ g, T* __restrict__ wk, int Co, int Ci) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)Ci * Ci) return;
+    const int n = (int)(idx / Ci), np = (int)(idx - (long)n * Ci);
+    wk[(long)n * (Co + Ci) + Co + np] = Elem<T>::from_f(g[(long)np * Ci + n]);
+}
+
+template <typename T>
+static int bn_fold_t(int Co, int Ci, const void* wf, const void* wd, const float* gamma, const float* invstd, const float* mean, const float* c1c2,
+                     void* w_kcat, float* bias, void* scratch, long scratch_bytes, hipStream_t s) {
+    // scratch: pm [Co][Ci] T | g [Ci][Ci] fp32 | slab of the G GEMM
+    const long pm_bytes = ((long)Co * Ci * (long)sizeof(T) + 255) / 256 * 256, g_bytes = ((long)Ci * Ci * 4 + 255) / 256 * 256;
+    TNArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.M = Co; a.I = Ci; a.J = Ci; a.ldp = Ci; a.ldq = Ci; a.ldd = Ci;
+    long slab = 0;
+    if (int e = launch_tn<T>(a, MODE_DENSE, s, &slab)) return e;
+    if (!scratch) return rpe_set_error(RPE_ERR_WORKSPACE, "bn_bwd_fold_conv1x1: null scratch");
+    if (scratch_bytes < pm_bytes + g_bytes + slab) return rpe_set_error(RPE_ERR_WORKSPACE, "bn_bwd_fold_conv1x1: scratch smaller than rpe_bn_bwd_fold_scratch_bytes()");
+    T* pm = (T*)scratch;
+    float* g = (float*)((char*)scratch + pm_bytes);
+    hipLaunchKernelGGL((bn_fold_scale_kernel<T>), dim3(Ci + Co), dim3(64), 0, s, (const T*)wd, (const T*)wf, gamma, invstd, mean, c1c2, c1c2 + Co, (T*)w_kcat, pm,
+                       bias, Co, Ci);
+    RPE_CHECK_LAUNCH();
+    a.P = pm; a.Q = (const T*)wf; a.D = g;
+    a.slab = (float*)((char*)scratch + pm_bytes + g_bytes); a.slab_bytes = scratch_bytes - pm_bytes - g_bytes;
+    if (int e = launch_tn<T>(a, MODE_DENSE, s)) return e;
+    hipLaunchKernelGGL((bn_fold_g_kernel<T>), dim3((unsigned)(((long)Ci * Ci + 255) / 256)), dim3(256), 0, s, g, (T*)w_kcat, Co, Ci);
+    RPE_CHECK_LAUNCH();
+    note_kernel("bn_fold_scale_kernel + tn_kernel(G) + bn_fold_g_kernel");
+    return 0;
+}
+template <typename T> static int bn_fold_scratch_t(int Co, int Ci, long* bytes) {
+    TNArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.M = Co; a.I = Ci; a.J = Ci; a.ldp = Ci; a.ldq = Ci; a.ldd = Ci;
+    long slab = 0;
+    if (int e = launch_tn<T>(a, MODE_DENSE, nullptr, &slab)) return e;
+    *bytes = ((long)Co * Ci * (long)sizeof(T) + 255) / 256 * 256 + ((long)Ci * Ci * 4 + 255) / 256 * 256 + slab;
+    return 0;
+}
+
+// data gradient of a 1x1 / stride-1 conv from A = [dz (M x Co) | a_in (M x Ci)] and the folded weight w_kcat [Ci][Co + Ci]
+template <typename T>
+static int conv1x1_dgrad_kcat_t(const rpe_conv_desc* d, const void* dz, const void* a_in, const void* w_kcat, const float* bias, void* dx,
+                                const rpe_bn_bwd_epilogue* bn, hipStream_t s) {
+    NTArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.A = (const T*)dz; a.A2 = (const T*)a_in; a.Bw = (const T*)w_kcat; a.C = (T*)dx;
+    a.M = d->batch * d->in_h * d->in_w; a.N = d->in_c; a.K = d->out_c + d->in_c; a.K1 = d->out_c;
+    a.lda = d->out_c; a.lda2 = d->in_c; a.ldb = a.K; a.ldc = d->in_c;
+    a.bias = bias;
+    a.role = 1;
+    if (bn) {
+        if (!bn->y || !bn->mean || !bn->invstd || !bn->stats_part) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_dgrad_kcat: y, mean, invstd, stats_part are required");
+        a.bn_mode = bn->a_mask ? 4 : bn->a_out ? 1 : (bn->scale && bn->shift ? 2 : 3);
+        a.bn_y = (const T*)bn->y; a.bn_a = (const T*)bn->a_out; a.bn_mask = bn->a_mask;
+        a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bn_scale = bn->scale; a.bn_shift = bn->shift;
+        a.stats_part = bn->stats_part;
+    }
+    return launch_nt<T>(a, MODE_DENSE, s);
+}
+
 static void stem_gather(Gather& g, int H, int W) {
     const int Ho = out_dim(H, 7, 2, 3), Wo = out_dim(W, 7, 2, 3);
     g.H = H; g.W = W; g.C = 4; g.Ho = Ho; g.Wo = Wo; g.R = 8; g.S = 8;
@@ -225,6 +326,31 @@ int rpe_conv2d_dgrad_bn(const rpe_conv_desc* d, int dtype, const void* dy, const
     if (int e = check_desc(d)) return e;
     if (!bn) return rpe_set_error(RPE_ERR_SHAPE, "conv2d_dgrad_bn: null epilogue descriptor");
     DISPATCH(dtype, conv_dgrad_t, d, dy, w_crsk, dz, addend, bn, (hipStream_t)stream);
+}
+
+long rpe_bn_bwd_fold_scratch_bytes(int dtype, int out_c, int in_c) {
+    long bytes = 0;
+    int rc;
+    if (out_c <= 0 || in_c <= 0) return -1;
+    if (dtype == RPE_F32) rc = bn_fold_scratch_t<float>(out_c, in_c, &bytes);
+    else if (dtype == RPE_BF16) rc = bn_fold_scratch_t<bf16>(out_c, in_c, &bytes);
+    else if (dtype == RPE_F16) rc = bn_fold_scratch_t<f16>(out_c, in_c, &bytes);
+    else return -1;
+    return rc ? -1 : bytes;
+}
+
+int rpe_bn_bwd_fold_conv1x1(int dtype, int out_c, int in_c, const void* w_fwd, const void* w_dgrad, const float* gamma, const float* invstd,
+                            const float* mean, const float* c1c2, void* w_kcat, float* bias, void* scratch, long scratch_bytes, void* stream) {
+    if (out_c <= 0 || in_c <= 0 || (out_c % 64) || (in_c % 8) || !w_fwd || !w_dgrad || !gamma || !invstd || !mean || !c1c2 || !w_kcat || !bias)
+        return rpe_set_error(RPE_ERR_SHAPE, "bn_bwd_fold_conv1x1: bad arguments (out_c % 64 == 0, in_c % 8 == 0)");
+    DISPATCH(dtype, bn_fold_t, out_c, in_c, w_fwd, w_dgrad, gamma, invstd, mean, c1c2, w_kcat, bias, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+int rpe_conv1x1_dgrad_kcat(const rpe_conv_desc* d, int dtype, const void* dz, const void* a_in, const void* w_kcat, const float* bias, void* dx,
+                           const rpe_bn_bwd_epilogue* bn, void* stream) {
+    if (int e = check_desc(d)) return e;
+    if (d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_dgrad_kcat: 1x1 / stride 1 / no padding only");
+    DISPATCH(dtype, conv1x1_dgrad_kcat_t, d, dz, a_in, w_kcat, bias, dx, bn, (hipStream_t)stream);
 }
 
 int rpe_conv2d_wgrad(const rpe_conv_desc* d, int dtype, const void* x, const void* dy, float* dw_krsc, void* stream) {

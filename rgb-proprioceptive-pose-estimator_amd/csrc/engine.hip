@@ -32,6 +32,7 @@ struct ConvL {
     void* a = nullptr;   // after BN (+residual) (+ReLU)
     void* dy = nullptr;  // backward: dz of this layer's BN output, turned into dy (gradient of the raw conv output) in place
     float *scale = nullptr, *shift = nullptr, *mean = nullptr, *invstd = nullptr;
+    float* c1c2 = nullptr;   // backward: mean(dz), mean(dz xhat) of this layer's BN ([2][out_c]; per layer: the side stream reads them later)
 };
 
 struct Block {
@@ -86,6 +87,12 @@ struct rpe_resnet50 {
     // aux-head gradient in compact form for the fused stem backward (rpe_resnet50_set_aux_grad)
     const float* aux_dout = nullptr; long aux_ld = 0; const float* aux_df = nullptr; const unsigned char* aux_idx = nullptr; const float* aux_w = nullptr;
     float* stem_dw = nullptr;    // [64][8][8][4]
+    // BN backward folded into the conv3 data gradients (rpe_bn_bwd_fold_conv1x1): main-stream-only scratch, rebuilt per block
+    bool fold = true;
+    void* w_kcat = nullptr;      // [planes][4 planes + planes] compute dtype
+    float* fold_bias = nullptr;  // [planes]
+    void* fold_scratch = nullptr;
+    long fold_scratch_bytes = 0;
     void* main_slab = nullptr;   // the same for the two weight gradients that run on the caller's stream (stem conv, fc)
     long main_slab_bytes = 0;
     void* wg_slab = nullptr;     // per-workgroup fp32 tiles of the deterministic weight-gradient form (one launch at a time: side stream order)
@@ -145,7 +152,7 @@ static hipEvent_t next_event(rpe_resnet50* e) {
             if (pa__) (void)hipEventRecord(pa__, (hipStream_t)(stream)); }                 \
         if (int err__ = (call)) return err__;                                        \
         if ((e)->profiling && pa__ && pb__) { (void)hipEventRecord(pb__, (hipStream_t)(stream)); \
-            (e)->spans.push_back({(cat), pa__, pb__, (cat) <= RPE_PROF_CONV_WGRAD ? kernel_id(e) : -1, (e)->pending_flops, (e)->pending_bytes}); (e)->pending_flops = 0; (e)->pending_bytes = 0; } \
+            (e)->spans.push_back({(cat), pa__, pb__, kernel_id(e), (e)->pending_flops, (e)->pending_bytes}); (e)->pending_flops = 0; (e)->pending_bytes = 0; } \
     } while (0)
 
 static int add_conv(rpe_resnet50* e, const std::string& name, const std::string& bn, int in_h, int in_w, int in_c, int out_c, int k,
@@ -226,6 +233,7 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
         want(e, (void**)&c.shift, c.d.out_c * 4L);
         want(e, (void**)&c.mean, c.d.out_c * 4L);
         want(e, (void**)&c.invstd, c.d.out_c * 4L);
+        want(e, (void**)&c.c1c2, 2L * c.d.out_c * 4);
         const long sf = rpe_conv_stats_tiles(c.rows) * 2 * c.d.out_c;
         if (sf > e->stats_floats) e->stats_floats = sf;
         const long sf2 = (rpe_conv2d_dgrad_stats_tiles(&c.d) + 4) * 2 * c.d.in_c;  // fused dgrad partials (parity classes round up)
@@ -254,6 +262,20 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
     want(e, (void**)&e->dpart, RPE_BN_DPART_DOUBLES(2048) * 8);
     want(e, (void**)&e->dpart2, RPE_BN_DPART_DOUBLES(2048) * 8);
     want(e, (void**)&e->stem_dw, 64L * 256 * 4);
+    e->fold = getenv("RPE_NO_BN_FOLD") == nullptr;
+    if (e->fold) {
+        long wk = 0;
+        for (auto& b : e->blocks) {
+            const rpe_conv_desc& d = e->convs[b.c3].d;
+            const long sb = rpe_bn_bwd_fold_scratch_bytes(dtype, d.out_c, d.in_c);
+            if (sb > e->fold_scratch_bytes) e->fold_scratch_bytes = sb;
+            const long w = (long)d.in_c * (d.out_c + d.in_c) * (long)es;
+            if (w > wk) wk = w;
+        }
+        want(e, &e->w_kcat, wk);
+        want(e, (void**)&e->fold_bias, 512L * 4);
+        want(e, &e->fold_scratch, e->fold_scratch_bytes);
+    }
     if (!getenv("RPE_WGRAD_ATOMIC")) {
         for (size_t i = 1; i < e->convs.size(); ++i) {
             const long b = rpe_conv2d_wgrad_workspace_bytes(&e->convs[i].d, dtype);
@@ -507,8 +529,10 @@ static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residua
     else PROF(e, RPE_PROF_CONV_FWD, stream, rpe_conv2d_fwd(&c.d, e->dtype, x, fwd_weight(e, c), c.y, stats, stream));
     float* rm = e->running[2 * c.bn_i];
     float* rv = e->running[2 * c.bn_i + 1];
+    e->pending_bytes = 0;
     PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_finalize(stats, (int)rpe_conv_stats_tiles(c.rows), c.d.out_c, c.rows, e->params[c.p_g], e->params[c.p_b], rm, rv,
                         e->nbt[c.bn_i], 0.1f, 1e-5f, c.scale, c.shift, c.mean, c.invstd, dpart, stream));
+    e->pending_bytes = conv_out_bytes(e, c) * (2.0 + (residual ? 1.0 : 0.0) + ((relu_mask && relu) ? 1.0 / 16 : 0.0));   // y (+residual) -> a (+mask)
     if (relu_mask && relu) PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_apply_mask(e->dtype, c.y, residual, c.a, c.scale, c.shift, c.rows, c.d.out_c, relu_mask, stream));
     else PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_apply(e->dtype, c.y, residual, c.a, c.scale, c.shift, c.rows, c.d.out_c, relu, stream));
     return 0;
@@ -525,6 +549,7 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
     else PROF(e, RPE_PROF_OTHER, stream, rpe_stage_image_nhwc4(e->dtype, img_nchw, e->x4, e->B, e->H, e->W, stream));
     ConvL& st = e->convs[0];
     TRY(conv_bn(e, st, e->x4, nullptr, 1, stream));
+    e->pending_bytes = conv_out_bytes(e, st) * 1.25 + (double)e->B * (st.Ho / 2) * (st.Wo / 2) * 64;   // a1 -> pool + winner index
     PROF(e, RPE_PROF_OTHER, stream, rpe_maxpool3x3s2_fwd(e->dtype, st.a, e->pool, e->pool_idx, e->B, st.Ho, st.Wo, 64, stream));
     const void* x = e->pool;
     TRY(ensure_side(e));
@@ -578,6 +603,7 @@ extern "C" void* rpe_resnet50_early_grad(rpe_resnet50_t* e) { return e ? e->earl
 
 // BN backward of layer c: dA (grad wrt c.a) -> dy (may alias dA); dz_out optional
 static int bn_back(rpe_resnet50* e, ConvL& c, const void* dA, int relu, void* dy, void* dz_out, void* stream) {
+    e->pending_bytes = conv_out_bytes(e, c) * ((relu ? 3.0 : 2.0) + 3.0 + (dz_out ? 1.0 : 0.0));   // reduce pass: dA, y (, a); apply pass: dA, y -> dy (, dz)
     PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_backward(e->dtype, dA, relu ? c.a : nullptr, c.y, c.mean, c.invstd, e->params[c.p_g], e->grads[c.p_g], e->grads[c.p_b], dy,
                            dz_out, c.rows, c.d.out_c, e->bwd_part, e->bwd_part_floats, e->c1c2, e->dpart, stream));
     return 0;
@@ -605,6 +631,7 @@ static int dgrad_fused(rpe_resnet50* e, ConvL& c, const void* dy, void* dz, cons
 
 // second half of the fused BN backward of layer c: partials (left in stats_part by dgrad_fused) -> dgamma, dbeta, dy
 static int bn_from_dz(rpe_resnet50* e, ConvL& c, const void* dz, void* dy, void* stream) {
+    e->pending_bytes = conv_out_bytes(e, c) * 3.0;   // dz, y -> dy
     PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_backward_from_dz(e->dtype, dz, c.y, c.mean, c.invstd, e->params[c.p_g], e->stats_part,
                                                               e->fused_tiles, e->grads[c.p_g], e->grads[c.p_b], dy, c.rows,
                                                               c.d.out_c, e->c1c2, e->dpart, stream));
@@ -631,6 +658,47 @@ static int wgrad(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, void*
     PROF(e, RPE_PROF_CONV_WGRAD, run, rpe_conv2d_wgrad(&c.d, e->dtype, x, dy, dw, run));
     return 0;
 }
+// Folded form of (BN backward of c.bn -> weight gradient + data gradient of the 1x1 conv c), entered with dz = gradient wrt the BN
+// output and this BN's partial sums in stats_part (left by the data gradient that produced dz):
+//   main: coefficients -> fold (w_kcat, bias) -> K-concatenated data gradient [dz | x] with the epilogue of the layer behind;
+//   side: dz, y -> dy (streaming), weight gradient from dy.   The main stream never touches dy.
+static int conv1x1_backward_folded(rpe_resnet50* e, ConvL& c, const void* dz, ConvL& behind, void* stream) {
+    const void* x = behind.a;
+    e->pending_bytes = 0;
+    PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_backward_coeffs(e->stats_part, e->fused_tiles, c.d.out_c, c.rows, e->grads[c.p_g], e->grads[c.p_b], c.c1c2, e->dpart, stream));
+    hipStream_t run = (hipStream_t)stream;
+    if (e->overlap && e->side) {
+        hipEvent_t ready = sync_event(e);
+        if (!ready) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
+        HIPTRY(hipEventRecord(ready, (hipStream_t)stream));
+        HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
+        run = e->side;
+    }
+    e->pending_bytes = conv_out_bytes(e, c) * 3.0;   // dz, y -> dy
+    PROF(e, RPE_PROF_BN_BWD, run, rpe_bn_backward_apply_dz(e->dtype, dz, c.y, c.mean, c.invstd, e->params[c.p_g], c.c1c2, c.dy, c.rows, c.d.out_c, run));
+    e->pending_flops = conv_flops(c);
+    e->pending_bytes = conv_in_bytes(e, c) + conv_out_bytes(e, c);
+    float* dw = e->grads[c.p_w];
+    if (e->wg_slab) {
+        PROF(e, RPE_PROF_CONV_WGRAD, run, rpe_conv2d_wgrad_det(&c.d, e->dtype, x, c.dy, dw, e->wg_slab, e->wg_slab_bytes, run));
+    } else {
+        if (!e->gspan_lo) HIPTRY(hipMemsetAsync(dw, 0, (size_t)e->pnumel[c.p_w] * 4, run));
+        PROF(e, RPE_PROF_CONV_WGRAD, run, rpe_conv2d_wgrad(&c.d, e->dtype, x, c.dy, dw, run));
+    }
+    e->pending_bytes = 0;
+    PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_bwd_fold_conv1x1(e->dtype, c.d.out_c, c.d.in_c, fwd_weight(e, c), c.wd, e->params[c.p_g], c.invstd, c.mean, c.c1c2,
+                                                              e->w_kcat, e->fold_bias, e->fold_scratch, e->fold_scratch_bytes, stream));
+    rpe_bn_bwd_epilogue ep;
+    ep.y = behind.y; ep.a_mask = nullptr; ep.a_out = nullptr;
+    ep.mean = behind.mean; ep.invstd = behind.invstd; ep.scale = behind.scale; ep.shift = behind.shift;   // mask recomputed from y
+    ep.stats_part = e->stats_part;
+    e->pending_flops = conv_flops(c) * (1.0 + (double)c.d.in_c / c.d.out_c);
+    e->pending_bytes = conv_out_bytes(e, c) + conv_in_bytes(e, c) * 3.0;   // reads dz, x, y_behind; writes dz_behind
+    e->fused_tiles = (int)rpe_conv2d_dgrad_stats_tiles(&c.d);
+    PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv1x1_dgrad_kcat(&c.d, e->dtype, dz, x, e->w_kcat, e->fold_bias, behind.dy, &ep, stream));
+    return 0;
+}
+
 static int join_side(rpe_resnet50* e, hipStream_t s) {
     // everything the side stream produced so far (weight gradients) is complete before the caller's next launch on s
     if (e->overlap && e->side) {
@@ -693,10 +761,14 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
         const void* x_in = bi == 0 ? (const void*)e->pool : (const void*)e->convs[e->blocks[bi - 1].c3].a;
         void* gA = b.dz;                                             // dz3 (for the last block: the raw dA)
         void* gD = bi == 0 ? e->d_pool : e->blocks[bi - 1].dz;       // where the gradient of the block input goes
-        if (bi == (int)e->blocks.size() - 1) TRY(bn_back(e, c3, gA, 1, c3.dy, gA, stream));  // unfused: dy3, dz3 (in place)
-        else TRY(bn_from_dz(e, c3, gA, c3.dy, stream));                                       // dy3 (gA keeps dz3 = shortcut gradient)
-        TRY(wgrad(e, c3, c2.a, c3.dy, stream));
-        TRY(dgrad_fused(e, c3, c3.dy, c2.dy, nullptr, &c2, 2, stream));   // dz2
+        if (e->fold && bi != (int)e->blocks.size() - 1 && e->train_mode) {
+            TRY(conv1x1_backward_folded(e, c3, gA, c2, stream));                                  // dz2 (dy3 exists on the side stream only)
+        } else {
+            if (bi == (int)e->blocks.size() - 1) TRY(bn_back(e, c3, gA, 1, c3.dy, gA, stream));  // unfused: dy3, dz3 (in place)
+            else TRY(bn_from_dz(e, c3, gA, c3.dy, stream));                                       // dy3 (gA keeps dz3 = shortcut gradient)
+            TRY(wgrad(e, c3, c2.a, c3.dy, stream));
+            TRY(dgrad_fused(e, c3, c3.dy, c2.dy, nullptr, &c2, 2, stream));   // dz2
+        }
         TRY(bn_from_dz(e, c2, c2.dy, c2.dy, stream));
         TRY(wgrad(e, c2, c1.a, c2.dy, stream));
         TRY(dgrad_fused(e, c2, c2.dy, c1.dy, nullptr, &c1, 2, stream));   // dz1
@@ -737,6 +809,7 @@ extern "C" int rpe_resnet50_backward_end(rpe_resnet50_t* e, int use_d_early, voi
         TRY(bn_back(e, st, g1, 1, g1, nullptr, stream));
     } else {
         const bool aux = use_d_early != 0;
+        e->pending_bytes = conv_out_bytes(e, st) * 3.0 + 2.0 * (double)e->B * (st.Ho / 2) * (st.Wo / 2) * 64 * (e->esz + 1);   // y twice -> dy; pooled gradient + index twice
         PROF(e, RPE_PROF_BN_BWD, stream, rpe_stem_bwd(e->dtype, g0, e->pool_idx, st.y, st.scale, st.shift, st.mean, st.invstd, e->params[st.p_g],
                                                       aux ? e->aux_dout : nullptr, e->aux_ld, aux ? e->aux_df : nullptr, aux ? e->aux_idx : nullptr,
                                                       aux ? e->aux_w : nullptr, e->grads[st.p_g], e->grads[st.p_b], g1, e->B, st.Ho, st.Wo,

@@ -664,6 +664,7 @@ int rpe_pack_conv_weight(int dtype, const float* w_krsc, void* w_fwd, void* w_dg
 }
 
 int rpe_pack_conv_weights_multi(int dtype, const rpe_pack_desc* table_dev, int nlayers, long total, void* stream) {
+    note_kernel("pack_conv_weights_multi_kernel");
     if (nlayers <= 0 || nlayers > 127 || total <= 0) return rpe_set_error(RPE_ERR_SHAPE, "pack_conv_weights_multi: bad table");
     const int grid = (int)((total + 4095) / 4096 < 8192 ? (total + 4095) / 4096 : 8192);
     if (dtype == RPE_F32) hipLaunchKernelGGL((pack_conv_weights_multi_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, table_dev, nlayers, total);
@@ -675,6 +676,7 @@ int rpe_pack_conv_weights_multi(int dtype, const rpe_pack_desc* table_dev, int n
 }
 
 int rpe_pack_stem_weight(int dtype, const float* w_oihw, const float* scale, void* out, void* stream) {
+    note_kernel("pack_stem_weight_kernel");
     if (dtype == RPE_F32) hipLaunchKernelGGL((pack_stem_weight_kernel<float>), dim3(64), dim3(256), 0, (hipStream_t)stream, w_oihw, scale, (float*)out);
     else if (dtype == RPE_BF16) hipLaunchKernelGGL((pack_stem_weight_kernel<bf16>), dim3(64), dim3(256), 0, (hipStream_t)stream, w_oihw, scale, (bf16*)out);
     else if (dtype == RPE_F16) hipLaunchKernelGGL((pack_stem_weight_kernel<f16>), dim3(64), dim3(256), 0, (hipStream_t)stream, w_oihw, scale, (f16*)out);

@@ -30,6 +30,12 @@ struct Gather {
 
 template <typename T> struct NTArgs {
     const T* A;     // activations (dense [M][lda] or NHWC tensor described by g)
+    // K-concatenated dense A operand (role 1 only): columns k >= K1 of the im2col matrix come from a second row-major tensor
+    // A2[M][lda2] (K1 a multiple of the K step).  Used by the data gradient of a 1x1 conv with the BN backward of its output
+    // folded in: dx = [dz | a_in] * [A o W ; G]^T (rpe_bn_bwd_fold_conv1x1).
+    const T* A2;
+    int lda2, K1;
+    unsigned a2_bytes;
     const T* Bw;    // weights [N][ldb], K contiguous
     T* C;           // output [M][ldc]
     int M, N, K;

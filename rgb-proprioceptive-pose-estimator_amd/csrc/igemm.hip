@@ -25,6 +25,13 @@ template <typename T> int launch_nt(NTArgs<T>& a, int mode, hipStream_t s) {
         if (ab <= 0 || bb <= 0 || ab >= (1L << 31) || bb >= (1L << 31))
             return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: an operand of 2 GiB or more (split the batch)");
         a.a_bytes = (unsigned)ab; a.b_bytes = (unsigned)bb;
+        if (a.A2) {
+            const long a2b = (long)a.M * a.lda2 * (long)sizeof(T);
+            if (mode != MODE_DENSE || a.role != 1 || a.K1 <= 0 || a.K1 >= a.K || (a.K1 % (8 * CE)) || (a.lda2 % CE) || (((uintptr_t)a.A2) & 15) || a2b <= 0 || a2b >= (1L << 31))
+                return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: bad K-concatenated operand (dense data-gradient role, K1 a multiple of 8 chunks, < 2 GiB)");
+            a.a2_bytes = (unsigned)a2b;
+            if ((long)a.M * a.lda * (long)sizeof(T) >= (1L << 31)) return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: an operand of 2 GiB or more (split the batch)");
+        }
     }
     if (a.role != 2) {
         // conv roles run the vector-only epilogue: whole 16-byte chunks of 8 channels, aligned rows

@@ -195,6 +195,12 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
             a_wb[i] = (int)ow * g.sn + g.base_w;
         }
     }
+    constexpr bool KCAT = MODE == MODE_DENSE && ROLE == 1;   // a second A tensor for k >= K1 (NTArgs::A2)
+    unsigned a_voff2[AR];
+    if (KCAT) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) a_voff2[i] = (a_ok[i] && p.A2) ? (unsigned)(((long)(m0 + a_row[i]) * p.lda2 + a_chunk[i] * CE) * ES) : OOB;
+    }
     long b_off[BR];
     bool b_ok[BR];
 #pragma unroll
@@ -260,17 +266,28 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
     typedef __attribute__((address_space(3))) void lds_void;
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bw, 0, (int)p.b_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(KCAT && p.A2 ? p.A2 : p.A), 0, (int)(KCAT && p.A2 ? p.a2_bytes : p.a_bytes), 0x00020000);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // provably uniform: the LDS base of a DMA goes through M0
     const bool ktail = (p.K % BK) != 0;                        // dense only (conv: C % BK == 0, checked by the launcher)
     auto dma_tile = [&](int st) {
         lds_char* base = (lds_char*)lds + st * (STAGE * 16);
         if (MODE == MODE_CONV && tap_dirty) { tap_offsets(); tap_dirty = false; }
         const int so_a = (MODE == MODE_CONV ? c0 : kbase) * ES, so_b = kbase * ES;
+        if (KCAT && p.A2 && kbase >= p.K1) {   // (uniform: the K step lies in the second tensor)
+            const int so_a2 = (kbase - p.K1) * ES;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            unsigned vo = a_voff[i];
-            if (MODE == MODE_DENSE && ktail && kbase + a_chunk[i] * CE >= p.K) vo = OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(base + (wave_u * AR + i) * 1024), 16, (int)vo, so_a, 0, 0);
+            for (int i = 0; i < AR; ++i) {
+                unsigned vo = a_voff2[i];
+                if (ktail && kbase + a_chunk[i] * CE >= p.K) vo = OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (lds_void*)(base + (wave_u * AR + i) * 1024), 16, (int)vo, so_a2, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                unsigned vo = a_voff[i];
+                if (MODE == MODE_DENSE && ktail && kbase + a_chunk[i] * CE >= p.K) vo = OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(base + (wave_u * AR + i) * 1024), 16, (int)vo, so_a, 0, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
@@ -319,7 +336,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
     const T* const e_addend = HAS_ADDEND ? p.addend : nullptr;
     const bool vec_add = VEC_ONLY ? (ncol_ok && e_addend != nullptr) : nfull && e_addend && (p.ld_add % CE == 0) && (((uintptr_t)e_addend) & 15) == 0;
     constexpr int bn_mode = HAS_BN ? BNM : 0;
-    const float* const e_bias = HAS_AFFINE ? p.bias : nullptr;
+    const float* const e_bias = (HAS_AFFINE || ROLE == 1) ? p.bias : nullptr;   // (role 1: the constant term of a folded BN backward)
     const int e_relu = HAS_AFFINE ? p.relu : 0;
     // Data-gradient launches with short K are bound by the epilogue's operand stream (residual gradient, y, a_out: up to
     // three reads and one write per output element against K/N-th of that for the GEMM operands).  One step at a time
@@ -876,20 +893,36 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
         }
 }
 
-// Sums the per-split slabs of tn_kernel<.., SLAB = true> in split order and writes D (overwritten, or added to when `accumulate`).  One thread
-// per 16-byte fragment element group: the slab reads are 1 KB per wave and split, the D writes 64-byte row segments.
+// Sums the per-split slabs of tn_kernel<.., SLAB = true> in a fixed order and writes D (overwritten, or added to when `accumulate`).
+// One block per 64 consecutive 16-byte fragment groups (1 KB per split: one coalesced wave load); its 8 waves take every 8th
+// split each (several loads in flight per wave -- with few tiles and hundreds of splits a one-thread-per-element loop was
+// latency bound: 170 us for the 64x64 layer1 gradient), then the 8 partial sums are added in wave order.
 template <int BI, int BJ>
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ slab, float* __restrict__ D, int I, int J, int ldd, int tiles_j,
+__global__ __launch_bounds__(512) void tn_reduce_kernel(const float* __restrict__ slab, float* __restrict__ D, int I, int J, int ldd, int tiles_j,
                                                        int nt, int splits, int accumulate) {
     constexpr int WI = BI / 2, WJ = BJ / 2, FI = WI / 16, FJ = WJ / 16, PER_TILE = BI * BJ / 4;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)nt * PER_TILE) return;
+    static_assert(PER_TILE % 64 == 0, "whole waves per tile");
+    __shared__ f32x4 sh[8][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long idx = (long)blockIdx.x * 64 + lane;
+    const long stride = (long)nt * PER_TILE;
+    const f32x4* src = (const f32x4*)slab + idx;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    int sp = w;
+    for (; sp + 8 < splits; sp += 16) {
+        const f32x4 a = src[(long)sp * stride], b = src[(long)(sp + 8) * stride];
+        s0 += a; s1 += b;
+    }
+    if (sp < splits) s0 += src[(long)sp * stride];
+    sh[w][lane] = s0 + s1;
+    __syncthreads();
+    if (w != 0) return;
+    f32x4 sum = sh[0][lane];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) sum += sh[i][lane];
     const int tile = (int)(idx / PER_TILE), r = (int)(idx - (long)tile * PER_TILE);
-    const int lane = r & 63, frag = r >> 6;
+    const int frag = r >> 6;
     const int b = frag % FJ, a = (frag / FJ) % FI, wave = frag / (FI * FJ);
-    const f32x4* src = (const f32x4*)slab + (long)tile * PER_TILE + r;
-    f32x4 sum = src[0];
-    for (int sp = 1; sp < splits; ++sp) { const f32x4 v = src[(long)sp * nt * PER_TILE]; sum += v; }
     const int tile_j = tile % tiles_j, tile_i = tile / tiles_j;
     const int j = tile_j * BJ + (wave & 1) * WJ + b * 16 + (lane & 15);
     if (j >= J) return;
@@ -904,7 +937,6 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 // host launchers (templates; instantiated per element type and staging mode in the igemm_*.hip units, which compile in
 // parallel -- one unit with every configuration took 5 minutes)
 // -----------------------------------------------------------------------------------------------
-extern thread_local char g_last_kernel[96];
 
 template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE> static int launch_nt_role(NTArgs<T>& a, hipStream_t s, long nwg) {
     snprintf(g_last_kernel, sizeof(g_last_kernel), "nt_kernel<%s,%d,%d,%d,%d,%d,%d,%d>", Elem<T>::kName, WAVES_M, BN, KCH, MODE, NST, ROLE,
@@ -972,13 +1004,13 @@ template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s) 
 // Split of M over workgroups for one tile configuration.  Atomic mode: every workgroup adds its whole BIxBJ fp32 tile with
 // atomics (64 KB at 128x128) at ~1.3 TB/s chip-wide -> ~512 workgroups of 128x128.  Slab mode: the same bytes are written once
 // with plain stores and read once by tn_reduce_kernel.
-template <typename T, int BI, int BJ, int MODE> static void plan_tn_cfg(TNArgs<T>& a, int BMK) {
+template <typename T, int BI, int BJ, int MODE> static void plan_tn_cfg(TNArgs<T>& a, int BMK, int wg_div) {
     a.tiles_i = ceil_div(a.I, BI);
     a.tiles_j = ceil_div(a.J, BJ);
     const long tiles = (long)a.tiles_i * a.tiles_j;
     static const long target_wgs = getenv("RPE_TN_WGS") ? atol(getenv("RPE_TN_WGS")) : 512;
     // (scaled so the atomic / slab bytes, not the workgroup count, stay constant across tile sizes)
-    const long wgs = target_wgs * (128 * 128) / (BI * BJ);
+    const long wgs = target_wgs * (128 * 128) / (BI * BJ) / wg_div;   // (wg_div 2: one 96-KB workgroup per CU)
     // round DOWN when that still fills >= 70 % of the target: the target is what is resident at once (64 KB of LDS per
     // 128x128 workgroup = 2 per CU), and e.g. 144 tiles x 4 splits = 576 workgroups ran as a full round plus a 12 % round
     long want = wgs / tiles;
@@ -993,14 +1025,21 @@ template <typename T, int BI, int BJ, int MODE> static void plan_tn_cfg(TNArgs<T
     a.splits = (int)((a.M + rps - 1) / rps);
 }
 
-// ring configuration of the DMA path (A/B switch for experiments: RPE_TN_RING = "ksub,nslot", e.g. "2,2" = the round-1 loop)
-static inline void tn_ring(int& ksub, int& nslot) {
-    static int k = 0, n = 0;
-    if (!k) {
-        k = 1; n = 4;
+// Ring configuration of the DMA path.  Measured per shape at 256 images (tools/sweep_tn.sh, isolated launches): the 2-slot
+// ring with 64-row steps at 2 workgroups per CU wins wherever the operands are re-read through L2 (the per-CU LDS fill rate,
+// not HBM latency, bounds those launches: 128x128x64 steps fetch 32 KB per 2.1 MFLOP), a 3-slot ring (96 KB, one workgroup per
+// CU, two tiles in flight) wins on the long, HBM-streaming reductions of layer1 (M = 802816 rows: 0.33 -> 0.18 ms for the 3x3,
+// 0.23 -> 0.16 ms for the 64 <-> 256 1x1 with half the workgroups).  RPE_TN_RING = "ksub,nslot" forces one setting.
+static inline void tn_ring(long M, int& ksub, int& nslot, bool& forced) {
+    static int k = -1, n = 0;
+    if (k < 0) {
+        k = 0;
         if (const char* e = getenv("RPE_TN_RING")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 1 || a == 2) && b >= 2 && b <= 4) { k = a; n = b; } }
     }
-    ksub = k; nslot = n;
+    forced = k > 0;
+    if (forced) { ksub = k; nslot = n; return; }
+    ksub = 2;
+    nslot = M >= 400000 ? 3 : 2;
 }
 
 template <typename T, int BI, int BJ, int MODE, int KS, int NS> static int launch_tn_ring(TNArgs<T>& a, hipStream_t s, long nwg) {
@@ -1008,7 +1047,7 @@ template <typename T, int BI, int BJ, int MODE, int KS, int NS> static int launc
         hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, true, KS, NS, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
         RPE_CHECK_LAUNCH();
         const long nt = (long)a.tiles_i * a.tiles_j, groups = nt * (BI * BJ / 4);
-        hipLaunchKernelGGL((tn_reduce_kernel<BI, BJ>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, a.slab, a.D, a.I, a.J, a.ldd, a.tiles_j,
+        hipLaunchKernelGGL((tn_reduce_kernel<BI, BJ>), dim3((unsigned)(groups / 64)), dim3(512), 0, s, a.slab, a.D, a.I, a.J, a.ldd, a.tiles_j,
                            (int)nt, a.splits, a.accumulate);
     } else {
         hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, true, KS, NS, false>), dim3((unsigned)nwg), dim3(256), 0, s, a);
@@ -1023,9 +1062,10 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
     static const bool reg = getenv("RPE_TN_REG") != nullptr;
     const bool dma = MODE != MODE_STEM && !reg;
     int ksub = 1, nslot = 2;
-    if (dma) tn_ring(ksub, nslot);
+    bool forced = false;
+    if (dma) tn_ring(a.M, ksub, nslot, forced);
     const int BMK = (dma ? 4 * ksub : 4) * Elem<T>::kChunk;
-    plan_tn_cfg<T, BI, BJ, MODE>(a, BMK);
+    plan_tn_cfg<T, BI, BJ, MODE>(a, BMK, (dma && !forced && nslot == 3) ? 2 : 1);
     const long nwg = (long)a.tiles_i * a.tiles_j * a.splits;
     const long slab_bytes = nwg * (long)(BI * BJ) * 4;
     if (slab_query) { *slab_query = slab_bytes; return 0; }
@@ -1042,7 +1082,7 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
             hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, false, 1, 2, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
             RPE_CHECK_LAUNCH();
             const long nt = (long)a.tiles_i * a.tiles_j, groups = nt * (BI * BJ / 4);
-            hipLaunchKernelGGL((tn_reduce_kernel<BI, BJ>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, a.slab, a.D, a.I, a.J, a.ldd,
+            hipLaunchKernelGGL((tn_reduce_kernel<BI, BJ>), dim3((unsigned)(groups / 64)), dim3(512), 0, s, a.slab, a.D, a.I, a.J, a.ldd,
                                a.tiles_j, (int)nt, a.splits, a.accumulate);
         } else {
             hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, false, 1, 2, false>), dim3((unsigned)nwg), dim3(256), 0, s, a);

@@ -761,6 +761,12 @@ int stem_bwd_launch(const void* dpool, const unsigned char* pidx, const StemAux&
     return 0;
 }
 
+template <typename T> int bn_apply_dz_checked(const void* dz, const void* y, const float* mean, const float* invstd, const float* gamma,
+                                                    const float* c1c2, void* dy, long rows, int C, hipStream_t s) {
+    if (C % Elem<T>::kChunk) return rpe_set_error(RPE_ERR_SHAPE, "bn_backward_apply_dz: C must be a multiple of the 16-byte chunk");
+    return bn_apply_dz_launch<T>(dz, y, mean, invstd, gamma, c1c2, c1c2 + C, dy, rows, C, s);
+}
+
 }  // namespace rpe
 
 using namespace rpe;
@@ -770,6 +776,7 @@ extern "C" {
 int rpe_bn_finalize(const float* part, int tiles, int C, long count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, long long* num_batches, float momentum, float eps, float* scale, float* shift,
                     float* save_mean, float* save_invstd, double* dpart, void* stream) {
+    note_kernel("reduce_finalize_kernel<BnFwdFin>");
     if (tiles <= 0 || C <= 0 || count <= 0) return rpe_set_error(RPE_ERR_SHAPE, "bn_finalize: empty problem");
     return reduce_finalize(part, tiles, C, dpart, BnFwdFin{(double)count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, scale,
                                                            shift, save_mean, save_invstd}, (hipStream_t)stream);
@@ -785,6 +792,7 @@ int rpe_bn_eval_affine(int C, const float* gamma, const float* beta, const float
 
 int rpe_bn_apply(int dtype, const void* y, const void* residual, void* out, const float* scale, const float* shift, long rows, int C,
                  int relu, void* stream) {
+    note_kernel("bn_apply_kernel");
     if (dtype == RPE_F32) return bn_apply_launch<float>(y, residual, out, scale, shift, rows, C, relu, nullptr, (hipStream_t)stream);
     if (dtype == RPE_BF16) return bn_apply_launch<bf16>(y, residual, out, scale, shift, rows, C, relu, nullptr, (hipStream_t)stream);
     if (dtype == RPE_F16) return bn_apply_launch<f16>(y, residual, out, scale, shift, rows, C, relu, nullptr, (hipStream_t)stream);
@@ -793,6 +801,7 @@ int rpe_bn_apply(int dtype, const void* y, const void* residual, void* out, cons
 
 int rpe_bn_apply_mask(int dtype, const void* y, const void* residual, void* out, const float* scale, const float* shift, long rows, int C,
                       unsigned char* relu_mask, void* stream) {
+    note_kernel("bn_apply_kernel<mask>");
     if (!relu_mask || (C % 8)) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply_mask: mask buffer and C % 8 == 0 required");
     if (dtype == RPE_BF16) return bn_apply_launch<bf16>(y, residual, out, scale, shift, rows, C, 1, relu_mask, (hipStream_t)stream);
     if (dtype == RPE_F16) return bn_apply_launch<f16>(y, residual, out, scale, shift, rows, C, 1, relu_mask, (hipStream_t)stream);
@@ -802,6 +811,7 @@ int rpe_bn_apply_mask(int dtype, const void* y, const void* residual, void* out,
 int rpe_bn_backward(int dtype, const void* dA, const void* a_out, const void* y, const float* mean, const float* invstd,
                     const float* gamma, float* dgamma, float* dbeta, void* dy, void* dz_out, long rows, int C, float* part,
                     long part_floats, float* c1c2, double* dpart, void* stream) {
+    note_kernel("bn_bwd_reduce_kernel + reduce_finalize_kernel<BnBwdFin> + bn_bwd_apply_kernel");
     if (dtype == RPE_F32)
         return bn_bwd_launch<float>(dA, a_out, y, mean, invstd, gamma, dgamma, dbeta, dy, dz_out, rows, C, part, part_floats, c1c2, dpart, (hipStream_t)stream);
     if (dtype == RPE_BF16)
@@ -814,6 +824,7 @@ int rpe_bn_backward(int dtype, const void* dA, const void* a_out, const void* y,
 int rpe_bn_backward_from_dz(int dtype, const void* dz, const void* y, const float* mean, const float* invstd, const float* gamma,
                             const float* stats_part, int tiles, float* dgamma, float* dbeta, void* dy, long rows, int C, float* c1c2,
                             double* dpart, void* stream) {
+    note_kernel("reduce_finalize_kernel<BnBwdFin> + bn_bwd_apply_dz_kernel");
     if (dtype == RPE_F32)
         return bn_bwd_from_dz_launch<float>(dz, y, mean, invstd, gamma, stats_part, tiles, dgamma, dbeta, dy, rows, C, c1c2, dpart, (hipStream_t)stream);
     if (dtype == RPE_BF16)
@@ -823,7 +834,26 @@ int rpe_bn_backward_from_dz(int dtype, const void* dz, const void* y, const floa
     return rpe_set_error(RPE_ERR_DTYPE, "bn_backward_from_dz: unsupported dtype");
 }
 
+// The two halves of rpe_bn_backward_from_dz as separate calls: the per-channel coefficients (one tiny launch) are what the
+// K-concatenated data gradient needs (rpe_bn_bwd_fold_conv1x1); the streaming dz -> dy pass then only feeds the weight gradient
+// and can run on another stream.
+int rpe_bn_backward_coeffs(const float* stats_part, int tiles, int C, long rows, float* dgamma, float* dbeta, float* c1c2, double* dpart, void* stream) {
+    note_kernel("reduce_finalize_kernel<BnBwdFin>");
+    if (!stats_part || !c1c2 || !dpart || tiles <= 0 || C <= 0 || rows <= 0) return rpe_set_error(RPE_ERR_SHAPE, "bn_backward_coeffs: bad arguments");
+    return reduce_finalize(stats_part, tiles, C, dpart, BnBwdFin{(double)rows, dgamma, dbeta, c1c2, c1c2 + C}, (hipStream_t)stream);
+}
+
+int rpe_bn_backward_apply_dz(int dtype, const void* dz, const void* y, const float* mean, const float* invstd, const float* gamma, const float* c1c2,
+                             void* dy, long rows, int C, void* stream) {
+    note_kernel("bn_bwd_apply_dz_kernel");
+    if (dtype == RPE_F32) return bn_apply_dz_checked<float>(dz, y, mean, invstd, gamma, c1c2, dy, rows, C, (hipStream_t)stream);
+    if (dtype == RPE_BF16) return bn_apply_dz_checked<bf16>(dz, y, mean, invstd, gamma, c1c2, dy, rows, C, (hipStream_t)stream);
+    if (dtype == RPE_F16) return bn_apply_dz_checked<f16>(dz, y, mean, invstd, gamma, c1c2, dy, rows, C, (hipStream_t)stream);
+    return rpe_set_error(RPE_ERR_DTYPE, "bn_backward_apply_dz: unsupported dtype");
+}
+
 int rpe_maxpool3x3s2_fwd(int dtype, const void* x, void* out, unsigned char* idx, int B, int H, int W, int C, void* stream) {
+    note_kernel("maxpool_fwd_kernel");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long n = (long)B * Ho * Wo * C;
     if (dtype == RPE_F32) hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)out, idx, B, H, W, C, Ho, Wo);
@@ -836,6 +866,7 @@ int rpe_maxpool3x3s2_fwd(int dtype, const void* x, void* out, unsigned char* idx
 
 int rpe_maxpool3x3s2_bwd(int dtype, const void* dout, const unsigned char* idx, const void* addend, void* dx, int B, int H, int W, int C,
                          void* stream) {
+    note_kernel("maxpool_bwd_kernel");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long n = (long)B * H * W * C;
     if (dtype == RPE_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)dout, idx, (const float*)addend, (float*)dx, B, H, W, C, Ho, Wo);
@@ -866,6 +897,7 @@ int rpe_avgpool_bwd(int dtype, const float* dout, void* dx, int B, int HW, int C
 }
 
 int rpe_stage_image_nhwc4(int dtype, const float* img_nchw, void* out, int B, int H, int W, void* stream) {
+    note_kernel("nchw_to_nhwc4_kernel");
     const long n = (long)B * H * W;
     if (dtype == RPE_F32) hipLaunchKernelGGL((nchw_to_nhwc4_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, img_nchw, (float*)out, B, H * W);
     else if (dtype == RPE_BF16) hipLaunchKernelGGL((nchw_to_nhwc4_kernel<bf16>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, img_nchw, (bf16*)out, B, H * W);
@@ -877,6 +909,7 @@ int rpe_stage_image_nhwc4(int dtype, const float* img_nchw, void* out, int B, in
 
 int rpe_stage_frames_u8(int dtype, const unsigned char* frames, void* out, int B, int Hs, int Ws, int H, int W, const float* mean3_host,
                         const float* std3_host, void* stream) {
+    note_kernel("frames_u8_to_nhwc4_kernel");
     if (B <= 0 || H <= 0 || W <= 0 || Hs < H || Ws < W || !mean3_host || !std3_host) return rpe_set_error(RPE_ERR_SHAPE, "stage_frames_u8: bad shape");
     const long n = (long)B * H * W;
     const float i0 = 1.f / std3_host[0], i1 = 1.f / std3_host[1], i2 = 1.f / std3_host[2];
@@ -892,6 +925,7 @@ int rpe_stem_bwd(int dtype, const void* dpool, const unsigned char* pool_idx, co
                  const float* invstd, const float* gamma, const float* aux_dout, long aux_ld, const float* aux_depth_feat,
                  const unsigned char* aux_idx, const float* aux_w, float* dgamma, float* dbeta, void* dy, int B, int H, int W, float* part,
                  long part_floats, float* c1c2, double* dpart, void* stream) {
+    note_kernel("stem_bwd_reduce_kernel + reduce_finalize_kernel + stem_bwd_apply_kernel");
     if (B <= 0 || H <= 0 || W <= 0 || ((H | W) & 1)) return rpe_set_error(RPE_ERR_SHAPE, "stem_bwd: H and W must be even");
     if (aux_dout && (!aux_idx || !aux_w)) return rpe_set_error(RPE_ERR_SHAPE, "stem_bwd: aux gradient needs its winner indices and weight");
     const StemAux ax{aux_dout, aux_ld, aux_depth_feat, aux_idx, aux_w};

@@ -132,6 +132,56 @@ def scratch(nbytes, device):
     return buf
 
 
+def bn_backward_coeffs(stats_part, rows):
+    """per-tile partial sums [tiles, 2, C] of (dz, dz*xhat) -> (dgamma, dbeta, c1c2 [2, C] = their means)"""
+    tiles, _, c = stats_part.shape
+    dev = stats_part.device
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    c1c2 = torch.empty((2, c), dtype=torch.float32, device=dev)
+    dpart = torch.zeros(256 * 2 * c + 64, dtype=torch.float64, device=dev)
+    lib.rpe_bn_backward_coeffs(_p(stats_part), tiles, c, rows, _p(dgamma), _p(dbeta), _p(c1c2), _p(dpart), _stream())
+    return dgamma, dbeta, c1c2
+
+
+def bn_backward_apply_dz(dz, y, mean, invstd, gamma, c1c2):
+    dy = torch.empty_like(y)
+    c = y.shape[-1]
+    lib.rpe_bn_backward_apply_dz(dtype_code(y), _p(dz), _p(y), _p(mean), _p(invstd), _p(gamma), _p(c1c2), _p(dy), y.numel() // c, c, _stream())
+    return dy
+
+
+def bn_bwd_fold_conv1x1(w_fwd, w_dgrad, gamma, invstd, mean, c1c2):
+    """w_fwd [Co, Ci], w_dgrad [Ci, Co] (compute dtype) -> (w_kcat [Ci, Co + Ci], bias [Ci] fp32): the BN backward of the conv's
+    output folded into its data gradient (see include/rpe_hip.h)."""
+    co, ci = w_fwd.shape
+    dev = w_fwd.device
+    wk = torch.empty((ci, co + ci), dtype=w_fwd.dtype, device=dev)
+    bias = torch.empty(ci, dtype=torch.float32, device=dev)
+    ws = scratch(lib.rpe_bn_bwd_fold_scratch_bytes(dtype_code(w_fwd), co, ci), dev)
+    lib.rpe_bn_bwd_fold_conv1x1(dtype_code(w_fwd), co, ci, _p(_chk(w_fwd, "w_fwd")), _p(_chk(w_dgrad, "w_dgrad")), _p(gamma), _p(invstd), _p(mean), _p(c1c2),
+                                _p(wk), _p(bias), _p(ws), ws.numel(), _stream())
+    return wk, bias
+
+
+def conv1x1_dgrad_kcat(dz, a_in, w_kcat, bias, bn=None):
+    """dz [B,H,W,Co], a_in [B,H,W,Ci] -> dx [B,H,W,Ci].  bn: optional dict(y, mean, invstd, scale, shift, a_out, a_mask) of the
+    layer BEHIND a_in (fused ReLU mask + BN-backward partial sums, as conv2d_dgrad_bn); then returns (dz_in, stats)."""
+    _chk(dz, "dz"), _chk(a_in, "a_in")
+    b, h, w, co = dz.shape
+    ci = a_in.shape[3]
+    d = conv_desc((b, h, w, ci), co, 1, 1, 0)
+    dx = torch.empty_like(a_in)
+    if bn is None:
+        lib.rpe_conv1x1_dgrad_kcat(ctypes.byref(d), dtype_code(dz), _p(dz), _p(a_in), _p(w_kcat), _p(bias), _p(dx), None, _stream())
+        return dx
+    st = torch.empty((lib.rpe_conv2d_dgrad_stats_tiles(ctypes.byref(d)), 2, ci), dtype=torch.float32, device=dz.device)
+    ep = BnBwdEpilogue(*(None if t is None else t.data_ptr() for t in (bn["y"], bn.get("a_out"), bn["mean"], bn["invstd"], bn.get("scale"), bn.get("shift"), st,
+                                                                      bn.get("a_mask"))))
+    lib.rpe_conv1x1_dgrad_kcat(ctypes.byref(d), dtype_code(dz), _p(dz), _p(a_in), _p(w_kcat), _p(bias), _p(dx), ctypes.byref(ep), _stream())
+    return dx, st
+
+
 def conv2d_wgrad(x, dy, k, stride, pad, deterministic=True):
     """-> dw [Co,kh,kw,Ci] fp32.  deterministic: slab + fixed-order sum (bitwise reproducible); else fp32 atomics."""
     _chk(x, "x"), _chk(dy, "dy")

@@ -214,6 +214,65 @@ def test_dgrad_with_fused_bn_backward(dtype, mask_mode, cfg):
     assert rel_err(dg, dg_ref) < t and rel_err(db, db_ref) < t
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 14, 64, 256), (3, 10, 128, 512), (5, 24, 64, 256), (2, 7, 512, 2048)])
+@pytest.mark.parametrize("epilogue", [False, True])
+def test_bn_backward_folded_into_conv1x1_dgrad(dtype, cfg, epilogue):
+    """dx = dz (A o W) + a_in G + b (rpe_bn_bwd_fold_conv1x1 + rpe_conv1x1_dgrad_kcat) == torch's BatchNorm backward followed by
+    the 1x1 conv data gradient; optionally with the fused ReLU-mask / BN-partial-sum epilogue of the layer behind."""
+    b, h, ci, co = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    y_prev = q(torch.randn(b, ci, h, h, generator=g) * 1.3 + 0.2, dtype).requires_grad_(True)      # the layer behind: BN2 -> ReLU = a_in
+    g2 = (0.5 + torch.rand(ci, generator=g)).requires_grad_(True)
+    b2 = (torch.rand(ci, generator=g) - 0.5).requires_grad_(True)
+    a_in_t = F.relu(F.batch_norm(y_prev, None, None, g2, b2, True, 0.1, 1e-5))
+    a_in = q(a_in_t.detach(), dtype)
+    a_leaf = a_in.clone().requires_grad_(True)
+    w = q(torch.randn(co, ci, 1, 1, generator=g) / ci ** 0.5, dtype)
+    y = q(F.conv2d(a_leaf, w), dtype)            # stored in the compute dtype, as the engine does
+    y_leaf = y.detach().clone().requires_grad_(True)
+    gamma = (0.5 + torch.rand(co, generator=g))
+    beta = torch.rand(co, generator=g) - 0.5
+    z = F.batch_norm(y_leaf, None, None, gamma, beta, True, 0.1, 1e-5)
+    dz = q(torch.randn(z.shape, generator=g) + 0.3, dtype)
+    (dy_ref,) = torch.autograd.grad(z, y_leaf, dz)
+    dx_ref = F.conv_transpose2d(dy_ref, w)       # gradient of the 1x1 conv wrt a_in, from the UNROUNDED dy
+    # GPU
+    yn = nhwc(y.detach())
+    rows = yn.numel() // co
+    mean = yn.reshape(rows, co).mean(0)
+    var = yn.reshape(rows, co).var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    dzn = nhwc(dz)
+    xhat = (yn - mean) * invstd
+    st = torch.stack([dzn.reshape(rows, co).sum(0), (dzn * xhat).reshape(rows, co).sum(0)])[None].contiguous()   # one "tile" of partial sums
+    dgamma, dbeta, c1c2 = ops.bn_backward_coeffs(st.to(DEV), rows)
+    assert rel_err(dbeta, dzn.reshape(rows, co).sum(0)) < 1e-5
+    wf = w.reshape(co, ci).to(dtype).to(DEV).contiguous()
+    wd = wf.t().contiguous()
+    wk, bias = ops.bn_bwd_fold_conv1x1(wf, wd, gamma.to(DEV), invstd.to(DEV), mean.to(DEV), c1c2)
+    a_d, dz_d = nhwc(a_in).to(dtype).to(DEV), dzn.to(dtype).to(DEV)
+    t = {torch.float32: 1e-4, torch.bfloat16: 3e-2, torch.float16: 5e-3}[dtype]
+    if not epilogue:
+        dx = ops.conv1x1_dgrad_kcat(dz_d, a_d, wk, bias)
+        assert rel_err(nchw(dx), dx_ref) < t
+        # and the streaming form of the same BN backward (what still feeds the weight gradient)
+        dy = ops.bn_backward_apply_dz(dz_d, yn.to(dtype).to(DEV), mean.to(DEV), invstd.to(DEV), gamma.to(DEV), c1c2)
+        assert rel_err(nchw(dy), dy_ref) < t
+        return
+    # with the epilogue of the layer behind (mask recomputed from y_prev, BN2 partial sums)
+    ypn = nhwc(y_prev.detach())
+    m2 = ypn.reshape(rows, ci).mean(0)
+    r2 = 1.0 / torch.sqrt(ypn.reshape(rows, ci).var(0, unbiased=False) + 1e-5)
+    sc2 = g2.detach() * r2
+    sh2 = b2.detach() - m2 * sc2
+    dzin, st2 = ops.conv1x1_dgrad_kcat(dz_d, a_d, wk, bias, bn=dict(y=ypn.to(dtype).to(DEV), mean=m2.to(DEV), invstd=r2.to(DEV), scale=sc2.to(DEV), shift=sh2.to(DEV)))
+    dyp, dg2, db2 = ops.bn_backward_from_dz(dzin, ypn.to(dtype).to(DEV), m2.to(DEV), r2.to(DEV), g2.detach().to(DEV), st2)
+    dyp_ref, dg2_ref, db2_ref = torch.autograd.grad(a_in_t, (y_prev, g2, b2), dx_ref)
+    assert rel_err(nchw(dyp), dyp_ref) < t
+    assert rel_err(dg2, dg2_ref) < t and rel_err(db2, db2_ref) < t
+
+
 def test_pack_conv_weight():
     w = torch.randn(64, 3, 3, 128)
     wf, wd = ops.pack_conv_weight(w.to(DEV), torch.bfloat16)
