@@ -249,7 +249,7 @@ def main():
                 "kernels": sorted(({"kernel": k["kernel"], "launches_per_step": k["launches"] // n_prof, "ms_per_step": round(k["ms"] / n_prof, 3),
                                     "tflops": round(k["flops"] / 1e12 / (k["ms"] / 1e3), 1) if k["flops"] else None,
                                     "gbs": round(k["bytes"] / 1e9 / (k["ms"] / 1e3), 1) if k["bytes"] else None} for k in syms),
-                                  key=lambda k: -k["ms_per_step"])[:8],
+                                  key=lambda k: -k["ms_per_step"])[:int(os.environ.get("RPE_BENCH_TOPK", "8"))],
                 "families": {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in fam.items()}}
 
     if rank == 0:

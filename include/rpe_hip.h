@@ -100,6 +100,11 @@ int rpe_bn_bwd_fold_conv1x1(int dtype, int out_c, int in_c, const void* w_fwd, c
                             const float* mean, const float* c1c2, void* w_kcat, float* bias, void* scratch, long scratch_bytes, void* stream);
 int rpe_conv1x1_dgrad_kcat(const rpe_conv_desc* d, int dtype, const void* dz, const void* a_in, const void* w_kcat, const float* bias, void* dx,
                            const rpe_bn_bwd_epilogue* bn, void* stream);
+/* The weight-gradient side of the same fold: dw[out_c][in_c] (fp32, OVERWRITTEN) = A o (dz^T a_in) + B' colsum(a_in)^T + C' o (W S),
+ * S = a_in^T a_in -- reads dz and a_in only, no dy.  w_master: the fp32 weight [out_c][in_c].  Deterministic (slab sums). */
+long rpe_conv1x1_wgrad_folded_scratch_bytes(const rpe_conv_desc* d, int dtype);
+int rpe_conv1x1_wgrad_folded(const rpe_conv_desc* d, int dtype, const void* dz, const void* a_in, const float* w_master, const float* gamma,
+                             const float* invstd, const float* mean, const float* c1c2, float* dw, void* scratch, long scratch_bytes, void* stream);
 /* the two halves of rpe_bn_backward_from_dz as separate calls (c1c2: [2][C] fp32 = mean(dz), mean(dz xhat)) */
 int rpe_bn_backward_coeffs(const float* stats_part, int tiles, int C, long rows, float* dgamma, float* dbeta, float* c1c2, double* dpart, void* stream);
 int rpe_bn_backward_apply_dz(int dtype, const void* dz, const void* y, const float* mean, const float* invstd, const float* gamma, const float* c1c2,

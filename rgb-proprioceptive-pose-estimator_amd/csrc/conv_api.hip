@@ -201,6 +201,128 @@ template <typename T> static int bn_fold_scratch_t(int Co, int Ci, long* bytes) 
     return 0;
 }
 
+// ---- the weight-gradient side of the same fold ------------------------------------------------
+//   dW[c][n] = sum_m dy[m][c] a_in[m][n] = A_c (dz^T a_in)[c][n] + B'_c colsum(a_in)[n] + C'_c (W (a_in^T a_in))[c][n]
+// (y = a_in W^T makes sum_m y[m][c] a_in[m][n] = (W S)[c][n] with S = a_in^T a_in, Ci x Ci): the weight gradient reads dz and
+// a_in only -- the streaming dz, y -> dy pass and the dy tensor disappear.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ x, long rows, int C, int rows_per_block, float* __restrict__ part) {
+    constexpr int CE = Elem<T>::kChunk;
+    __shared__ float sh[256][CE + 1];
+    const int cpr = C / CE;                       // chunks per row (a power of two <= 256 here)
+    const int ch = threadIdx.x % cpr, rl = threadIdx.x / cpr, rpp = 256 / cpr;
+    float acc[CE];
+#pragma unroll
+    for (int j = 0; j < CE; ++j) acc[j] = 0.f;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (long r = r0 + rl; r < r1; r += rpp) {
+        float f[CE];
+        chunk_to_f<T>(*(const u32x4*)(x + r * C + ch * CE), f);
+#pragma unroll
+        for (int j = 0; j < CE; ++j) acc[j] += f[j];
+    }
+#pragma unroll
+    for (int j = 0; j < CE; ++j) sh[threadIdx.x][j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < cpr) {
+#pragma unroll
+        for (int j = 0; j < CE; ++j) {
+            float t = 0.f;
+            for (int k = 0; k < rpp; ++k) t += sh[k * cpr + threadIdx.x][j];
+            part[(long)blockIdx.x * C + threadIdx.x * CE + j] = t;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double t = 0.0;
+    for (int b = 0; b < nb; ++b) t += (double)part[(long)b * C + c];
+    out[c] = (float)t;
+}
+// dw[c][n] = A_c dw[c][n] + B'_c s1[n] + C'_c ws[c][n]
+__global__ __launch_bounds__(256) void wgrad_fold_combine_kernel(float* __restrict__ dw, const float* __restrict__ ws, const float* __restrict__ s1,
+                                                                const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                                const float* __restrict__ mean, const float* __restrict__ c1, const float* __restrict__ c2,
+                                                                int Co, int Ci) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)Co * Ci) return;
+    const int c = (int)(idx / Ci), n = (int)(idx - (long)c * Ci);
+    const float a = gamma[c] * invstd[c];
+    const float cp = -a * invstd[c] * c2[c];
+    const float bp = -a * c1[c] - cp * mean[c];
+    dw[idx] = fmaf(a, dw[idx], fmaf(bp, s1[n], cp * ws[idx]));
+}
+
+struct WFoldPlan { long s_off, s1_off, part_off, ws_off, slab_off, total; int nb, rpb; };
+template <typename T> static int wfold_plan(long M, int Co, int Ci, WFoldPlan& pl) {
+    auto al = [](long b) { return (b + 255) / 256 * 256; };
+    long rpb = (M + 511) / 512;
+    if (rpb < 64) rpb = 64;
+    pl.rpb = (int)rpb;
+    pl.nb = (int)((M + rpb - 1) / rpb);
+    TNArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    long slab1 = 0, slab2 = 0;
+    a.M = (int)M; a.I = Co; a.J = Ci; a.ldp = Co; a.ldq = Ci; a.ldd = Ci;
+    if (int e = launch_tn<T>(a, MODE_DENSE, nullptr, &slab1)) return e;
+    memset(&a, 0, sizeof(a));
+    a.M = (int)M; a.I = Ci; a.J = Ci; a.ldp = Ci; a.ldq = Ci; a.ldd = Ci;
+    if (int e = launch_tn<T>(a, MODE_DENSE, nullptr, &slab2)) return e;
+    pl.s_off = 0;
+    pl.s1_off = pl.s_off + al((long)Ci * Ci * 4);
+    pl.part_off = pl.s1_off + al(Ci * 4L);
+    pl.ws_off = pl.part_off + al((long)pl.nb * Ci * 4);
+    pl.slab_off = pl.ws_off + al((long)Co * Ci * 4);
+    pl.total = pl.slab_off + (slab1 > slab2 ? slab1 : slab2);
+    return 0;
+}
+
+template <typename T>
+static int conv1x1_wgrad_folded_t(const rpe_conv_desc* d, const void* dz, const void* a_in, const float* w_master, const float* gamma, const float* invstd,
+                                  const float* mean, const float* c1c2, float* dw, void* scratch, long scratch_bytes, long* query, hipStream_t s) {
+    const long M = (long)d->batch * d->in_h * d->in_w;
+    const int Co = d->out_c, Ci = d->in_c;
+    WFoldPlan pl;
+    if (int e = wfold_plan<T>(M, Co, Ci, pl)) return e;
+    if (query) { *query = pl.total; return 0; }
+    if (!scratch || scratch_bytes < pl.total) return rpe_set_error(RPE_ERR_WORKSPACE, "conv1x1_wgrad_folded: scratch smaller than rpe_conv1x1_wgrad_folded_scratch_bytes()");
+    if ((Ci % Elem<T>::kChunk) || 256 % (Ci / Elem<T>::kChunk)) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_wgrad_folded: in_c / chunk must divide 256");
+    char* sc = (char*)scratch;
+    float *S = (float*)(sc + pl.s_off), *s1 = (float*)(sc + pl.s1_off), *part = (float*)(sc + pl.part_off), *ws = (float*)(sc + pl.ws_off);
+    float* slab = (float*)(sc + pl.slab_off);
+    const long slab_bytes = scratch_bytes - pl.slab_off;
+    TNArgs<T> a;
+    memset(&a, 0, sizeof(a));      // D1 = dz^T a_in -> dw
+    a.P = (const T*)dz; a.Q = (const T*)a_in; a.D = dw; a.slab = slab; a.slab_bytes = slab_bytes;
+    a.M = (int)M; a.I = Co; a.J = Ci; a.ldp = Co; a.ldq = Ci; a.ldd = Ci;
+    if (int e = launch_tn<T>(a, MODE_DENSE, s)) return e;
+    char name[96];
+    snprintf(name, sizeof(name), "%s", g_last_kernel);
+    memset(&a, 0, sizeof(a));      // S = a_in^T a_in
+    a.P = (const T*)a_in; a.Q = (const T*)a_in; a.D = S; a.slab = slab; a.slab_bytes = slab_bytes;
+    a.M = (int)M; a.I = Ci; a.J = Ci; a.ldp = Ci; a.ldq = Ci; a.ldd = Ci;
+    if (int e = launch_tn<T>(a, MODE_DENSE, s)) return e;
+    hipLaunchKernelGGL((colsum_part_kernel<T>), dim3(pl.nb), dim3(256), 0, s, (const T*)a_in, M, Ci, pl.rpb, part);
+    RPE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((Ci + 255) / 256), dim3(256), 0, s, part, pl.nb, Ci, s1);
+    RPE_CHECK_LAUNCH();
+    {   // ws = W S  (fp32, exact-MFMA GEMM: [Co][Ci] x [Ci][Ci]; S is symmetric, so it serves as the [N][K] operand as it stands)
+        NTArgs<float> n;
+        memset(&n, 0, sizeof(n));
+        n.A = w_master; n.Bw = S; n.C = ws;
+        n.M = Co; n.N = Ci; n.K = Ci; n.lda = Ci; n.ldb = Ci; n.ldc = Ci;
+        n.role = 2;
+        if (int e = launch_nt<float>(n, MODE_DENSE, s)) return e;
+    }
+    hipLaunchKernelGGL(wgrad_fold_combine_kernel, dim3((unsigned)(((long)Co * Ci + 255) / 256)), dim3(256), 0, s, dw, ws, s1, gamma, invstd, mean, c1c2, c1c2 + Co, Co, Ci);
+    RPE_CHECK_LAUNCH();
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "%.70s + fold(S, colsum, WS)", name);
+    return 0;
+}
+
 // data gradient of a 1x1 / stride-1 conv from A = [dz (M x Co) | a_in (M x Ci)] and the folded weight w_kcat [Ci][Co + Ci]
 template <typename T>
 static int conv1x1_dgrad_kcat_t(const rpe_conv_desc* d, const void* dz, const void* a_in, const void* w_kcat, const float* bias, void* dx,
@@ -344,6 +466,25 @@ int rpe_bn_bwd_fold_conv1x1(int dtype, int out_c, int in_c, const void* w_fwd, c
     if (out_c <= 0 || in_c <= 0 || (out_c % 64) || (in_c % 8) || !w_fwd || !w_dgrad || !gamma || !invstd || !mean || !c1c2 || !w_kcat || !bias)
         return rpe_set_error(RPE_ERR_SHAPE, "bn_bwd_fold_conv1x1: bad arguments (out_c % 64 == 0, in_c % 8 == 0)");
     DISPATCH(dtype, bn_fold_t, out_c, in_c, w_fwd, w_dgrad, gamma, invstd, mean, c1c2, w_kcat, bias, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+static int wfold_dispatch(const rpe_conv_desc* d, int dtype, const void* dz, const void* a_in, const float* w_master, const float* gamma, const float* invstd,
+                          const float* mean, const float* c1c2, float* dw, void* scratch, long scratch_bytes, long* query, hipStream_t s) {
+    DISPATCH(dtype, conv1x1_wgrad_folded_t, d, dz, a_in, w_master, gamma, invstd, mean, c1c2, dw, scratch, scratch_bytes, query, s);
+}
+
+long rpe_conv1x1_wgrad_folded_scratch_bytes(const rpe_conv_desc* d, int dtype) {
+    long bytes = 0;
+    if (check_desc(d) || wfold_dispatch(d, dtype, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &bytes, nullptr)) return -1;
+    return bytes;
+}
+
+int rpe_conv1x1_wgrad_folded(const rpe_conv_desc* d, int dtype, const void* dz, const void* a_in, const float* w_master, const float* gamma,
+                             const float* invstd, const float* mean, const float* c1c2, float* dw, void* scratch, long scratch_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    if (d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_wgrad_folded: 1x1 / stride 1 / no padding only");
+    if (!dz || !a_in || !w_master || !gamma || !invstd || !mean || !c1c2 || !dw) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_wgrad_folded: null argument");
+    return wfold_dispatch(d, dtype, dz, a_in, w_master, gamma, invstd, mean, c1c2, dw, scratch, scratch_bytes, nullptr, (hipStream_t)stream);
 }
 
 int rpe_conv1x1_dgrad_kcat(const rpe_conv_desc* d, int dtype, const void* dz, const void* a_in, const void* w_kcat, const float* bias, void* dx,

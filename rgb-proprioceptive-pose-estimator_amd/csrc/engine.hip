@@ -93,6 +93,9 @@ struct rpe_resnet50 {
     float* fold_bias = nullptr;  // [planes]
     void* fold_scratch = nullptr;
     long fold_scratch_bytes = 0;
+    void* wfold_scratch = nullptr;   // side-stream scratch of the folded weight gradient (S, colsum, W S, slabs)
+    long wfold_scratch_bytes = 0;
+    bool fold_w = true;
     void* main_slab = nullptr;   // the same for the two weight gradients that run on the caller's stream (stem conv, fc)
     long main_slab_bytes = 0;
     void* wg_slab = nullptr;     // per-workgroup fp32 tiles of the deterministic weight-gradient form (one launch at a time: side stream order)
@@ -271,6 +274,14 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
             if (sb > e->fold_scratch_bytes) e->fold_scratch_bytes = sb;
             const long w = (long)d.in_c * (d.out_c + d.in_c) * (long)es;
             if (w > wk) wk = w;
+        }
+        e->fold_w = getenv("RPE_NO_WGRAD_FOLD") == nullptr;
+        if (e->fold_w) {
+            for (auto& b : e->blocks) {
+                const long sb = rpe_conv1x1_wgrad_folded_scratch_bytes(&e->convs[b.c3].d, dtype);
+                if (sb > e->wfold_scratch_bytes) e->wfold_scratch_bytes = sb;
+            }
+            if (e->wfold_scratch_bytes > 0) want(e, &e->wfold_scratch, e->wfold_scratch_bytes);
         }
         want(e, &e->w_kcat, wk);
         want(e, (void**)&e->fold_bias, 512L * 4);
@@ -674,16 +685,24 @@ static int conv1x1_backward_folded(rpe_resnet50* e, ConvL& c, const void* dz, Co
         HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
         run = e->side;
     }
+    float* dw = e->grads[c.p_w];
+    if (e->fold_w && e->wfold_scratch) {
+        // weight gradient from dz and x alone (no dy): dz^T x, x^T x, colsum(x), W (x^T x), combine
+        e->pending_flops = conv_flops(c) * (1.0 + (double)c.d.in_c / c.d.out_c);
+        e->pending_bytes = conv_out_bytes(e, c) + 3.0 * conv_in_bytes(e, c);
+        PROF(e, RPE_PROF_CONV_WGRAD, run, rpe_conv1x1_wgrad_folded(&c.d, e->dtype, dz, x, e->params[c.p_w], e->params[c.p_g], c.invstd, c.mean, c.c1c2, dw,
+                                                                  e->wfold_scratch, e->wfold_scratch_bytes, run));
+    } else {
     e->pending_bytes = conv_out_bytes(e, c) * 3.0;   // dz, y -> dy
     PROF(e, RPE_PROF_BN_BWD, run, rpe_bn_backward_apply_dz(e->dtype, dz, c.y, c.mean, c.invstd, e->params[c.p_g], c.c1c2, c.dy, c.rows, c.d.out_c, run));
     e->pending_flops = conv_flops(c);
     e->pending_bytes = conv_in_bytes(e, c) + conv_out_bytes(e, c);
-    float* dw = e->grads[c.p_w];
     if (e->wg_slab) {
         PROF(e, RPE_PROF_CONV_WGRAD, run, rpe_conv2d_wgrad_det(&c.d, e->dtype, x, c.dy, dw, e->wg_slab, e->wg_slab_bytes, run));
     } else {
         if (!e->gspan_lo) HIPTRY(hipMemsetAsync(dw, 0, (size_t)e->pnumel[c.p_w] * 4, run));
         PROF(e, RPE_PROF_CONV_WGRAD, run, rpe_conv2d_wgrad(&c.d, e->dtype, x, c.dy, dw, run));
+    }
     }
     e->pending_bytes = 0;
     PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_bwd_fold_conv1x1(e->dtype, c.d.out_c, c.d.in_c, fwd_weight(e, c), c.wd, e->params[c.p_g], c.invstd, c.mean, c.c1c2,

@@ -164,6 +164,19 @@ def bn_bwd_fold_conv1x1(w_fwd, w_dgrad, gamma, invstd, mean, c1c2):
     return wk, bias
 
 
+def conv1x1_wgrad_folded(dz, a_in, w_master, gamma, invstd, mean, c1c2):
+    """dW [Co, Ci] fp32 of a 1x1 conv with its output BN's backward folded in: reads dz and the conv input only."""
+    _chk(dz, "dz"), _chk(a_in, "a_in")
+    b, h, w, co = dz.shape
+    ci = a_in.shape[3]
+    d = conv_desc((b, h, w, ci), co, 1, 1, 0)
+    dw = torch.empty((co, ci), dtype=torch.float32, device=dz.device)
+    ws = scratch(lib.rpe_conv1x1_wgrad_folded_scratch_bytes(ctypes.byref(d), dtype_code(dz)), dz.device)
+    lib.rpe_conv1x1_wgrad_folded(ctypes.byref(d), dtype_code(dz), _p(dz), _p(a_in), _p(_chk(w_master, "w")), _p(gamma), _p(invstd), _p(mean), _p(c1c2), _p(dw),
+                                 _p(ws), ws.numel(), _stream())
+    return dw
+
+
 def conv1x1_dgrad_kcat(dz, a_in, w_kcat, bias, bn=None):
     """dz [B,H,W,Co], a_in [B,H,W,Ci] -> dx [B,H,W,Ci].  bn: optional dict(y, mean, invstd, scale, shift, a_out, a_mask) of the
     layer BEHIND a_in (fused ReLU mask + BN-backward partial sums, as conv2d_dgrad_bn); then returns (dz_in, stats)."""

