@@ -278,6 +278,7 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
         e->fold_w = getenv("RPE_NO_WGRAD_FOLD") == nullptr;
         if (e->fold_w) {
             for (auto& b : e->blocks) {
+                if (e->convs[b.c3].d.in_c > 128) continue;   // layers 1-2: where the 4-planes-wide tensors are big
                 const long sb = rpe_conv1x1_wgrad_folded_scratch_bytes(&e->convs[b.c3].d, dtype);
                 if (sb > e->wfold_scratch_bytes) e->wfold_scratch_bytes = sb;
             }
@@ -686,7 +687,7 @@ static int conv1x1_backward_folded(rpe_resnet50* e, ConvL& c, const void* dz, Co
         run = e->side;
     }
     float* dw = e->grads[c.p_w];
-    if (e->fold_w && e->wfold_scratch) {
+    if (e->fold_w && e->wfold_scratch && c.d.in_c <= 128) {
         // weight gradient from dz and x alone (no dy): dz^T x, x^T x, colsum(x), W (x^T x), combine
         e->pending_flops = conv_flops(c) * (1.0 + (double)c.d.in_c / c.d.out_c);
         e->pending_bytes = conv_out_bytes(e, c) + 3.0 * conv_in_bytes(e, c);
@@ -780,7 +781,7 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
         const void* x_in = bi == 0 ? (const void*)e->pool : (const void*)e->convs[e->blocks[bi - 1].c3].a;
         void* gA = b.dz;                                             // dz3 (for the last block: the raw dA)
         void* gD = bi == 0 ? e->d_pool : e->blocks[bi - 1].dz;       // where the gradient of the block input goes
-        if (e->fold && bi != (int)e->blocks.size() - 1 && e->train_mode) {
+        if (e->fold && c3.d.in_c <= 256 && e->train_mode) {   // layers 1-3 (layer4's tensors are small: the unfolded form is faster there)
             TRY(conv1x1_backward_folded(e, c3, gA, c2, stream));                                  // dz2 (dy3 exists on the side stream only)
         } else {
             if (bi == (int)e->blocks.size() - 1) TRY(bn_back(e, c3, gA, 1, c3.dy, gA, stream));  // unfused: dy3, dz3 (in place)

@@ -65,6 +65,12 @@ template <typename T> struct TNArgs {
     const T* P;     // [M][ldp]   (dy / upstream gradient), columns i (Cout)
     const T* Q;     // im2col source (dense [M][ldq] or NHWC tensor described by g), columns j (K)
     float* D;       // [I][ldd] fp32: D[i][j] += sum_m P[m][i] * Q[m][j] with atomics, or (slab mode) D[i][j] = that sum, overwritten
+    // Row-concatenated P (dense DMA path): output rows i in [I1, I1 + I2) take their P columns from a second tensor P2[M][ldp2]
+    // (I1 a multiple of the I tile), and the tile starting at row ones_i0 (>= 0, a multiple of the I tile) multiplies Q by an
+    // all-ones P: its rows are the column sums of Q.  One launch then yields dz^T x, x^T x and colsum(x) (folded weight gradient).
+    const T* P2;
+    int ldp2, I1, I2, ones_i0;
+    unsigned p2_bytes;
     float* slab;    // optional workspace of >= slab_bytes (16-byte aligned): per-workgroup fp32 tiles, summed by tn_reduce_kernel in a
     long slab_bytes;  // fixed order (deterministic, no float atomics); null -> atomic accumulation into D
     int accumulate;   // slab mode: D += sum instead of D = sum

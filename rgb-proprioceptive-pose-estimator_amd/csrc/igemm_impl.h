@@ -654,7 +654,11 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
     typedef __attribute__((address_space(3))) char lds_char;
     typedef __attribute__((address_space(3))) void lds_void;
     constexpr unsigned OOB = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)p.P, 0, (int)p.p_bytes, 0x00020000);
+    // which tensor this tile's P columns come from (uniform per workgroup): P, P2 (rows >= I1), or none (the all-ones tile)
+    const bool ones_tile = DMA && MODE == MODE_DENSE && p.ones_i0 > 0 && i0 == p.ones_i0;
+    const bool second_p = DMA && MODE == MODE_DENSE && p.P2 != nullptr && i0 >= p.I1 && !ones_tile;
+    const int p_col0 = second_p ? i0 - p.I1 : i0, p_cols = ones_tile ? 0 : (second_p ? p.I2 : (p.P2 ? p.I1 : p.I)), p_ld = second_p ? p.ldp2 : p.ldp;
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)(second_p ? p.P2 : p.P), 0, (int)(second_p ? p.p2_bytes : p.p_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)p.Q, 0, (int)p.q_bytes, 0x00020000);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     unsigned p_voff[NPI], q_voff[NPJ];
@@ -677,7 +681,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
         for (int i = 0; i < NPI; ++i) {
             const int row = p_r + i * RPI;
             const int cc = p_slot ^ tn_swz<T, CPI>(row);
-            p_voff[i] = (i0 + cc * CE) < p.I ? (unsigned)(((long)(m_begin + row) * p.ldp + i0 + cc * CE) * ES) : OOB;
+            p_voff[i] = (p_col0 + cc * CE) < p_cols ? (unsigned)(((long)(m_begin + row) * p_ld + p_col0 + cc * CE) * ES) : OOB;
         }
 #pragma unroll
         for (int i = 0; i < NPJ; ++i) {
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
             }
         }
     }
-    const unsigned p_step = (unsigned)(BMK * p.ldp * ES), q_step = (unsigned)(BMK * p.ldq * ES);
+    const unsigned p_step = (unsigned)(BMK * p_ld * ES), q_step = (unsigned)(BMK * p.ldq * ES);
     auto dma_tile = [&](int st) {
         lds_char* base = (lds_char*)lds + st * (STAGE * 16);
 #pragma unroll
@@ -772,6 +776,11 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
             // it receives column base + (l&15) for rows 8g + 4h + 0..3  -> MFMA k = 8g + (4h + e)
             const int q = fl >> 2, pp = fl & 3;
             u32x4 pf[FI], qf[FJ];
+            if (ones_tile) {   // P = all ones: the tile's rows become the column sums of Q
+                const unsigned one2 = Elem<T>::kDtype == RPE_BF16 ? 0x3F803F80u : 0x3C003C00u;
+#pragma unroll
+                for (int a = 0; a < FI; ++a) pf[a] = u32x4{one2, one2, one2, one2};
+            } else
 #pragma unroll
             for (int a = 0; a < FI; ++a) {
                 const int col = wave_i * WI + a * 16 + 4 * pp;  // element column inside the tile
@@ -815,7 +824,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
 #pragma unroll
                 for (int a = 0; a < FI; ++a) {
                     const int col = wave_i * WI + a * 16 + fl;
-                    pf[a] = *(const float*)(pb + (row * CPI + ((col >> 2) ^ tn_swz<T, CPI>(row))) * 16 + (col & 3) * 4);
+                    pf[a] = ones_tile ? 1.f : *(const float*)(pb + (row * CPI + ((col >> 2) ^ tn_swz<T, CPI>(row))) * 16 + (col & 3) * 4);
                 }
 #pragma unroll
                 for (int b = 0; b < FJ; ++b) {
@@ -1075,6 +1084,13 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
     if (dma && (pb <= 0 || qb <= 0 || pb >= (1L << 31) || qb >= (1L << 31)))
         return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: an operand of 2 GiB or more (split the batch)");
     a.p_bytes = (unsigned)pb; a.q_bytes = (unsigned)qb;
+    if (a.P2 || a.ones_i0 > 0) {
+        const long p2b = (long)a.M * a.ldp2 * (long)sizeof(T);
+        if (!dma || MODE != MODE_DENSE || !a.P2 || (a.I1 % BI) || (a.ones_i0 > 0 && (a.ones_i0 % BI)) || a.I1 <= 0 || a.I2 <= 0 || (a.ldp2 % Elem<T>::kChunk) ||
+            (((uintptr_t)a.P2) & 15) || p2b <= 0 || p2b >= (1L << 31))
+            return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: bad row-concatenated P operand (dense DMA path, I1 / ones_i0 multiples of the I tile)");
+        a.p2_bytes = (unsigned)p2b;
+    }
     snprintf(g_last_kernel, sizeof(g_last_kernel), "tn_kernel<%s,%d,%d,%d,%d,%d,%d,%d>", Elem<T>::kName, BI, BJ, MODE, dma ? 1 : 0, dma ? ksub : 1,
              dma ? nslot : 2, a.slab ? 1 : 0);
     if (!dma) {
