@@ -155,6 +155,13 @@ int rpe_stage_image_nhwc4(int dtype, const float* img_nchw, void* out, int B, in
  * centre-cropped to (H, W), normalised with the HOST arrays mean3/std3 and written as NHWC4 in the compute dtype. */
 int rpe_stage_frames_u8(int dtype, const unsigned char* frames, void* out, int B, int Hs, int Ws, int H, int W, const float* mean3_host,
                         const float* std3_host, void* stream);
+/* The same for frames whose shorter side is not the transform's resize target: Pillow's antialiased 8-bit bilinear resample
+ * (Resize(256) on a PIL image, util/data_utils.py:48-54) to Hr x Wr in its own 22-bit fixed-point arithmetic, then the crop of
+ * H x W at (top, left) and the normalisation.  xb/yb: [Wr]/[Hr] x (first tap, tap count); xk/yk: [Wr][ksx] / [Hr][ksy] int32 weights
+ * (device pointers; a pass whose size does not change takes nulls); tmp: B*Hs*Wr*3 bytes of device scratch. */
+int rpe_stage_frames_u8_resized(int dtype, const unsigned char* frames, void* out, int B, int Hs, int Ws, int Hr, int Wr, int top, int left, int H, int W,
+                                const int* xb, const int* xk, int ksx, const int* yb, const int* yk, int ksy, unsigned char* tmp, const float* mean3_host,
+                                const float* std3_host, void* stream);
 
 /* ------------------------------------------------------------------ batch norm */
 /* replaces: nn.BatchNorm2d (train mode: biased batch variance, eps, momentum with
@@ -309,6 +316,14 @@ int rpe_resnet50_forward(rpe_resnet50_t* e, const float* img_nchw, float* featur
 /* the same from raw simulator frames (uint8 [B][Hs][Ws][3]): crop + normalise + stage in one kernel (rpe_stage_frames_u8) */
 int rpe_resnet50_forward_u8(rpe_resnet50_t* e, const unsigned char* frames, int Hs, int Ws, const float* mean3_host, const float* std3_host,
                             float* features, long ld_features, int training, void* stream);
+/* ... with the resize in front (rpe_stage_frames_u8_resized); `rs`: its geometry and device tables */
+typedef struct {
+    int Hr, Wr, top, left, ksx, ksy;
+    const int *xb, *xk, *yb, *yk;
+    unsigned char* tmp;
+} rpe_resize_plan;
+int rpe_resnet50_forward_u8_resized(rpe_resnet50_t* e, const unsigned char* frames, int Hs, int Ws, const rpe_resize_plan* rs, const float* mean3_host,
+                                    const float* std3_host, float* features, long ld_features, int training, void* stream);
 /* the hooked early feature relu(bn1(conv1 x)): NHWC [B][H/2][W/2][64] in the compute dtype (inside the workspace) */
 const void* rpe_resnet50_early_feature(const rpe_resnet50_t* e);
 /* gradient buffer of the early feature; the caller writes d(loss)/d(early) there (or passes use_d_early = 0) */

@@ -27,6 +27,10 @@ class BnBwdEpilogue(Structure):
     _fields_ = [(n, c_void_p) for n in ("y", "a_out", "mean", "invstd", "scale", "shift", "stats_part", "a_mask")]
 
 
+class ResizePlan(Structure):
+    _fields_ = [(n, c_int) for n in ("Hr", "Wr", "top", "left", "ksx", "ksy")] + [(n, c_void_p) for n in ("xb", "xk", "yb", "yk", "tmp")]
+
+
 class ConvDesc(Structure):
     _fields_ = [(n, c_int) for n in ("batch", "in_h", "in_w", "in_c", "out_c", "kh", "kw", "stride", "pad")]
 
@@ -67,6 +71,7 @@ _SPEC = {
     "rpe_unpack_stem_grad": (I, [P, P, P]),
     "rpe_stage_image_nhwc4": (I, [I, P, P, I, I, I, P]),
     "rpe_stage_frames_u8": (I, [I, P, P, I, I, I, I, I, POINTER(c_float), POINTER(c_float), P]),
+    "rpe_stage_frames_u8_resized": (I, [I, P, P, I, I, I, I, I, I, I, I, I, P, P, I, P, P, I, P, POINTER(c_float), POINTER(c_float), P]),
     "rpe_bn_finalize": (I, [P, I, I, L, P, P, P, P, P, F, F, P, P, P, P, P, P]),
     "rpe_bn_eval_affine": (I, [I, P, P, P, P, F, P, P, P]),
     "rpe_bn_apply": (I, [I, P, P, P, P, P, L, I, I, P]),
@@ -106,6 +111,7 @@ _SPEC = {
     "rpe_resnet50_weights_changed": (I, [P]),
     "rpe_resnet50_forward": (I, [P, P, P, L, I, P]),
     "rpe_resnet50_forward_u8": (I, [P, P, I, I, POINTER(c_float), POINTER(c_float), P, L, I, P]),
+    "rpe_resnet50_forward_u8_resized": (I, [P, P, I, I, POINTER(ResizePlan), POINTER(c_float), POINTER(c_float), P, L, I, P]),
     "rpe_resnet50_early_feature": (c_void_p, [P]),
     "rpe_resnet50_early_grad": (c_void_p, [P]),
     "rpe_resnet50_backward": (I, [P, P, L, I, P]),

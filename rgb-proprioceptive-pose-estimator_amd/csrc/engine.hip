@@ -551,13 +551,15 @@ static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residua
 }
 
 static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned char* frames, int Hs, int Ws, const float* mean3, const float* std3,
-                        float* features, long ld_features, int training, void* stream) {
+                        float* features, long ld_features, int training, void* stream, const rpe_resize_plan* rs = nullptr) {
     if (!e || !e->bound) return rpe_set_error(RPE_ERR_STATE, "resnet50_forward: engine not bound");
     if ((!img_nchw && !frames) || !features || ld_features < e->latent) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_forward: bad img/features");
     e->train_mode = training;
     if (training && e->pack_state != 1) TRY(rpe_resnet50_pack_weights(e, stream));
     if (!training && e->pack_state != 2) TRY(fold_for_eval(e, stream));
-    if (frames) PROF(e, RPE_PROF_OTHER, stream, rpe_stage_frames_u8(e->dtype, frames, e->x4, e->B, Hs, Ws, e->H, e->W, mean3, std3, stream));
+    if (frames && rs) PROF(e, RPE_PROF_OTHER, stream, rpe_stage_frames_u8_resized(e->dtype, frames, e->x4, e->B, Hs, Ws, rs->Hr, rs->Wr, rs->top, rs->left, e->H, e->W,
+                                                                                    rs->xb, rs->xk, rs->ksx, rs->yb, rs->yk, rs->ksy, rs->tmp, mean3, std3, stream));
+    else if (frames) PROF(e, RPE_PROF_OTHER, stream, rpe_stage_frames_u8(e->dtype, frames, e->x4, e->B, Hs, Ws, e->H, e->W, mean3, std3, stream));
     else PROF(e, RPE_PROF_OTHER, stream, rpe_stage_image_nhwc4(e->dtype, img_nchw, e->x4, e->B, e->H, e->W, stream));
     ConvL& st = e->convs[0];
     TRY(conv_bn(e, st, e->x4, nullptr, 1, stream));
@@ -608,6 +610,12 @@ extern "C" int rpe_resnet50_forward_u8(rpe_resnet50_t* e, const unsigned char* f
                                        const float* std3_host, float* features, long ld_features, int training, void* stream) {
     if (!frames) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_forward_u8: null frames");
     return forward_impl(e, nullptr, frames, Hs, Ws, mean3_host, std3_host, features, ld_features, training, stream);
+}
+
+extern "C" int rpe_resnet50_forward_u8_resized(rpe_resnet50_t* e, const unsigned char* frames, int Hs, int Ws, const rpe_resize_plan* rs,
+                                               const float* mean3_host, const float* std3_host, float* features, long ld_features, int training, void* stream) {
+    if (!frames || !rs) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_forward_u8_resized: null frames / resize plan");
+    return forward_impl(e, nullptr, frames, Hs, Ws, mean3_host, std3_host, features, ld_features, training, stream, rs);
 }
 
 extern "C" const void* rpe_resnet50_early_feature(const rpe_resnet50_t* e) { return e ? e->convs[0].a : nullptr; }

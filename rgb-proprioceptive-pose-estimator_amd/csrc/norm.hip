@@ -605,6 +605,62 @@ __global__ __launch_bounds__(256) void frames_u8_to_nhwc4_kernel(const unsigned 
     }
 }
 
+// Frames whose shorter side is not the resize target: Pillow's antialiased 8-bit bilinear resample (what Resize(256) on a PIL image
+// runs, util/data_utils.py:48-54) in its own arithmetic -- per output pixel a window of taps with 22-bit fixed-point weights
+// (tables built on the host in double precision, util/data_utils.py pil_bilinear_tables), accumulated from 1 << 21 and shifted
+// back, horizontally into an 8-bit intermediate, then vertically -- so the result is bit-identical to the CPU transform.
+__global__ __launch_bounds__(256) void resize_h_u8_kernel(const unsigned char* __restrict__ fr, unsigned char* __restrict__ tmp, int B, int Hs, int Ws, int Wr,
+                                                         const int* __restrict__ xb, const int* __restrict__ xk, int ksx) {
+    const long total = (long)B * Hs * Wr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int xo = (int)(i % Wr);
+        const long row = i / Wr;   // b * Hs + y
+        const int x0 = xb[2 * xo], n = xb[2 * xo + 1];
+        const unsigned char* p = fr + (row * Ws + x0) * 3;
+        const int* k = xk + (long)xo * ksx;
+        int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+        for (int t = 0; t < n; ++t) { const int kv = k[t]; s0 += p[3 * t] * kv; s1 += p[3 * t + 1] * kv; s2 += p[3 * t + 2] * kv; }
+        unsigned char* o = tmp + i * 3;
+        o[0] = (unsigned char)min(max(s0 >> 22, 0), 255); o[1] = (unsigned char)min(max(s1 >> 22, 0), 255); o[2] = (unsigned char)min(max(s2 >> 22, 0), 255);
+    }
+}
+// vertical pass + centre crop (top, left inside the resized Hr x Wr image) + (x/255 - mean)/std -> NHWC4 compute type
+template <typename T>
+__global__ __launch_bounds__(256) void resize_v_crop_norm_kernel(const unsigned char* __restrict__ tmp, T* __restrict__ out, int B, int Hs, int Wr, int top, int left,
+                                                                int H, int W, const int* __restrict__ yb, const int* __restrict__ yk, int ksy, int vertical,
+                                                                float m0, float m1, float m2, float i0, float i1, float i2) {
+    const long total = (long)B * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        const long t2 = i / W;
+        const int h = (int)(t2 % H);
+        const long b = t2 / H;
+        const int yo = top + h, xo = left + w;
+        int c0, c1, c2;
+        if (vertical) {
+            const int y0 = yb[2 * yo], n = yb[2 * yo + 1];
+            const int* k = yk + (long)yo * ksy;
+            int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+            for (int t = 0; t < n; ++t) {
+                const unsigned char* p = tmp + ((b * Hs + y0 + t) * Wr + xo) * 3;
+                const int kv = k[t];
+                s0 += p[0] * kv; s1 += p[1] * kv; s2 += p[2] * kv;
+            }
+            c0 = min(max(s0 >> 22, 0), 255); c1 = min(max(s1 >> 22, 0), 255); c2 = min(max(s2 >> 22, 0), 255);
+        } else {
+            const unsigned char* p = tmp + ((b * Hs + yo) * Wr + xo) * 3;
+            c0 = p[0]; c1 = p[1]; c2 = p[2];
+        }
+        const float r = ((float)c0 * (1.f / 255.f) - m0) * i0, g = ((float)c1 * (1.f / 255.f) - m1) * i1, bl = ((float)c2 * (1.f / 255.f) - m2) * i2;
+        if (sizeof(T) == 4) {
+            *(f32x4*)(out + i * 4) = f32x4{r, g, bl, 0.f};
+        } else {
+            u32x2 v; v.x = pack2<T>(r, g); v.y = pack2<T>(bl, 0.f);
+            *(u32x2*)(out + i * 4) = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -917,6 +973,32 @@ int rpe_stage_frames_u8(int dtype, const unsigned char* frames, void* out, int B
     else if (dtype == RPE_BF16) hipLaunchKernelGGL((frames_u8_to_nhwc4_kernel<bf16>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, frames, (bf16*)out, B, Hs, Ws, H, W, mean3_host[0], mean3_host[1], mean3_host[2], i0, i1, i2);
     else if (dtype == RPE_F16) hipLaunchKernelGGL((frames_u8_to_nhwc4_kernel<f16>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, frames, (f16*)out, B, Hs, Ws, H, W, mean3_host[0], mean3_host[1], mean3_host[2], i0, i1, i2);
     else return rpe_set_error(RPE_ERR_DTYPE, "stage_frames_u8: unsupported dtype");
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_stage_frames_u8_resized(int dtype, const unsigned char* frames, void* out, int B, int Hs, int Ws, int Hr, int Wr, int top, int left, int H, int W,
+                                const int* xb, const int* xk, int ksx, const int* yb, const int* yk, int ksy, unsigned char* tmp, const float* mean3_host,
+                                const float* std3_host, void* stream) {
+    note_kernel("resize_h_u8_kernel + resize_v_crop_norm_kernel");
+    if (B <= 0 || H <= 0 || W <= 0 || Hr < top + H || Wr < left + W || top < 0 || left < 0 || !mean3_host || !std3_host || !frames || !out)
+        return rpe_set_error(RPE_ERR_SHAPE, "stage_frames_u8_resized: bad shape");
+    const bool horiz = Wr != Ws, vert = Hr != Hs;
+    if ((horiz && (!xb || !xk || ksx <= 0 || !tmp)) || (vert && (!yb || !yk || ksy <= 0))) return rpe_set_error(RPE_ERR_SHAPE, "stage_frames_u8_resized: missing tap tables / intermediate");
+    const unsigned char* mid = frames;
+    if (horiz) {
+        hipLaunchKernelGGL(resize_h_u8_kernel, dim3(ew_grid((long)B * Hs * Wr)), dim3(256), 0, (hipStream_t)stream, frames, tmp, B, Hs, Ws, Wr, xb, xk, ksx);
+        RPE_CHECK_LAUNCH();
+        mid = tmp;
+    }
+    const long n = (long)B * H * W;
+    const float i0 = 1.f / std3_host[0], i1 = 1.f / std3_host[1], i2 = 1.f / std3_host[2];
+#define RPE_RV(T) hipLaunchKernelGGL((resize_v_crop_norm_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, mid, (T*)out, B, Hs, Wr, top, left, H, W, yb, yk, ksy, vert ? 1 : 0, mean3_host[0], mean3_host[1], mean3_host[2], i0, i1, i2)
+    if (dtype == RPE_F32) RPE_RV(float);
+    else if (dtype == RPE_BF16) RPE_RV(bf16);
+    else if (dtype == RPE_F16) RPE_RV(f16);
+    else return rpe_set_error(RPE_ERR_DTYPE, "stage_frames_u8_resized: unsupported dtype");
+#undef RPE_RV
     RPE_CHECK_LAUNCH();
     return 0;
 }

@@ -10,7 +10,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import lib
+from ._lib import ResizePlan, lib
+from .util.data_utils import crop_origin, pil_bilinear_tables, resized_hw
 
 _STAGES = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))
 
@@ -59,6 +60,8 @@ class ResNet50Trunk(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
         self.compute_dtype = compute_dtype
         # device-side preprocessing of uint8 frames (the reference's transform, util/data_utils.py:48-54)
+        self.resize_to = 256   # Resize(256): frames whose shorter side differs are resampled on the device (Pillow's bilinear)
+        self._resize_plans = {}
         self.crop_hw = (224, 224)
         self.norm_mean = (0.485, 0.456, 0.406)
         self.norm_std = (0.229, 0.224, 0.225)
@@ -127,7 +130,7 @@ class ResNet50Trunk(nn.Module):
         if frames:
             b, hs, ws, c = img.shape
             h, w = self.crop_hw
-            assert c == 3 and img.is_contiguous() and hs >= h and ws >= w
+            assert c == 3 and img.is_contiguous()
         else:
             b, c, h, w = img.shape
             assert c == 3 and img.dtype == torch.float32 and img.is_contiguous()
@@ -144,14 +147,42 @@ class ResNet50Trunk(nn.Module):
         plan.wver = self._wver
         if frames:
             F3 = ctypes.c_float * 3
-            lib.rpe_resnet50_forward_u8(plan.handle, ops._p(img), hs, ws, F3(*self.norm_mean), F3(*self.norm_std), ops._p(features),
-                                        features.stride(0), int(training), s)
+            hr, wr = resized_hw(hs, ws, self.resize_to)
+            if min(hr, wr) < min(h, w) or hr < h or wr < w:
+                raise ValueError("frames of %dx%d resize to %dx%d, smaller than the %dx%d crop" % (hs, ws, hr, wr, h, w))
+            if (hr, wr) == (hs, ws) and (hs - h) % 2 == 0 and (ws - w) % 2 == 0:
+                lib.rpe_resnet50_forward_u8(plan.handle, ops._p(img), hs, ws, F3(*self.norm_mean), F3(*self.norm_std), ops._p(features),
+                                            features.stride(0), int(training), s)
+            else:
+                rs = self._resize_plan(b, hs, ws, hr, wr, h, w, img.device)
+                lib.rpe_resnet50_forward_u8_resized(plan.handle, ops._p(img), hs, ws, ctypes.byref(rs["plan"]), F3(*self.norm_mean), F3(*self.norm_std),
+                                                    ops._p(features), features.stride(0), int(training), s)
         else:
             lib.rpe_resnet50_forward(plan.handle, ops._p(img), ops._p(features), features.stride(0), int(training), s)
         self._active = plan
         if training:
             self._wver += 1   # running statistics moved now; the masters will with the optimizer step that follows
         return plan
+
+    def _resize_plan(self, b, hs, ws, hr, wr, h, w, device):
+        """device tap tables + intermediate buffer of the Pillow-exact resize for one frame geometry (built once, kept)"""
+        key = (b, hs, ws, hr, wr, h, w, device)
+        rs = self._resize_plans.get(key)
+        if rs is None:
+            top, left = crop_origin(hr, wr, h, w)
+            tabs = {}
+            for name, (i, o) in (("x", (ws, wr)), ("y", (hs, hr))):
+                if i != o:
+                    bounds, kk = pil_bilinear_tables(i, o)
+                    tabs[name] = (torch.from_numpy(bounds).to(device), torch.from_numpy(kk).contiguous().to(device), kk.shape[1])
+            tmp = torch.empty(b * hs * wr * 3, dtype=torch.uint8, device=device) if "x" in tabs else None
+            xb, xk, ksx = tabs.get("x", (None, None, 0))
+            yb, yk, ksy = tabs.get("y", (None, None, 0))
+            ptr = lambda t: None if t is None else t.data_ptr()
+            plan = ResizePlan(hr, wr, top, left, ksx, ksy, ptr(xb), ptr(xk), ptr(yb), ptr(yk), ptr(tmp))
+            rs = {"plan": plan, "keep": (xb, xk, yb, yk, tmp)}
+            self._resize_plans[key] = rs
+        return rs
 
     def forward(self, img):
         """Inference-style call (no autograd): returns the latent features (B, latent)."""

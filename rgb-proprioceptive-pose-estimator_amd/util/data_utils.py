@@ -19,6 +19,50 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
+PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def pil_bilinear_tables(in_size, out_size):
+    """Tap tables of Pillow's antialiased 8-bit bilinear resample along one axis (what `Resize(256)` on a PIL image runs,
+    util/data_utils.py:48-54 of the reference): (bounds [out, 2] int32 = first input index and tap count, weights [out, ksize]
+    int32 in 22-bit fixed point).  Host side, double precision, exactly Pillow's arithmetic (Resample.c precompute_coeffs +
+    normalize_coeffs_8bpc); the device kernels only multiply-accumulate with them (csrc/norm.hip resize_*_kernel)."""
+    import math
+    import numpy as np
+    scale = filterscale = in_size / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    xx = np.arange(out_size, dtype=np.float64)
+    center = (xx + 0.5) * scale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)       # (int) truncation of non-negative values
+    xmin = np.where(center - support + 0.5 < 0, 0, xmin)
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size) - xmin
+    taps = np.arange(ksize, dtype=np.float64)[None, :]
+    t = np.abs((taps + xmin[:, None] - center[:, None] + 0.5) / filterscale)
+    w = np.where((t < 1.0) & (taps < xmax[:, None]), 1.0 - t, 0.0)
+    ww = w.sum(1, keepdims=True)
+    w = np.where(ww != 0.0, w / np.where(ww != 0.0, ww, 1.0), w)
+    kk = np.floor(0.5 + w * (1 << PIL_PRECISION_BITS)).astype(np.int32)   # weights are >= 0 for the triangle filter: (int)(0.5 + v)
+    kk = np.where(taps < xmax[:, None], kk, 0).astype(np.int32)
+    return np.stack([xmin, xmax], 1).astype(np.int32), kk
+
+
+def resized_hw(h, w, size=256):
+    """torchvision.transforms.Resize(int) geometry: the shorter side becomes `size`, the longer int(size * long / short)."""
+    if (w <= h and w == size) or (h <= w and h == size):
+        return h, w
+    if w < h:
+        return int(size * h / w), size
+    return size, int(size * w / h)
+
+
+def crop_origin(h, w, ch, cw):
+    """torchvision.transforms.CenterCrop: int(round((h - ch) / 2.0)), Python rounding (half to even)."""
+    return int(round((h - ch) / 2.0)), int(round((w - cw) / 2.0))
+
+
 def standardize_quat(quat):
     """(x,y,z,w) quaternion with a non-negative w (reference: util/data_utils.py:207-211)."""
     return -quat if quat[-1] < 0 else quat

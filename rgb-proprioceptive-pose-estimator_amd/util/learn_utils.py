@@ -2,8 +2,9 @@
 
 Same signature, phases, criterion dict, statistics and checkpoint naming as train() of the reference
 (util/learn_utils.py:21-255); what changes is underneath:
-  * batches are time-major slices of data already resident in HBM (no DataLoader worker processes, no
-    per-tensor pageable .cuda() copies, util/learn_utils.py:75-76,130-138);
+  * batches are time-major slices of data already resident in HBM when the dataset offers `chunk()`; a dataset with only
+    the reference's `__getitem__` contract is stacked the way its DataLoader would and staged through pinned, double-buffered
+    asynchronous copies (no per-tensor pageable .cuda(), util/learn_utils.py:75-76,130-138);
   * the per-step "val" metric is reduced on the device and only read back once per phase (the reference
     synchronises twice per step: models/losses.py:99-113 and util/learn_utils.py:182);
   * with torch.distributed initialised, episodes are sharded over ranks and the flat gradient buffer is
@@ -30,6 +31,36 @@ def _writer(logging):
         return SummaryWriter()
     except Exception:  # tensorboard is optional here
         return None
+
+
+def _host_chunks(dataset, horizon, seq, use_depth):
+    """What `DataLoader(dataset, batch_size=S, shuffle=False)` yields for a reference-shaped dataset (util/learn_utils.py:75-76,
+    util/data_utils.py:62-73): `dataset[t]` is the 6-tuple of all episodes at timestep t; S consecutive timesteps are stacked
+    time-major (S, N, ...).  Fields the model never reads (the reference fills them with torch.empty garbage) are dropped here
+    instead of being copied to the device."""
+    for t0 in range(0, horizon, seq):
+        items = [dataset[t] for t in range(t0, min(t0 + seq, horizon))]
+        cols = list(zip(*items))
+        stack = lambda c: torch.stack([torch.as_tensor(x) for x in c], 0)
+        img, depth, x0bar, x0, x1, obj = cols
+        yield (stack(img), stack(depth) if use_depth else None, stack(x0bar), stack(x0), stack(x1), stack(obj))
+
+
+def _chunks(dataset, horizon, seq, use_depth):
+    """Time-major device batches of one phase.  Datasets that keep their episodes in HBM offer `chunk(t0, S)` (the synthetic one
+    does); any other dataset with the reference's contract -- `__len__`, `__getitem__(t)` -> 6-tuple of host tensors -- goes
+    through pinned, double-buffered asynchronous staging (FramePrefetcher), replacing the reference's per-tensor synchronous
+    pageable `.cuda()` (util/learn_utils.py:130-138)."""
+    if hasattr(dataset, "chunk"):
+        for t0 in range(0, horizon, seq):
+            yield dataset.chunk(t0, min(seq, horizon - t0))
+        return
+    from .data_utils import FramePrefetcher
+    first = dataset[0][0]
+    if torch.as_tensor(first).is_cuda:   # device-resident tensors behind a plain __getitem__: just stack
+        yield from _host_chunks(dataset, horizon, seq, use_depth)
+        return
+    yield from FramePrefetcher(_host_chunks(dataset, horizon, seq, use_depth), torch.device("cuda", torch.cuda.current_device()))
 
 
 def train_step(model, batch, criterion, optimizer, train_obj_pose, phase="train", grad_sync=None):
@@ -96,8 +127,7 @@ def train(model, dataset, criterion, optimizer, num_epochs, num_train_episodes_p
             model.reset_initial_state(hi - lo)
             sums = torch.zeros(3, dtype=torch.float64, device="cuda")
             horizon = len(dataset)
-            for t0 in range(0, horizon, seq):
-                img, depth, x0bar, x0, x1, obj = dataset.chunk(t0, min(seq, horizon - t0))
+            for img, depth, x0bar, x0, x1, obj in _chunks(dataset, horizon, seq, model.use_depth if hasattr(model, "use_depth") else False):
                 if not model.requires_sequence:  # the reference squeezes the leading batch-of-1 dim (learn_utils.py:141-149)
                     img, x0bar, x0 = img[0], x0bar[0], x0[0]
                     depth = None if depth is None else depth[0]

@@ -251,3 +251,81 @@ def test_plan_cache_is_bounded():
                 assert torch.equal(o, outs[n])   # an evicted and rebuilt plan computes the same thing
             outs[n] = o.clone()
     assert len(model.trunk._plans) <= model.trunk.max_plans
+
+
+class _HostEpisodes:
+    """A dataset with exactly the reference's contract (util/data_utils.py:10-73): host tensors, `__getitem__(t)` returns all
+    episodes at timestep t as a 6-tuple whose unused fields are uninitialised garbage, no `chunk()`."""
+
+    def __init__(self, horizon, use_depth, seed):
+        from rgb_proprioceptive_pose_estimator_amd.util.data_utils import SyntheticEpisodeDataset
+        self._src = SyntheticEpisodeDataset(horizon=horizon, use_depth=use_depth, obj_name="hammer", seed=seed)
+        self.env = self._src.env
+        self.use_depth = use_depth
+        self.data = None
+
+    def refresh_data(self, num_episodes, camera_name=None, noise_scale=0.001):
+        self._src.refresh_data(num_episodes, camera_name, noise_scale)
+        self.data = {k: (None if v is None else v.cpu()) for k, v in self._src.data.items()}
+
+    def __len__(self):
+        return self.data["measurement_self"].size(1)
+
+    def __getitem__(self, index):
+        d = self.data
+        x0 = d["true_self"][:, index]
+        depth = d["depths"][:, index] if self.use_depth else torch.empty(0)
+        return d["imgs"][:, index], depth, d["measurement_self"][:, index], x0, torch.empty_like(x0), d["true_obj"][:, index]
+
+
+@pytest.mark.parametrize("kind", ["no", "tdo"])
+def test_train_accepts_reference_shaped_host_dataset(kind):
+    """train() with a host-resident dataset that only offers the reference's __getitem__ contract (stacked time-major and staged
+    through the pinned double-buffered prefetcher) lands on the same validation loss as the HBM-resident chunk() path."""
+    from rgb_proprioceptive_pose_estimator_amd import models as M
+    from rgb_proprioceptive_pose_estimator_amd.optim import FusedAdam
+    from rgb_proprioceptive_pose_estimator_amd.util.data_utils import SyntheticEpisodeDataset
+    from rgb_proprioceptive_pose_estimator_amd.util.learn_utils import train
+
+    def run(ds):
+        torch.manual_seed(0)
+        if kind == "no":
+            model = M.NaiveObjectStateEstimator("hammer", [32], 50, 32, False, (9,), False, False, False, compute_dtype=torch.float32)
+        else:
+            model = M.TemporallyDependentObjectStateEstimator("hammer", 32, 50, 32, 2, 0.1, False, (9,), True, False, False, compute_dtype=torch.float32)
+        crit = lambda: M.PoseDistanceLoss("combined", 1.0, 0.5, 1e-4, "pose")
+        criterion = {"x0_loss": crit(), "x1_loss": crit(), "obj_loss": crit(), "val_loss": M.PoseDistanceLoss(mode="val")}
+        opt = FusedAdam(model.parameters(), lr=1e-3)
+        _, best = train(model, ds, criterion, opt, num_epochs=1, num_train_episodes_per_epoch=3, num_val_episodes_per_epoch=2,
+                        params={"camera_name": "frontview", "noise_scale": 0.001}, device="cuda:0", save_model=False, logging=False)
+        return best
+
+    use_depth = kind == "tdo"
+    a = run(_HostEpisodes(4, use_depth, 9))
+    b = run(SyntheticEpisodeDataset(horizon=4, use_depth=use_depth, obj_name="hammer", seed=9))
+    assert a < float("inf") and abs(a - b) <= 1e-3 * abs(b)
+
+
+def test_uint8_frames_resized_like_pillow(golden_dir):
+    """Frames whose shorter side is not 256 go through the device-side Pillow-exact bilinear resize + centre crop + normalise:
+    same model output as the reference's host transform (oracle/pil_resize.py, pinned bit for bit to Pillow: resize_pil.npz)."""
+    import numpy as np
+    from oracle.pil_resize import reference_transform
+    from rgb_proprioceptive_pose_estimator_amd import models as M
+
+    gold = np.load(os.path.join(golden_dir, "resize_pil.npz"))
+    torch.manual_seed(3)
+    model = M.NaiveObjectStateEstimator("cube", [32], 50, 32, False, (9,), False, False, False, compute_dtype=torch.float32).cuda().eval()
+    g = torch.Generator().manual_seed(0)
+    for i in range(3):
+        frame = gold["in%d" % i]
+        frames = np.stack([frame, frame[::-1].copy()])              # two frames per geometry
+        x0bar = torch.randn(2, 7, generator=g)
+        img = torch.from_numpy(np.stack([reference_transform(f) for f in frames]))
+        with torch.no_grad():
+            a = model(img.cuda(), None, x0bar.cuda())
+            b = model(torch.from_numpy(frames).cuda(), None, x0bar.cuda())
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), (i, (a - b).abs().max().item())
+        # and the staged image itself (NHWC4 in the trunk's workspace) against the host transform
+        x4 = model.trunk._active.tensor("x4").float().reshape(2, 224, 224, 4)[..., :3].permute(0, 3, 1, 2).cpu()
+        assert torch.allclose(x4, img, rtol=0, atol=2e-6), (i, (x4 - img).abs().max().item())
