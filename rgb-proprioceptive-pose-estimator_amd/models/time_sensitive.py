@@ -30,17 +30,30 @@ class _SequenceModel(PoseModelBase):
         return S, N, img, depth, None if x0bar is None else x0bar.reshape(S * N, 7)
 
     def _state(self, name, n, hid, device):
-        """carried (h, c) in rollout mode, None (zero start) otherwise"""
+        """carried (h, c) in rollout mode, None (zero start) otherwise.  The state tensors are PERSISTENT (updated in place by
+        _keep): a frame captured into a hipGraph (util.learn_utils.GraphedRolloutFrame) reads and writes fixed addresses."""
         if not self.rollout:
             return None, None
         st = self._carried.get(name)
-        if st is None or st[0].shape[0] != n or st[0].device != device:
+        if st is None or st[0].shape != (n, hid) or st[0].device != device:
             st = (torch.zeros((n, hid), dtype=torch.float32, device=device), torch.zeros((n, hid), dtype=torch.float32, device=device))
+            self._carried[name] = st
         return st
 
     def _keep(self, name, hc):
         if self.rollout:
-            self._carried[name] = (hc[0].clone(), hc[1].clone())
+            st = self._carried.get(name)
+            if st is None or st[0].shape != hc[0].shape or st[0].device != hc[0].device:
+                self._carried[name] = (hc[0].clone(), hc[1].clone())
+            else:
+                st[0].copy_(hc[0])
+                st[1].copy_(hc[1])
+
+    def _reset_carried(self):
+        """zero initial state (reset_initial_state of the reference: time_sensitive.py:256-270,519-529,788-800), in place"""
+        for h, c in self._carried.values():
+            h.zero_()
+            c.zero_()
 
     @property
     def requires_sequence(self):
@@ -118,7 +131,7 @@ class TemporallyDependentStateEstimator(_SequenceModel):
 
     def reset_initial_state(self, batch_size):
         """Zero the carried LSTM states (reference: models/time_sensitive.py:256-270)."""
-        self._carried = {}
+        self._reset_carried()
         self.pre_out_vec = []
         self.post_out_vec = []
 
@@ -174,7 +187,7 @@ class TemporallyDependentObjectStateEstimator(_SequenceModel):
 
     def reset_initial_state(self, batch_size):
         """Zero the carried LSTM state (reference: models/time_sensitive.py:519-529)."""
-        self._carried = {}
+        self._reset_carried()
         self.out_vec = []
 
 
@@ -240,5 +253,5 @@ class TemporallyDependentObjectStateEstimatorV2(_SequenceModel):
 
     def reset_initial_state(self, batch_size):
         """Zero the carried LSTM states (reference: models/time_sensitive.py:788-800)."""
-        self._carried = {}
+        self._reset_carried()
         self.out_vec = []

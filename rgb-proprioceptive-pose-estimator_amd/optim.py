@@ -11,10 +11,15 @@ from .params import arena_of
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
+        """capturable: keep the step count (for the bias corrections) on the DEVICE, so that a captured hipGraph of the whole
+        train step (util.learn_utils.GraphedTrainStep) advances it at every replay; a host-side count would be frozen at its
+        capture-time value.  Same update rule either way."""
         if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.capturable = capturable
+        self._dev_state = None
         self._step = 0
         self._m = self._v = None
         self._arena = None
@@ -52,6 +57,19 @@ class FusedAdam(torch.optim.Optimizer):
             for lo, hi in arena.trainable_segments():
                 lib.rpe_adam_step_amp(ops._p(arena.flat[lo:hi]), ops._p(arena.grad[lo:hi]), ops._p(self._m[lo:hi]), ops._p(self._v[lo:hi]), hi - lo,
                                       g["lr"], b1, b2, g["eps"], ops._p(st), s)
+            return None
+        if self.capturable:
+            # device-side step count: the same state block the loss scaler uses (amp.py), with scale 1 and no unscale pass
+            if self._dev_state is None or self._dev_state.device != arena.flat.device:
+                st = torch.zeros(8, dtype=torch.float32)
+                st[0] = st[1] = 1.0
+                st[5] = float(self._step - 1)
+                self._dev_state = st.to(arena.flat.device)
+            s = ops._stream()
+            lib.rpe_amp_update(ops._p(self._dev_state), 1.0, 1.0, 1 << 30, s)   # steps += 1 (found_inf is never set)
+            for lo, hi in arena.trainable_segments():
+                lib.rpe_adam_step_amp(ops._p(arena.flat[lo:hi]), ops._p(arena.grad[lo:hi]), ops._p(self._m[lo:hi]), ops._p(self._v[lo:hi]), hi - lo,
+                                      g["lr"], b1, b2, g["eps"], ops._p(self._dev_state), s)
             return None
         for lo, hi in arena.trainable_segments():
             ops.adam_step(arena.flat[lo:hi], arena.grad[lo:hi], self._m[lo:hi], self._v[lo:hi], g["lr"], b1, b2, g["eps"], self._step)

@@ -88,6 +88,77 @@ def train_step(model, batch, criterion, optimizer, train_obj_pose, phase="train"
     return loss.detach(), pos_err, ori_err
 
 
+class GraphedTrainStep:
+    """One train step (forward -> loss -> on-device val metrics -> backward -> Adam) captured ONCE into a hipGraph and replayed.
+
+    The step is ~330 kernel launches issued from Python + C++ through ctypes; replaying one graph removes the launch gaps on the
+    device and the host work between them (HIP streams and graphs instead of a tracing compiler).  Everything a replay touches
+    lives at a fixed address: the inputs are copied into static tensors, the trunk plan's workspace and the weight-gradient
+    scratch are allocated before the capture, temporaries come from the graph's private pool, and the optimizer's step count is
+    kept on the device (FusedAdam(capturable=True)).  Single-process only: with a process group the step stays eager (RCCL
+    collectives inside a captured graph are not exercised here).
+
+        step = GraphedTrainStep(model, criterion, optimizer, train_obj_pose=True, example_batch=batch)
+        loss, pos_err, ori_err = step(batch)          # device scalars, valid until the next call
+    """
+
+    def __init__(self, model, criterion, optimizer, train_obj_pose, example_batch, warmup=3):
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            raise RuntimeError("GraphedTrainStep is single-process; data-parallel steps run eagerly")
+        if not getattr(optimizer, "capturable", False):
+            raise RuntimeError("GraphedTrainStep needs FusedAdam(..., capturable=True): the step count must live on the device")
+        self.model, self.criterion, self.optimizer, self.train_obj_pose = model, criterion, optimizer, train_obj_pose
+        self.static = tuple(None if t is None else t.clone() for t in example_batch)
+        model.train()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):   # warm-up on a side stream: plans, workspaces and scratch buffers exist before the capture
+            for _ in range(warmup):
+                train_step(model, self.static, criterion, optimizer, train_obj_pose, "train", None)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = train_step(model, self.static, criterion, optimizer, train_obj_pose, "train", None)
+        self.warmup_steps = warmup + 1   # optimizer steps taken while building (the capture itself does not execute)
+
+    def __call__(self, batch):
+        for dst, src in zip(self.static, batch):
+            if dst is not None and dst is not src:   # (fill `self.static` in place to skip the copy)
+                dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+
+class GraphedRolloutFrame:
+    """One eval-mode rollout frame (BN folded into the convs, LSTM state carried in place on the device) as a hipGraph:
+    the per-frame path of rollout() (util/learn_utils.py:322-323,342,446 of the reference) is launch-bound at batch 1."""
+
+    def __init__(self, model, img, depth, x0bar, warmup=2):
+        self.model = model
+        model.eval()
+        self.img, self.x0bar = img.clone(), x0bar.clone()
+        self.depth = None if depth is None else depth.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                model(self.img, self.depth, self.x0bar)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.out = model(self.img, self.depth, self.x0bar)
+
+    def __call__(self, img, depth, x0bar):
+        self.img.copy_(img, non_blocking=True)
+        self.x0bar.copy_(x0bar, non_blocking=True)
+        if self.depth is not None:
+            self.depth.copy_(depth, non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+
 def train(model, dataset, criterion, optimizer, num_epochs, num_train_episodes_per_epoch, num_val_episodes_per_epoch, params, device,
           save_path='default', save_model=True, logging=True, *, save_optimizer=False):
     """See the module docstring.  Returns (model with the best validation weights, best validation loss).

@@ -329,3 +329,65 @@ def test_uint8_frames_resized_like_pillow(golden_dir):
         # and the staged image itself (NHWC4 in the trunk's workspace) against the host transform
         x4 = model.trunk._active.tensor("x4").float().reshape(2, 224, 224, 4)[..., :3].permute(0, 3, 1, 2).cpu()
         assert torch.allclose(x4, img, rtol=0, atol=2e-6), (i, (x4 - img).abs().max().item())
+
+
+@pytest.mark.parametrize("kind", ["no", "tdo_v2"])
+def test_graphed_train_step_matches_eager(kind):
+    """The whole train step captured into one hipGraph and replayed == the same steps issued eagerly (same init, same batches):
+    parameters after 4 steps agree to the noise of the few atomically-accumulated aux-head parameters."""
+    from rgb_proprioceptive_pose_estimator_amd import models as M
+    from rgb_proprioceptive_pose_estimator_amd.optim import FusedAdam
+    from rgb_proprioceptive_pose_estimator_amd.util.data_utils import synthetic_batch
+    from rgb_proprioceptive_pose_estimator_amd.util.learn_utils import GraphedTrainStep, train_step
+
+    def make():
+        torch.manual_seed(4)
+        if kind == "no":
+            return M.NaiveObjectStateEstimator("cube", [32], 50, 32, False, (9,), False, False, False, compute_dtype=torch.bfloat16).cuda().train()
+        return M.TemporallyDependentObjectStateEstimatorV2("robot1_eef", 32, 8, 50, 32, 2, 0.1, False, (9,), False, False, compute_dtype=torch.bfloat16).cuda().train()
+
+    lead = (4,) if kind == "no" else (2, 2)
+    batches = []
+    for i in range(3):
+        b = synthetic_batch(lead, 20 + i)
+        batches.append((b["img"], None, b["x0bar"], b["x0"], None, b["obj"]))
+    crit = M.PoseDistanceLoss("combined", 1.0, 0.5, 1e-4, "pose")
+    criterion = {"obj_loss": crit, "val_loss": M.PoseDistanceLoss(mode="val")}
+    # eager: warm-up steps on batch 0 exactly as the graphed object does, then batches 1, 2, 1
+    order = [0, 0, 0, 1, 2, 1]
+    m1 = make()
+    o1 = FusedAdam(m1.parameters(), lr=1e-3)
+    losses1 = [train_step(m1, batches[i], criterion, o1, True, "train", None)[0].item() for i in order]
+    m2 = make()
+    o2 = FusedAdam(m2.parameters(), lr=1e-3, capturable=True)
+    g = GraphedTrainStep(m2, criterion, o2, True, batches[0], warmup=2)
+    losses2 = [float(g(batches[0])[0].item())] + [float(g(batches[i])[0].item()) for i in (1, 2, 1)]
+    p1 = torch.cat([p.detach().flatten() for p in m1.parameters()])
+    p2 = torch.cat([p.detach().flatten() for p in m2.parameters()])
+    assert torch.isfinite(p2).all()
+    np_l1, np_l2 = losses1[2:], losses2
+    for a, b in zip(np_l1, np_l2):
+        assert abs(a - b) <= 2e-3 * abs(a), (np_l1, np_l2)
+    assert (p1 - p2).abs().max().item() < 2e-3   # Adam moves an element by <= lr per step; sign flips of noise-level gradients differ by 2 lr
+    assert ((p1 - p2).abs() > 1e-5).float().mean().item() < 0.02
+
+
+def test_graphed_rollout_frame_matches_eager():
+    from rgb_proprioceptive_pose_estimator_amd import models as M
+    from rgb_proprioceptive_pose_estimator_amd.util.data_utils import synthetic_batch
+    from rgb_proprioceptive_pose_estimator_amd.util.learn_utils import GraphedRolloutFrame
+
+    torch.manual_seed(5)
+    model = M.TemporallyDependentObjectStateEstimator("hammer", 32, 50, 32, 2, 0.1, False, (9,), True, False, False, compute_dtype=torch.bfloat16).cuda().eval()
+    model.rollout = True
+    b = synthetic_batch((6, 1), 33, with_depth=True)
+    frames = [(b["img"][t:t + 1], b["depth"][t:t + 1], b["x0bar"][t:t + 1]) for t in range(6)]
+    model.reset_initial_state(1)
+    with torch.no_grad():
+        eager = [model(*f).clone() for f in frames]
+    model.reset_initial_state(1)
+    g = GraphedRolloutFrame(model, *frames[0])
+    model.reset_initial_state(1)          # the warm-up frames advanced the carried state: start the episode again (in place)
+    graphed = [g(*f).clone() for f in frames]
+    for a, c in zip(eager, graphed):
+        assert torch.allclose(a, c, rtol=1e-5, atol=1e-6)
