@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying one captured hipGraph per step (N = 1 only)")
+    ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per step instead of issuing every launch (N = 1 only; measured SLOWER than eager issue here: the host already runs ahead of the device and the replay schedules the two-stream backward worse -- DESIGN.md section 6)")
     args = ap.parse_args()
 
     from rgb_proprioceptive_pose_estimator_amd import models as M
@@ -156,7 +156,7 @@ def main():
     model.cuda().train()
     crit = M.PoseDistanceLoss(distance_metric="combined", scale_factor=1.0, alpha=0.5, mode="pose")
     criterion = {"obj_loss": crit, "val_loss": M.PoseDistanceLoss(mode="val")}
-    use_graph = world == 1 and not args.no_graph
+    use_graph = world == 1 and args.graph
     opt = FusedAdam(model.parameters(), lr=1e-3, capturable=use_graph)
     b = synthetic_batch((args.batch,), 1234 + rank, device=dev)
     batch = (b["img"], None, b["x0bar"], b["x0"], None, b["obj"])

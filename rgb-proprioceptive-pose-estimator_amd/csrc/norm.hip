@@ -82,10 +82,19 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
         for (int i = 1; i < 8; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
     }
     if (NS > 1) {
-        // Hand-off without an agent-scope release/acquire FENCE: on this chip such a fence writes back / invalidates the
-        // whole XCD L2 (full of the conv output just written) and cost ~20 us per launch.  Instead the slice sums are stored
-        // and re-read with agent-scope (write-through / L2-bypassing) atomics, the stores are waited for, and only then the
-        // arrival is counted.
+        // Hand-off without an agent-scope release/acquire FENCE: on this chip a release fence writes back the whole XCD L2
+        // (full of the conv output just written) and cost ~20 us per launch.  What is relied on instead (gfx950 behaviour
+        // as measured in MI355X_MICROARCH.md, "Valid forms", table row 1 -- not an architectural guarantee of the HIP
+        // memory model, hence tests/test_gpu_ops.py::test_bn_reduce_handoff_under_load):
+        //   (1) every byte handed off is written by a relaxed agent-scope atomic store = global_store ... sc1 (write-through to
+        //       memory, nothing left dirty in this XCD's L2);
+        //   (2) every storing wave drains its stores (s_waitcnt vmcnt(0)) and then reaches the workgroup barrier, BEFORE
+        //   (3) ONE lane signals with an agent-scope atomic add on the column group's counter; the workgroup whose add returns
+        //       NS-1 is the last arriver, told through LDS behind a barrier;
+        //   (4) the last arriver reads every slice with relaxed agent-scope atomic loads = global_load ... sc1, which bypass
+        //       the CU's L1 (the only cache that could hold a stale copy: it never caches these lines otherwise) and are served
+        //       from L2 / memory, where (1) put the data.
+        // No plain load ever touches dpart.
         if (rl == 0 && c < C) {
             __hip_atomic_store(&dpart[((long)blockIdx.y * 2 + 0) * C + c], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&dpart[((long)blockIdx.y * 2 + 1) * C + c], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -606,3 +606,32 @@ def test_conv_fwd_affine_inference_form(dtype, cfg, residual):
     out = ops.conv2d_fwd_affine(nhwc(x).to(dtype).to(DEV), wq.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV), s, p, shift.to(DEV),
                                 None if add is None else nhwc(add).to(dtype).to(DEV), True)
     assert rel_err(nchw(out), ref) < tol(dtype)
+
+
+def test_bn_reduce_handoff_under_load():
+    """The multi-slice reduce+finalize launch hands partial sums between workgroups with write-through stores, a drained
+    counter add and L1-bypassing loads instead of release/acquire fences (csrc/norm.hip).  Hammer it while another stream
+    streams through HBM: every repetition must reproduce the first one bitwise and match a double-precision reference."""
+    g = torch.Generator().manual_seed(0)
+    tiles, c, rows = 6272, 256, 6272 * 128
+    part = (torch.randn(tiles, 2, c, generator=g) * 3 + 1).to(DEV)
+    part[:, 1] = part[:, 1].abs() * 40 + 130          # sum of squares large enough for a positive variance
+    gamma, beta = torch.rand(c, generator=g).to(DEV) + 0.5, torch.rand(c, generator=g).to(DEV)
+    mean_ref = part[:, 0].double().sum(0) / rows
+    var_ref = part[:, 1].double().sum(0) / rows - mean_ref * mean_ref
+    side = torch.cuda.Stream()
+    big_a, big_b = torch.empty(1 << 28, dtype=torch.uint8, device=DEV), torch.empty(1 << 28, dtype=torch.uint8, device=DEV)
+    first = None
+    for it in range(60):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                big_b.copy_(big_a)                      # ~1.5 GB of concurrent HBM traffic per repetition
+        scale, shift, mean, invstd = ops.bn_finalize(part, rows, gamma, beta)
+        res = torch.stack([scale, shift, mean, invstd])
+        if first is None:
+            first = res.clone()
+            assert rel_err(mean, mean_ref.float()) < 1e-6
+            assert rel_err(invstd, (1.0 / torch.sqrt(var_ref + 1e-5)).float()) < 1e-5
+        else:
+            assert torch.equal(res, first), "repetition %d differs" % it
+    torch.cuda.synchronize()

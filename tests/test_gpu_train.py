@@ -343,8 +343,8 @@ def test_graphed_train_step_matches_eager(kind):
     def make():
         torch.manual_seed(4)
         if kind == "no":
-            return M.NaiveObjectStateEstimator("cube", [32], 50, 32, False, (9,), False, False, False, compute_dtype=torch.bfloat16).cuda().train()
-        return M.TemporallyDependentObjectStateEstimatorV2("robot1_eef", 32, 8, 50, 32, 2, 0.1, False, (9,), False, False, compute_dtype=torch.bfloat16).cuda().train()
+            return M.NaiveObjectStateEstimator("cube", [32], 50, 32, False, (9,), False, False, False, compute_dtype=torch.float32).cuda().train()
+        return M.TemporallyDependentObjectStateEstimatorV2("robot1_eef", 32, 8, 50, 32, 2, 0.1, False, (9,), False, False, compute_dtype=torch.float32).cuda().train()
 
     lead = (4,) if kind == "no" else (2, 2)
     batches = []

@@ -33,7 +33,19 @@ def bench(name, make, dtype):
             model(img, None, x0)
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / N
-    print("%-8s %-9s %.3f ms per rollout step (%.0f frames/s)" % (name, str(dtype).replace("torch.", ""), dt * 1e3, 1.0 / dt))
+    # the same frame as ONE captured hipGraph (util.learn_utils.GraphedRolloutFrame)
+    from rgb_proprioceptive_pose_estimator_amd.util.learn_utils import GraphedRolloutFrame
+    g = GraphedRolloutFrame(model, img, None, x0)
+    for _ in range(10):
+        g(img, None, x0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(N):
+        g(img, None, x0)
+    torch.cuda.synchronize()
+    dg = (time.perf_counter() - t0) / N
+    print("%-8s %-9s eager %.3f ms per rollout step (%.0f frames/s) | hipGraph replay %.3f ms (%.0f frames/s)" % (
+        name, str(dtype).replace("torch.", ""), dt * 1e3, 1.0 / dt, dg * 1e3, 1.0 / dg))
 
 
 MODELS = {
