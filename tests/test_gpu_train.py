@@ -348,30 +348,33 @@ def test_graphed_train_step_matches_eager(kind):
 
     lead = (4,) if kind == "no" else (2, 2)
     batches = []
-    for i in range(3):
+    for i in range(2):
         b = synthetic_batch(lead, 20 + i)
         batches.append((b["img"], None, b["x0bar"], b["x0"], None, b["obj"]))
     crit = M.PoseDistanceLoss("combined", 1.0, 0.5, 1e-4, "pose")
     criterion = {"obj_loss": crit, "val_loss": M.PoseDistanceLoss(mode="val")}
-    # eager: warm-up steps on batch 0 exactly as the graphed object does, then batches 1, 2, 1
-    order = [0, 0, 0, 1, 2, 1]
-    m1 = make()
-    o1 = FusedAdam(m1.parameters(), lr=1e-3)
-    losses1 = [train_step(m1, batches[i], criterion, o1, True, "train", None)[0].item() for i in order]
-    m2 = make()
-    o2 = FusedAdam(m2.parameters(), lr=1e-3, capturable=True)
-    g = GraphedTrainStep(m2, criterion, o2, True, batches[0], warmup=2)
-    losses2 = [float(g(batches[0])[0].item())] + [float(g(batches[i])[0].item()) for i in (1, 2, 1)]
-    p1 = torch.cat([p.detach().flatten() for p in m1.parameters()])
-    p2 = torch.cat([p.detach().flatten() for p in m2.parameters()])
-    assert torch.isfinite(p2).all()
-    np_l1, np_l2 = losses1[2:], losses2
-    for a, b in zip(np_l1, np_l2):
-        assert abs(a - b) <= 1e-2 * abs(a), (np_l1, np_l2)
-    # Adam moves an element by <= lr per step: an element whose noise-level gradient flips sign (the aux head's atomically
-    # accumulated gradients differ in the last bits from run to run) ends up to 2 lr per step apart
-    assert (p1 - p2).abs().max().item() < 2 * 1e-3 * 4 + 1e-6
-    assert ((p1 - p2).abs() > 1e-4).float().mean().item() < 0.02
+    m = make()
+    opt = FusedAdam(m.parameters(), lr=1e-3, capturable=True)
+    g = GraphedTrainStep(m, criterion, opt, True, batches[0], warmup=2)
+    torch.cuda.synchronize()
+    # This network is chaotic at these sizes (a 1e-7 perturbation moves the next gradient by up to 1e-2), so the two forms are
+    # compared over ONE step from an identical state: snapshot, eager step, restore, graph replay of the same step.
+    bufs = [b_ for b_ in m.buffers()]
+    snap = (m._arena.flat.clone(), opt._m.clone(), opt._v.clone(), opt._dev_state.clone(), [b_.clone() for b_ in bufs])
+    loss_e = train_step(m, batches[1], criterion, opt, True, "train", None)[0].item()
+    p_e = m._arena.flat.clone()
+    steps_e = opt._dev_state[5].item()
+    m._arena.flat.copy_(snap[0]); opt._m.copy_(snap[1]); opt._v.copy_(snap[2]); opt._dev_state.copy_(snap[3])
+    for b_, s_ in zip(bufs, snap[4]):
+        b_.copy_(s_)
+    loss_g = g(batches[1])[0].item()
+    p_g = m._arena.flat.clone()
+    assert opt._dev_state[5].item() == steps_e == 4.0     # 3 steps while building + this one, counted on the device
+    assert abs(loss_e - loss_g) <= 1e-6 * abs(loss_e)
+    assert torch.isfinite(p_g).all() and (p_g - snap[0]).abs().max().item() > 1e-4      # the replay did train
+    # identical kernels on identical inputs: only the aux head's atomically accumulated gradients (66 parameters) may differ
+    assert ((p_e - p_g).abs() > 1e-7).float().mean().item() < 1e-3
+    assert (p_e - p_g).abs().max().item() <= 2.1e-3
 
 
 def test_graphed_rollout_frame_matches_eager():
