@@ -104,11 +104,16 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // epilogue variant only (role 1; 0 elsewhere).
 // (second launch-bound = minimum waves per SIMD: with the mode a constant hipcc hoisted the epilogue loads of mode 2 into 252
 // VGPRs -- one workgroup per CU, 25 % slower)
-template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE, int BNM = 0>
-__global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p) {
+// WAVES_N: waves along N (2: 64 x BN/2 per wave; 4: 64 x BN/4 -- twice the waves on the same tile and LDS footprint, for the
+// HBM-bound short-K launches whose workgroups spend most of their life in the load latency and the epilogue: more waves per CU
+// in flight, half the epilogue per wave).
+template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE, int BNM = 0, int WAVES_N = 2>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 4 : 2) void nt_kernel(const NTArgs<T> p) {
     constexpr int CE = Elem<T>::kChunk, BK = KCH * CE;
-    constexpr int NW = 2 * WAVES_M, NTHR = 64 * NW;
-    constexpr int BM = 64 * WAVES_M, WM = 64, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+    constexpr int NW = WAVES_N * WAVES_M, NTHR = 64 * NW;
+    constexpr int BM = 64 * WAVES_M, WM = 64, WN = BN / WAVES_N, FM = WM / 16, FN = WN / 16;
+    static_assert(WAVES_N == 2 || WAVES_N == 4, "2 or 4 waves along N");
+    static_assert(WN % 16 == 0 && WN >= 16, "a wave needs at least one 16-column fragment");
     constexpr int RPI = 64 / KCH;                       // rows covered by one 64-lane x 16-B DMA instruction
     constexpr int AR = BM / RPI / NW, BR = BN / RPI / NW;  // DMA instructions (= 16-B chunks per thread) per K-step
     static_assert((BM / RPI) % NW == 0 && (BN / RPI) % NW == 0, "tile rows must split evenly over the waves");
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
     __shared__ u32x4 lds[(NSTAGE * STAGE > EPI16) ? NSTAGE * STAGE : EPI16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
     const int lb = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     const int tile_n = lb % p.tiles_n, tile_m = lb / p.tiles_n;
     const int n0 = tile_n * BN;
@@ -947,35 +952,40 @@ __global__ __launch_bounds__(512) void tn_reduce_kernel(const float* __restrict_
 // parallel -- one unit with every configuration took 5 minutes)
 // -----------------------------------------------------------------------------------------------
 
-template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE> static int launch_nt_role(NTArgs<T>& a, hipStream_t s, long nwg) {
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "nt_kernel<%s,%d,%d,%d,%d,%d,%d,%d>", Elem<T>::kName, WAVES_M, BN, KCH, MODE, NST, ROLE,
-             ROLE == 1 ? a.bn_mode : 0);
-    const dim3 grid((unsigned)nwg), block(128 * WAVES_M);
+template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE, int WAVES_N = 2> static int launch_nt_role(NTArgs<T>& a, hipStream_t s, long nwg) {
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "nt_kernel<%s,%d,%d,%d,%d,%d,%d,%d%s>", Elem<T>::kName, WAVES_M, BN, KCH, MODE, NST, ROLE,
+             ROLE == 1 ? a.bn_mode : 0, WAVES_N == 4 ? ",w4" : "");
+    const dim3 grid((unsigned)nwg), block(64 * WAVES_M * WAVES_N);
     if (ROLE == 1) {
         switch (a.bn_mode) {
-            case 1: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 1 : 0>), grid, block, 0, s, a); break;
-            case 2: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 2 : 0>), grid, block, 0, s, a); break;
-            case 3: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 3 : 0>), grid, block, 0, s, a); break;
-            case 4: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 4 : 0>), grid, block, 0, s, a); break;
-            default: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, 0>), grid, block, 0, s, a); break;
+            case 1: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 1 : 0, WAVES_N>), grid, block, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 2 : 0, WAVES_N>), grid, block, 0, s, a); break;
+            case 3: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 3 : 0, WAVES_N>), grid, block, 0, s, a); break;
+            case 4: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 4 : 0, WAVES_N>), grid, block, 0, s, a); break;
+            default: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, 0, WAVES_N>), grid, block, 0, s, a); break;
         }
     } else {
-        hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, 0>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, 0, WAVES_N>), grid, block, 0, s, a);
     }
     RPE_CHECK_LAUNCH();
     return 0;
 }
 
-template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST = 3> static int launch_nt_cfg(NTArgs<T>& a, hipStream_t s) {
+template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST = 3, int WAVES_N = 2> static int launch_nt_cfg(NTArgs<T>& a, hipStream_t s) {
     constexpr int BM = 64 * WAVES_M;
     a.tiles_m = (MODE == MODE_CONV && a.g.parity) ? 4 * ceil_div(a.g.rows_q, BM) : ceil_div(a.M, BM);
     a.tiles_n = ceil_div(a.N, BN);
     const long nwg = (long)a.tiles_m * a.tiles_n;
     if (nwg <= 0 || nwg > 0x7fffffffL) return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: bad grid");
+    if constexpr (WAVES_N == 4) {   // (the 8-wave form is instantiated for the two training roles only)
+        if (a.role == 1) return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 1, 4>(a, s, nwg);
+        return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 0, 4>(a, s, nwg);
+    } else {
     if (a.role == 1) return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 1>(a, s, nwg);
     if (a.role == 2) return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 2>(a, s, nwg);
     if (a.role == 3) return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 3>(a, s, nwg);
     return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 0>(a, s, nwg);
+    }
 }
 
 // configuration choice for one staging mode (argument checks are in launch_nt, igemm.hip)
@@ -1005,6 +1015,11 @@ template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s) 
             // alone at the fp32 MFMA rate -- 277 us for 256x1024x3655): 64x64 tiles / 2 waves put 4..8x as many workgroups
             // on the chip
             if (!a.stats_part && (long)ceil_div(a.M, 128) * ceil_div(a.N, wide ? 128 : 64) < 96) return launch_nt_cfg<T, 1, 64, 4, MODE_DENSE>(a, s);
+        }
+        if constexpr (MODE == MODE_DENSE) {
+            // 8 waves on the 128x128 tile for the short-K 1x1 layers of the two training roles (RPE_NT_W8=0 turns it off)
+            static const int w8 = getenv("RPE_NT_W8") ? atoi(getenv("RPE_NT_W8")) : 1;
+            if (w8 && a.role <= 1 && a.M >= 4096 && wide) return launch_nt_cfg<T, 2, 128, 4, MODE, 3, 4>(a, s);
         }
         return wide ? launch_nt_cfg<T, 2, 128, 4, MODE>(a, s) : launch_nt_cfg<T, 2, 64, 4, MODE>(a, s);
     }
