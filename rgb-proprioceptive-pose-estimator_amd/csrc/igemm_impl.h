@@ -1017,8 +1017,10 @@ template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s) 
             if (!a.stats_part && (long)ceil_div(a.M, 128) * ceil_div(a.N, wide ? 128 : 64) < 96) return launch_nt_cfg<T, 1, 64, 4, MODE_DENSE>(a, s);
         }
         if constexpr (MODE == MODE_DENSE) {
-            // 8 waves on the 128x128 tile for the short-K 1x1 layers of the two training roles (RPE_NT_W8=0 turns it off)
-            static const int w8 = getenv("RPE_NT_W8") ? atoi(getenv("RPE_NT_W8")) : 1;
+            // 8 waves on the 128x128 tile for the short-K 1x1 layers of the two training roles: an experiment switch (RPE_NT_W8=1).
+            // Measured at 256 images: forward launches +3 %, the fused-epilogue data gradients -7 % (128 VGPRs with spills at
+            // 4 waves per SIMD), the train step 22.6 vs 22.0 ms -- occupancy is not what bounds these launches.
+            static const int w8 = getenv("RPE_NT_W8") ? atoi(getenv("RPE_NT_W8")) : 0;
             if (w8 && a.role <= 1 && a.M >= 4096 && wide) return launch_nt_cfg<T, 2, 128, 4, MODE, 3, 4>(a, s);
         }
         return wide ? launch_nt_cfg<T, 2, 128, 4, MODE>(a, s) : launch_nt_cfg<T, 2, 64, 4, MODE>(a, s);

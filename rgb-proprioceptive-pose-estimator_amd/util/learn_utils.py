@@ -120,7 +120,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = train_step(model, self.static, criterion, optimizer, train_obj_pose, "train", None)
-        self.warmup_steps = warmup + 1   # optimizer steps taken while building (the capture itself does not execute)
+        self.warmup_steps = warmup   # optimizer steps taken while building (the capture itself does not execute anything)
 
     def __call__(self, batch):
         for dst, src in zip(self.static, batch):

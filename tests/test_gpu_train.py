@@ -369,7 +369,7 @@ def test_graphed_train_step_matches_eager(kind):
         b_.copy_(s_)
     loss_g = g(batches[1])[0].item()
     p_g = m._arena.flat.clone()
-    assert opt._dev_state[5].item() == steps_e == 4.0     # 3 steps while building + this one, counted on the device
+    assert opt._dev_state[5].item() == steps_e == 3.0     # 2 warm-up steps while building (the capture executes nothing) + this one, counted on the device
     assert abs(loss_e - loss_g) <= 1e-6 * abs(loss_e)
     assert torch.isfinite(p_g).all() and (p_g - snap[0]).abs().max().item() > 1e-4      # the replay did train
     # identical kernels on identical inputs: only the aux head's atomically accumulated gradients (66 parameters) may differ
