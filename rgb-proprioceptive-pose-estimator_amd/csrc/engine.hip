@@ -82,6 +82,7 @@ struct rpe_resnet50 {
     float* bwd_part = nullptr;
     long bwd_part_floats = 0;
     float* c1c2 = nullptr;
+    float* bwd_part2 = nullptr;
     double* dpart = nullptr;     // staged BN partial-sum reduction scratch
     double* dpart2 = nullptr;    // ... of the projection-shortcut branch
     // aux-head gradient in compact form for the fused stem backward (rpe_resnet50_set_aux_grad)
@@ -262,6 +263,7 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
     e->bwd_part_floats = 1024L * 2 * 2048;
     want(e, (void**)&e->bwd_part, e->bwd_part_floats * 4);
     want(e, (void**)&e->c1c2, 2 * 2048 * 4L);
+    want(e, (void**)&e->bwd_part2, e->bwd_part_floats * 4);   // the projection-shortcut backward runs on the side stream
     want(e, (void**)&e->dpart, RPE_BN_DPART_DOUBLES(2048) * 8);
     want(e, (void**)&e->dpart2, RPE_BN_DPART_DOUBLES(2048) * 8);
     want(e, (void**)&e->stem_dw, 64L * 256 * 4);
@@ -789,6 +791,36 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
         const void* x_in = bi == 0 ? (const void*)e->pool : (const void*)e->convs[e->blocks[bi - 1].c3].a;
         void* gA = b.dz;                                             // dz3 (for the last block: the raw dA)
         void* gD = bi == 0 ? e->d_pool : e->blocks[bi - 1].dz;       // where the gradient of the block input goes
+        // Projection shortcut (conv + BN, no ReLU) of a stage-entry block: its whole backward -- BN reduce / finalize / apply, weight
+        // gradient, data gradient into G[0] -- needs only gA, so it runs on the side stream beside the conv3 -> conv2 -> conv1
+        // chain and is joined in front of the block's last data gradient, which adds G[0].  (Own partial-sum / counter buffers;
+        // the side stream runs it in order with the weight gradients, which share its slab.)
+        static const bool cd_side_ok = getenv("RPE_NO_CD_SIDE") == nullptr;
+        const bool cd_on_side = b.cd >= 0 && cd_side_ok && e->overlap && e->side && bi != (int)e->blocks.size() - 1;
+        hipEvent_t cd_done = nullptr;
+        if (cd_on_side) {
+            ConvL& cd = e->convs[b.cd];
+            hipEvent_t ga_ready = sync_event(e);
+            cd_done = sync_event(e);
+            if (!ga_ready || !cd_done) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
+            HIPTRY(hipEventRecord(ga_ready, (hipStream_t)stream));
+            HIPTRY(hipStreamWaitEvent(e->side, ga_ready, 0));
+            e->pending_bytes = conv_out_bytes(e, cd) * 5.0;
+            PROF(e, RPE_PROF_BN_BWD, e->side, rpe_bn_backward(e->dtype, gA, nullptr, cd.y, cd.mean, cd.invstd, e->params[cd.p_g], e->grads[cd.p_g], e->grads[cd.p_b],
+                                                               cd.dy, nullptr, cd.rows, cd.d.out_c, e->bwd_part2, e->bwd_part_floats, cd.c1c2, e->dpart2, e->side));
+            float* dw = e->grads[cd.p_w];
+            e->pending_flops = conv_flops(cd);
+            e->pending_bytes = conv_in_bytes(e, cd) + conv_out_bytes(e, cd);
+            if (e->wg_slab) {
+                PROF(e, RPE_PROF_CONV_WGRAD, e->side, rpe_conv2d_wgrad_det(&cd.d, e->dtype, x_in, cd.dy, dw, e->wg_slab, e->wg_slab_bytes, e->side));
+            } else {
+                if (!e->gspan_lo) HIPTRY(hipMemsetAsync(dw, 0, (size_t)e->pnumel[cd.p_w] * 4, e->side));
+                PROF(e, RPE_PROF_CONV_WGRAD, e->side, rpe_conv2d_wgrad(&cd.d, e->dtype, x_in, cd.dy, dw, e->side));
+            }
+            e->pending_flops = conv_flops(cd);
+            e->pending_bytes = conv_in_bytes(e, cd) + conv_out_bytes(e, cd);
+            PROF(e, RPE_PROF_CONV_DGRAD, e->side, rpe_conv2d_dgrad(&cd.d, e->dtype, cd.dy, cd.wd, e->G[0], nullptr, e->side));
+        }
         if (e->fold && c3.d.in_c <= 256 && e->train_mode) {   // layers 1-3 (layer4's tensors are small: the unfolded form is faster there)
             TRY(conv1x1_backward_folded(e, c3, gA, c2, stream));                                  // dz2 (dy3 exists on the side stream only)
         } else {
@@ -805,10 +837,15 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
         const void* shortcut = gA;
         if (b.cd >= 0) {
             ConvL& cd = e->convs[b.cd];
-            TRY(bn_back(e, cd, gA, 0, cd.dy, nullptr, stream));          // no ReLU on the projection shortcut
-            TRY(wgrad(e, cd, x_in, cd.dy, stream));
-            PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&cd.d, e->dtype, cd.dy, cd.wd, e->G[0], nullptr, stream));
             shortcut = e->G[0];
+            if (cd_on_side) {
+                HIPTRY(hipEventRecord(cd_done, e->side));
+                HIPTRY(hipStreamWaitEvent((hipStream_t)stream, cd_done, 0));   // the shortcut gradient is what the block's last data gradient adds
+            } else {
+                TRY(bn_back(e, cd, gA, 0, cd.dy, nullptr, stream));          // no ReLU on the projection shortcut
+                TRY(wgrad(e, cd, x_in, cd.dy, stream));
+                PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&cd.d, e->dtype, cd.dy, cd.wd, e->G[0], nullptr, stream));
+            }
         }
         if (bi > 0) {
             static const bool use_mask = getenv("RPE_NO_RELU_MASK") == nullptr;
