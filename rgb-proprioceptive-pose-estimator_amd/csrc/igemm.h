@@ -55,6 +55,7 @@ template <typename T> struct NTArgs {
     const T* bn_a;       // BN(+residual)+ReLU output, [M][ldc] (mode 1)
     const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
     int tiles_m, tiles_n;
+    int nt_store;        // epilogue output stores non-temporal (streamed once, re-read only after >= its own size of other traffic)
     int role;            // 0 conv forward (training), 1 conv data gradient, 2 Linear, 3 conv forward (inference: bias/addend/ReLU):
                          // selects the epilogue variant compiled into the kernel and tags its symbol in profiles
     long a_elems;        // elements of the tensor behind A (conv modes; 0 = dense, derived from M and lda)

@@ -539,7 +539,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 4 : 2) void 
                 }
                 T* cp = p.C + m * p.ldc + n;
                 if (VEC_ONLY || vec_c) {
-                    if (CE == 8) { *(u32x4*)cp = f_to_chunk<T>(v); }
+                    if (VEC_ONLY && p.nt_store) {
+                        __builtin_nontemporal_store(f_to_chunk<T>(v), (u32x4*)cp);
+                        if (CE == 4) __builtin_nontemporal_store(f_to_chunk<T>(v + 4), (u32x4*)(cp + 4));
+                    } else if (CE == 8) { *(u32x4*)cp = f_to_chunk<T>(v); }
                     else { *(u32x4*)cp = f_to_chunk<T>(v); *(u32x4*)(cp + 4) = f_to_chunk<T>(v + 4); }
                 } else {
 #pragma unroll

@@ -19,6 +19,10 @@ VARIANTS = [
     {"RPE_TN_REG": "1"},      # register staging instead of the LDS-DMA ring in the weight-gradient kernel
     {"RPE_NO_PARITY": "1"},   # stride-2 data gradient without the parity-class decomposition
     {"RPE_TN_WGS": "64"},     # few, long split-M slices in the weight gradient
+    {"RPE_TN_RING": "1,4"},   # 4-slot ring of 32-row steps in the weight-gradient kernel
+    {"RPE_TN_RING": "2,3"},   # 3-slot ring of 64-row steps for every shape
+    {"RPE_NT_W8": "1"},       # 8 waves on the 128x128 tile of the short-K dense launches
+    {"RPE_NT_NTSTORE": "1"},  # non-temporal epilogue stores
 ]
 
 
@@ -38,6 +42,11 @@ ENGINE_VARIANTS = [
     {"RPE_NO_OVERLAP": "1"},        # everything on one stream
     {"RPE_NO_FWD_OVERLAP": "1"},    # projection-shortcut branch on the main stream
     {"RPE_STEM_UNFUSED": "1"},      # dense early-feature gradient + separate pool / BN backward passes for the stem
+    {"RPE_NO_SPLIT": "1"},          # forward as ONE pipeline over the whole batch instead of two concurrent half-batch pipelines
+    {"RPE_NO_BN_FOLD": "1"},        # conv3 backward through a materialised dy (streaming dz, y -> dy pass on the main stream)
+    {"RPE_NO_WGRAD_FOLD": "1"},     # conv3 weight gradient from dy (dz, y -> dy on the side stream) instead of the folded form
+    {"RPE_WGRAD_ATOMIC": "1"},      # fp32 atomics instead of slab + fixed-order sums in the weight gradients
+    {"RPE_CD_SIDE": "1"},           # projection-shortcut backward on the side stream
 ]
 
 
