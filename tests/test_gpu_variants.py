@@ -42,7 +42,7 @@ ENGINE_VARIANTS = [
     {"RPE_NO_OVERLAP": "1"},        # everything on one stream
     {"RPE_NO_FWD_OVERLAP": "1"},    # projection-shortcut branch on the main stream
     {"RPE_STEM_UNFUSED": "1"},      # dense early-feature gradient + separate pool / BN backward passes for the stem
-    {"RPE_NO_SPLIT": "1"},          # forward as ONE pipeline over the whole batch instead of two concurrent half-batch pipelines
+    {"RPE_FWD_SPLIT": "1"},         # forward as two concurrent half-batch pipelines joined at the BN statistics
     {"RPE_NO_BN_FOLD": "1"},        # conv3 backward through a materialised dy (streaming dz, y -> dy pass on the main stream)
     {"RPE_NO_WGRAD_FOLD": "1"},     # conv3 weight gradient from dy (dz, y -> dy on the side stream) instead of the folded form
     {"RPE_WGRAD_ATOMIC": "1"},      # fp32 atomics instead of slab + fixed-order sums in the weight gradients
