@@ -10,27 +10,28 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SUBSET = "conv_fwd_and_stats or conv_dgrad or conv_wgrad or dgrad_with_fused_bn_backward or linear_fwd_layout or linear_wgrad"
+NT = "conv_fwd_and_stats or conv_dgrad or dgrad_with_fused_bn_backward or linear_fwd_layout"
+TN = "conv_wgrad or linear_wgrad"
 
-VARIANTS = [
-    {"RPE_NT_BIG": "1"},      # 256-row / 8-wave NT tiles for M >= 4096, K >= 1024
-    {"RPE_NT_BK64": "1"},     # 128-byte K rows + 2-slot ring for every K
-    {"RPE_NT_NOBK64": "1"},   # ... and for none
-    {"RPE_TN_REG": "1"},      # register staging instead of the LDS-DMA ring in the weight-gradient kernel
-    {"RPE_NO_PARITY": "1"},   # stride-2 data gradient without the parity-class decomposition
-    {"RPE_TN_WGS": "64"},     # few, long split-M slices in the weight gradient
-    {"RPE_TN_RING": "1,4"},   # 4-slot ring of 32-row steps in the weight-gradient kernel
-    {"RPE_TN_RING": "2,3"},   # 3-slot ring of 64-row steps for every shape
-    {"RPE_NT_W8": "1"},       # 8 waves on the 128x128 tile of the short-K dense launches
-    {"RPE_NT_NTSTORE": "1"},  # non-temporal epilogue stores
+VARIANTS = [   # (switch, the parity cases of test_gpu_ops.py it can affect)
+    ({"RPE_NT_BIG": "1"}, NT),        # 256-row / 8-wave NT tiles for M >= 4096, K >= 1024
+    ({"RPE_NT_BK64": "1"}, NT),       # 128-byte K rows + 2-slot ring for every K
+    ({"RPE_NT_NOBK64": "1"}, NT),     # ... and for none
+    ({"RPE_NT_W8": "1"}, NT),         # 8 waves on the 128x128 tile of the short-K dense launches
+    ({"RPE_NT_NTSTORE": "1"}, NT),    # non-temporal epilogue stores
+    ({"RPE_NO_PARITY": "1"}, "conv_dgrad or dgrad_with_fused_bn_backward"),   # stride-2 data gradient without the parity-class decomposition
+    ({"RPE_TN_REG": "1"}, TN),        # register staging instead of the LDS-DMA ring in the weight-gradient kernel
+    ({"RPE_TN_WGS": "64"}, TN),       # few, long split-M slices in the weight gradient
+    ({"RPE_TN_RING": "1,4"}, TN),     # 4-slot ring of 32-row steps in the weight-gradient kernel
+    ({"RPE_TN_RING": "2,3"}, TN),     # 3-slot ring of 64-row steps for every shape
 ]
 
 
-@pytest.mark.parametrize("env", VARIANTS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
-def test_kernel_variant_parity(env):
+@pytest.mark.parametrize("env,subset", VARIANTS, ids=[",".join("%s=%s" % kv for kv in e.items()) for e, _ in VARIANTS])
+def test_kernel_variant_parity(env, subset):
     child_env = dict(os.environ)
     child_env.update(env)
-    cmd = [sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_ops.py"), "-q", "-x", "-p", "no:cacheprovider", "-k", SUBSET]
+    cmd = [sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_ops.py"), "-q", "-x", "-p", "no:cacheprovider", "-k", subset]
     r = subprocess.run(cmd, env=child_env, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=900)
     tail = (r.stdout or "")[-3000:] + (r.stderr or "")[-1000:]
     assert r.returncode == 0, "variant %r failed:\n%s" % (env, tail)
@@ -55,7 +56,7 @@ def test_engine_variant_parity(env):
     child_env = dict(os.environ)
     child_env.update(env)
     cmd = [sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_models.py"), "-q", "-x", "-p", "no:cacheprovider", "-k",
-           "test_model_fp32_matches_reference_and_oracle and (no or tdo_v2)"]
+           "test_model_fp32_matches_reference_and_oracle and tdo_v2"]
     r = subprocess.run(cmd, env=child_env, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=900)
     tail = (r.stdout or "")[-3000:] + (r.stderr or "")[-1000:]
     assert r.returncode == 0, "variant %r failed:\n%s" % (env, tail)
