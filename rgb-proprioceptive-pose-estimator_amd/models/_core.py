@@ -84,8 +84,13 @@ class _ModelFn(torch.autograd.Function):
         if scaler is not None:   # fp16 compute: the whole backward signal carries the loss scale (amp.py)
             sc = scaler.scale_tensor(next(d for d in d_outs if d is not None).device)
             d_outs = [None if d is None else d * sc for d in d_outs]
+        arena = model._arena
+        carry = arena.grad.clone() if arena.accumulating() else None   # a second backward() without zero_grad(): torch adds
         model._backward_impl(list(d_outs))
-        model._arena.publish_grads()
+        if carry is not None:
+            arena.grad.add_(carry)
+        arena._dirty = True
+        arena.publish_grads()
         return None, None, None, None, None
 
 

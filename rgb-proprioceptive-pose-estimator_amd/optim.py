@@ -38,8 +38,14 @@ class FusedAdam(torch.optim.Optimizer):
         return arena
 
     def zero_grad(self, set_to_none=True):
-        """The HIP backward overwrites every gradient view, so there is nothing to clear; kept for API parity
-        with the reference loop (util/learn_utils.py:152)."""
+        """The HIP backward overwrites every gradient view, so there is nothing to clear on the device; this only tells the arena
+        that the next backward starts fresh instead of accumulating (reference loop: util/learn_utils.py:152)."""
+        arena = self._arena
+        if arena is None:
+            params = [p for g in self.param_groups for p in g["params"]]
+            arena = arena_of(params)
+        if arena is not None:
+            arena.zero_grad()
         return None
 
     @torch.no_grad()

@@ -32,6 +32,7 @@ class ParamArena:
             self.offsets.append(total)
             total += _pad4(p.numel())  # 16-byte aligned segments
         self.numel = total
+        self._dirty = False       # a backward has written `grad` and nothing has zeroed it since (see accumulating())
         self.loss_scaler = None   # set by fp16 models: gradients in `grad` carry its scale until the optimizer unscales them
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -47,6 +48,19 @@ class ParamArena:
         """False once something (e.g. module.to()) re-allocated a parameter outside the arena."""
         base, end = self.flat.data_ptr(), self.flat.data_ptr() + self.numel * 4
         return all(base <= p.data_ptr() < end for p in self.params)
+
+    def accumulating(self):
+        """True when the next backward must ADD to the gradients instead of replacing them: torch semantics are that .grad
+        accumulates across backward() calls until the optimizer's zero_grad().  The kernels overwrite their gradient views, so
+        the model's backward carries the old values over only in this case; the reference loop zeroes every iteration
+        (util/learn_utils.py:152) and never pays for it.  `zero_grad(set_to_none=True)` of a torch optimizer is recognised by
+        the .grad attributes it cleared."""
+        if not self._dirty:
+            return False
+        return all(p.grad is not None for p in self.params if p.requires_grad)
+
+    def zero_grad(self):
+        self._dirty = False
 
     def publish_grads(self):
         """Expose the gradient views as .grad (what torch optimizers and checkpoints read)."""
