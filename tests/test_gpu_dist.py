@@ -36,6 +36,7 @@ def _worker(rank, world, port, q):
     b = synthetic_batch((2,), 100 + rank)
 
     def backward():
+        model._arena.zero_grad()            # a fresh gradient per call (torch semantics would otherwise accumulate)
         crit(model(b["img"], None, b["x0bar"]), b["obj"]).backward()
         return model._arena.grad.clone()
 

@@ -161,6 +161,7 @@ def test_gradients_repeat_across_passes():
     b = synthetic_batch((64,), 1234)
     grads = []
     for _ in range(4):
+        model._arena.zero_grad() if model._arena is not None else None   # fresh gradients per pass (no accumulation)
         crit(model(b["img"], None, b["x0bar"]), b["obj"]).backward()
         torch.cuda.synchronize()
         grads.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})

@@ -44,6 +44,8 @@ def grad_twice():
     b = synthetic_batch((64,), 1234)
     gs = []
     for _ in range(3):
+        if model._arena is not None:
+            model._arena.zero_grad()
         crit(model(b["img"], None, b["x0bar"]), b["obj"]).backward()
         torch.cuda.synchronize()
         gs.append(model._arena.grad.detach().clone())
