@@ -293,6 +293,9 @@ typedef struct rpe_resnet50 rpe_resnet50_t;
 #define RPE_RESNET50_NUM_BUFFERS 106
 
 int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, int width, int dtype, int latent_dim);
+/* the same engine for the deeper bottleneck ResNets the reference's import_resnet offers (util/model_utils.py:130-136):
+ * depth 50 ([3,4,6,3] blocks), 101 ([3,4,23,3]) or 152 ([3,8,36,3]); the BasicBlock networks (18, 34) have no plan */
+int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int height, int width, int dtype, int latent_dim);
 void rpe_resnet50_destroy(rpe_resnet50_t* e);
 /* bytes of device workspace the engine needs (activations, gradients, packed weights, scratch) */
 long rpe_resnet50_workspace_bytes(const rpe_resnet50_t* e);

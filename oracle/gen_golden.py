@@ -214,6 +214,40 @@ def run_c1():
     print("no_c1 loss", rec["loss_s1"], "pos/ori err", rec["pos_err_s1"], rec["ori_err_s1"])
 
 
+# The deeper bottleneck trunk import_resnet also offers (util/model_utils.py:130-136): NaiveObjectStateEstimator on ResNet-101,
+# two images.  Key table, pristine eval output, step-1 outputs / loss / gradient digests.
+R101 = (dict(latent_dim=64, hidden=[32], use_depth=False, no_proprioception=False, depth=101), (2,), 41, 401)
+
+
+def run_r101():
+    cfg, lead, wseed, dseed = R101
+    torch.manual_seed(0)
+    model = NaiveObjectStateEstimator("cube", list(cfg["hidden"]), 101, cfg["latent_dim"], False, (9,), False, False, False)
+    sd = po.make_state("no", cfg, wseed)
+    ref_keys = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    assert ref_keys == [(k, tuple(s)) for k, s in po.model_keys("no", cfg)], "state_dict key table mismatch (ResNet-101)"
+    load_values(model, "no", sd)
+    rec = {"keys": np.array([k for k, _ in ref_keys])}
+    model.eval()
+    with torch.no_grad():
+        b = po.synth_batch(lead, dseed + 9)
+        rec["pre_eval_out0"] = model(b["img"], torch.empty(*b["img"].shape), b["x0bar"]).numpy()
+    model.train()
+    b = po.synth_batch(lead, dseed + 1)
+    out = model(b["img"], torch.empty(*b["img"].shape), b["x0bar"])
+    loss = PoseDistanceLoss(**LOSS_CFG)(out, b["obj"])
+    loss.backward()
+    rec["out0_s1"], rec["loss_s1"] = out.detach().numpy(), np.array(loss.item())
+    gn, gd = [], []
+    for name, p in model.named_parameters():
+        if p.grad is not None:
+            gn.append(name)
+            gd.append(digest(p.grad))
+    rec["grad_keys_s1"], rec["grad_digest_s1"] = np.array(gn), np.stack(gd)
+    np.savez_compressed(os.path.join(OUT, "model_no_r101.npz"), **rec)
+    print("no_r101 loss", rec["loss_s1"])
+
+
 def run_loss():
     g = torch.Generator().manual_seed(7)
     rec = {}
@@ -244,11 +278,13 @@ def run_loss():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["loss"] + list(CASES) + ["c1"]
+    which = sys.argv[1:] or ["loss"] + list(CASES) + ["c1", "r101"]
     for w in which:
         if w == "loss":
             run_loss()
         elif w == "c1":
             run_c1()
+        elif w == "r101":
+            run_r101()
         else:
             run_case(w)

@@ -37,7 +37,12 @@ import torch.nn.functional as F
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
-STAGES = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))  # planes, blocks, stride
+STAGES = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))  # planes, blocks, stride  (ResNet-50)
+BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+
+def stages(depth=50):
+    return tuple((pl, n, st) for (pl, _, st), n in zip(STAGES, BLOCKS[depth]))
 
 MODEL_KINDS = ("n", "no", "td", "tdo", "tdo_v2")
 
@@ -45,8 +50,8 @@ MODEL_KINDS = ("n", "no", "td", "tdo", "tdo_v2")
 # ----------------------------------------------------------------------------
 # key tables (state_dict layout of the reference classes)
 # ----------------------------------------------------------------------------
-def resnet_keys(latent_dim):
-    """Ordered (key, shape) list of a torchvision ResNet-50 with fc -> latent_dim."""
+def resnet_keys(latent_dim, depth=50):
+    """Ordered (key, shape) list of a torchvision bottleneck ResNet (50 / 101 / 152) with fc -> latent_dim."""
     out = []
 
     def conv(name, cout, cin, k):
@@ -62,7 +67,7 @@ def resnet_keys(latent_dim):
     conv("conv1", 64, 3, 7)
     bn("bn1", 64)
     inpl = 64
-    for li, (planes, nblk, stride) in enumerate(STAGES, start=1):
+    for li, (planes, nblk, stride) in enumerate(stages(depth), start=1):
         for b in range(nblk):
             p = "layer%d.%d" % (li, b)
             conv(p + ".conv1", planes, inpl, 1)
@@ -105,7 +110,7 @@ def model_keys(kind, cfg):
         fpre = "feature_net."
     else:
         fpre = "feature_net.module."
-    keys += [(fpre + k, s) for k, s in resnet_keys(L)]
+    keys += [(fpre + k, s) for k, s in resnet_keys(L, cfg.get("depth", 50))]
     if kind in ("no", "tdo", "tdo_v2"):
         keys += [
             ("aux_nets.0.module.0.weight", (1, 64, 1, 1)),
@@ -280,13 +285,13 @@ def _bn(sd, name, x, train):
     return F.batch_norm(x, rm, rv, sd[name + ".weight"], sd[name + ".bias"], train, BN_MOMENTUM, BN_EPS)
 
 
-def resnet50_forward(sd, pre, x, train):
+def resnet50_forward(sd, pre, x, train, depth=50):
     """Returns (latent features (B, L), early feature relu(bn1(conv1 x)) (B,64,H/2,W/2))."""
     x = x if EMULATE is None else x.to(EMULATE).to(x.dtype)
     y = _q(F.conv2d(x, _qw(sd[pre + "conv1.weight"]), None, 2, 3))
     early = _q(F.relu(_bn(sd, pre + "bn1", y, train)))
     y = F.max_pool2d(early, 3, 2, 1)
-    for li, (planes, nblk, stride) in enumerate(STAGES, start=1):
+    for li, (planes, nblk, stride) in enumerate(stages(depth), start=1):
         for b in range(nblk):
             p = "%slayer%d.%d" % (pre, li, b)
             s = stride if b == 0 else 1
@@ -333,7 +338,7 @@ def lstm_forward(x, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None):
 def _features(kind, cfg, sd, img, depth, train):
     """ResNet + aux(+depth) concat shared by no/td/tdo/tdo_v2. img (B,3,H,W)."""
     fpre = "feature_net." if kind in ("n", "td") else "feature_net.module."
-    feat, early = resnet50_forward(sd, fpre, img, train)
+    feat, early = resnet50_forward(sd, fpre, img, train, cfg.get("depth", 50))
     if kind == "n":
         return feat
     if kind == "td":

@@ -103,6 +103,14 @@ def _resnet50(pretrained=False, **kw):
     return _ResNet([3, 4, 6, 3])
 
 
+def _resnet101(pretrained=False, **kw):
+    return _ResNet([3, 4, 23, 3])
+
+
+def _resnet152(pretrained=False, **kw):
+    return _ResNet([3, 8, 36, 3])
+
+
 class _Inert:
     def __init__(self, *a, **k):
         pass
@@ -158,7 +166,7 @@ def install():
         tv = types.ModuleType("torchvision")
         tvm = types.ModuleType("torchvision.models")
         tvt = types.ModuleType("torchvision.transforms")
-        tvm.resnet50 = _resnet50
+        tvm.resnet50, tvm.resnet101, tvm.resnet152 = _resnet50, _resnet101, _resnet152
         for name in ("Compose", "ToPILImage", "Resize", "CenterCrop", "ToTensor", "Normalize"):
             setattr(tvt, name, _Inert)
         tv.models, tv.transforms = tvm, tvt

@@ -102,6 +102,7 @@ _SPEC = {
     "rpe_amp_update": (I, [P, F, F, I, P]),
     "rpe_adam_step_amp": (I, [P, P, P, P, L, D, D, D, D, P, P]),
     "rpe_resnet50_create": (I, [POINTER(c_void_p), I, I, I, I, I]),
+    "rpe_resnet_create": (I, [POINTER(c_void_p), I, I, I, I, I, I]),
     "rpe_resnet50_destroy": (None, [P]),
     "rpe_resnet50_workspace_bytes": (L, [P]),
     "rpe_resnet50_param_name": (c_char_p, [P, I]),

@@ -191,8 +191,15 @@ static void want(rpe_resnet50* e, void** dst, long bytes) {
     e->ws_bytes += bytes;
 }
 
+extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int height, int width, int dtype, int latent_dim);
 extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, int width, int dtype, int latent_dim) {
+    return rpe_resnet_create(out, 50, batch, height, width, dtype, latent_dim);
+}
+
+// depth: 50, 101 or 152 -- the bottleneck members of the family util/model_utils.py:130-136 offers (18 / 34 are BasicBlock networks)
+extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int height, int width, int dtype, int latent_dim) {
     if (!out) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_create: null out");
+    if (depth != 50 && depth != 101 && depth != 152) return rpe_set_error(RPE_ERR_SHAPE, "resnet_create: depth must be 50, 101 or 152 (bottleneck ResNets)");
     if (batch <= 0 || latent_dim <= 0) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_create: bad batch/latent");
     if (height < 32 || width < 32 || (height % 32) || (width % 32)) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_create: H, W must be multiples of 32");
     if (dtype != RPE_F32 && dtype != RPE_BF16 && dtype != RPE_F16) return rpe_set_error(RPE_ERR_DTYPE, "resnet50_create: dtype must be RPE_F32, RPE_BF16 or RPE_F16");
@@ -202,7 +209,8 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
     add_conv(e, "conv1", "bn1", height, width, 3, 64, 7, 2, 3);
     int h = e->convs[0].Ho / 2, w = e->convs[0].Wo / 2;  // after maxpool 3x3/2 pad 1 (even sizes)
     int inpl = 64;
-    const int planes[4] = {64, 128, 256, 512}, nblk[4] = {3, 4, 6, 3}, strides[4] = {1, 2, 2, 2};
+    const int planes[4] = {64, 128, 256, 512}, strides[4] = {1, 2, 2, 2};
+    const int nblk[4] = {3, depth == 152 ? 8 : 4, depth == 50 ? 6 : (depth == 101 ? 23 : 36), 3};
     for (int li = 0; li < 4; ++li) {
         for (int b = 0; b < nblk[li]; ++b) {
             const std::string p = "layer" + std::to_string(li + 1) + "." + std::to_string(b);
@@ -308,8 +316,8 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
         if (fcb > e->main_slab_bytes) e->main_slab_bytes = fcb;
         if (e->main_slab_bytes > 0) want(e, &e->main_slab, e->main_slab_bytes);
     }
-    want(e, (void**)&e->pack_tab, 64L * sizeof(rpe_pack_desc));
-    want(e, (void**)&e->pack_tab_fold, 64L * sizeof(rpe_pack_desc));
+    want(e, (void**)&e->pack_tab, (long)(e->convs.size() + 8) * sizeof(rpe_pack_desc));
+    want(e, (void**)&e->pack_tab_fold, (long)(e->convs.size() + 8) * sizeof(rpe_pack_desc));
     for (auto& c : e->convs) {
         const double mnk = 2.0 * (double)c.rows * c.d.out_c * (double)(c.d.kh * c.d.kw * c.d.in_c);
         const double in_b = (double)batch * c.d.in_h * c.d.in_w * c.d.in_c * es, out_b = (double)c.rows * c.d.out_c * es;

@@ -13,7 +13,8 @@ from . import ops
 from ._lib import ResizePlan, lib
 from .util.data_utils import crop_origin, pil_bilinear_tables, resized_hw
 
-_STAGES = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))
+_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}   # bottleneck ResNets (util/model_utils.py:130-136 also lists 18 / 34: BasicBlock, no plan)
+_PLANES_STRIDES = ((64, 1), (128, 2), (256, 2), (512, 2))
 
 
 class _Shortcut(nn.Sequential):
@@ -43,12 +44,15 @@ class ResNet50Trunk(nn.Module):
     (exact-fp32 MFMA path used for the 1e-4 parity bar).
     """
 
-    def __init__(self, num_outputs=1000, compute_dtype=torch.bfloat16):
+    def __init__(self, num_outputs=1000, compute_dtype=torch.bfloat16, depth=50):
         super().__init__()
+        if depth not in _BLOCKS:
+            raise NotImplementedError("only the bottleneck ResNets (50, 101, 152) have a native MI355X launch plan (requested resnet%d)" % depth)
+        self.depth = depth
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         inpl = 64
-        for li, (planes, n, stride) in enumerate(_STAGES, start=1):
+        for li, ((planes, stride), n) in enumerate(zip(_PLANES_STRIDES, _BLOCKS[depth]), start=1):
             blocks = []
             for b in range(n):
                 blocks.append(_BottleneckParams(inpl, planes, stride if b == 0 else 1, b == 0))
@@ -200,7 +204,7 @@ class _Plan:
         self.batch, self.h, self.w = batch, h, w
         self.dtype = trunk.compute_dtype
         hp = ctypes.c_void_p()
-        lib.rpe_resnet50_create(ctypes.byref(hp), batch, h, w, ops.dtype_code(self.dtype), trunk.fc.out_features)
+        lib.rpe_resnet_create(ctypes.byref(hp), trunk.depth, batch, h, w, ops.dtype_code(self.dtype), trunk.fc.out_features)
         self.handle = hp
         nbytes = lib.rpe_resnet50_workspace_bytes(hp)
         self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=trunk.fc.weight.device)
@@ -267,7 +271,7 @@ class _Plan:
         lib.rpe_resnet50_tensor(self.handle, name.encode(), ctypes.byref(ptr), ctypes.byref(rows), ctypes.byref(ch))
         return self._alias(ptr.value, (rows.value, ch.value))
 
-    STAGES = (("layer4", 3), ("layer3", 6), ("layer2", 4), ("layer1", 3))  # bottleneck blocks per stage, in backward order
+    # (stage name, index into the per-stage block counts), in backward order
 
     def backward(self, d_features, use_d_early, stage_done=None):
         """stage_done(name): optional callback fired when the gradients of a stage ("fc", "layer4" .. "layer1", "stem") are
@@ -278,7 +282,9 @@ class _Plan:
             return
         lib.rpe_resnet50_backward_begin(self.handle, ops._p(d_features), d_features.stride(0), s)
         stage_done("fc")
-        for name, nblocks in self.STAGES:
+        counts = _BLOCKS[self.trunk.depth]
+        for li in (4, 3, 2, 1):
+            name, nblocks = "layer%d" % li, counts[li - 1]
             lib.rpe_resnet50_backward_blocks(self.handle, nblocks, 1, s)
             stage_done(name)
         lib.rpe_resnet50_backward_end(self.handle, int(use_d_early), s)

@@ -26,14 +26,14 @@ def import_resnet(num_layers, output_dim, feature_extract=True, use_pretrained=T
 
     Same contract as util/model_utils.py:116-147: validates `num_layers` against the reference's
     option set (which spells 34 as 32), freezes the body iff `feature_extract and use_pretrained`,
-    the new fc is always trainable, returns (model, 224).  Only depth 50 has a native launch plan
-    (every caller passes 50: scripts/train_model.py:63).
+    the new fc is always trainable, returns (model, 224).  Depths 50, 101 and 152 (the bottleneck members) have a
+    native launch plan; every caller of the reference passes 50 (scripts/train_model.py:63).
     """
     options = {18, 32, 50, 101, 152}
     assert num_layers in options, "Invalid layer size specified. Options are: {}".format(options)
-    if num_layers != 50:
-        raise NotImplementedError("only ResNet-50 has a native MI355X launch plan (requested resnet%d)" % num_layers)
-    model = ResNet50Trunk(1000, compute_dtype=compute_dtype)
+    if num_layers not in (50, 101, 152):   # 18 / "32" (the reference's spelling of 34) are BasicBlock networks
+        raise NotImplementedError("only the bottleneck ResNets (50, 101, 152) have a native MI355X launch plan (requested resnet%d)" % num_layers)
+    model = ResNet50Trunk(1000, compute_dtype=compute_dtype, depth=num_layers)
     if use_pretrained:
         path = os.environ.get(PRETRAINED_ENV)
         if path and os.path.exists(path):

@@ -11,8 +11,8 @@ def build(kind, cfg, dtype):
     if kind == "n":
         return M.NaiveEndEffectorStateEstimator(list(cfg["hidden"]), list(cfg["hidden"]), 50, L, False, compute_dtype=dtype)
     if kind == "no":
-        return M.NaiveObjectStateEstimator("cube", list(cfg["hidden"]), 50, L, False, (9,), cfg["use_depth"], False, cfg["no_proprioception"],
-                                           compute_dtype=dtype)
+        return M.NaiveObjectStateEstimator("cube", list(cfg["hidden"]), cfg.get("depth", 50), L, False, (9,), cfg["use_depth"], False,
+                                           cfg["no_proprioception"], compute_dtype=dtype)
     if kind == "td":
         return M.TemporallyDependentStateEstimator(cfg["hidden"], cfg["hidden"], 50, L, 2, 0.1, False, (9,), cfg["use_depth"], False,
                                                    compute_dtype=dtype)

@@ -11,3 +11,5 @@ LOSS_CFG = dict(metric="combined", scale=1.0, alpha=0.5, mode="pose")
 # BASELINE.json configs[0] at its own size (32 images, latent 512, hidden [1024, 256, 64]) -- must match oracle/gen_golden.py C1
 C1 = (dict(latent_dim=512, hidden=[1024, 256, 64], use_depth=False, no_proprioception=False), (32,), 21, 201)
 SAMPLE_STRIDE, SAMPLE_MAX = 997, 4096
+# NaiveObjectStateEstimator on ResNet-101 (import_resnet's deeper bottleneck option) -- must match oracle/gen_golden.py R101
+R101 = (dict(latent_dim=64, hidden=[32], use_depth=False, no_proprioception=False, depth=101), (2,), 41, 401)

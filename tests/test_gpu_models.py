@@ -159,3 +159,40 @@ def test_model_bf16_tracks_fp32_reference(kind, golden_dir):
     for name, p in model.named_parameters():
         if p.grad is not None:
             assert torch.isfinite(p.grad).all(), name
+
+
+def test_resnet101_trunk_matches_reference(golden_dir):
+    """import_resnet's deeper bottleneck option on the same native engine ([3,4,23,3] blocks): state_dict keys, pristine eval
+    output and train step 1 against the reference's vectors (fp32 path, 1e-4 bar), gradients against the oracle."""
+    from _helpers_cases import R101
+    gold = np.load(os.path.join(golden_dir, "model_no_r101.npz"))
+    cfg, lead, wseed, dseed = R101
+    sd = po.make_state("no", cfg, wseed)
+    model = build("no", cfg, torch.float32)
+    assert list(model.state_dict().keys()) == list(gold["keys"])
+    load_values(model, "no", sd)
+    model.cuda().eval()
+    b9 = to_dev(po.synth_batch(lead, dseed + 9))
+    with torch.no_grad():
+        assert rel(model(b9["img"], None, b9["x0bar"]), gold["pre_eval_out0"]) < 2e-4
+    model.train()
+    crit = M.PoseDistanceLoss(distance_metric="combined", scale_factor=1.0, alpha=0.5, mode="pose")
+    b1c = po.synth_batch(lead, dseed + 1)
+    b1 = to_dev(b1c)
+    out = model(b1["img"], None, b1["x0bar"])
+    loss = crit(out, b1["obj"])
+    loss.backward()
+    assert rel(out, gold["out0_s1"]) < 1e-4
+    np.testing.assert_allclose(loss.item(), gold["loss_s1"], rtol=1e-4)
+    ref = po.train_step("no", cfg, {k: v.clone() for k, v in sd.items()}, b1c, LOSS_CFG, {}, lr=1e-3, val_metrics=False)
+    named = dict(model.named_parameters())
+    cos = []
+    for name, g in ref["grads"].items():
+        if float(g.abs().max()) == 0.0:
+            continue
+        a, b = named[name].grad.detach().cpu().double().flatten(), g.double().flatten()
+        cos.append((torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-300)).item())
+    # 101 layers of train-mode BN at batch 2 amplify fp32 rounding further than ResNet-50 does (see the module docstring)
+    assert np.median(cos) > 0.95 and min(cos) > 0.5, (np.median(cos), min(cos))
+    with pytest.raises(NotImplementedError):
+        M.NaiveObjectStateEstimator("cube", [32], 18, 64, False, (9,), False, False, False)
