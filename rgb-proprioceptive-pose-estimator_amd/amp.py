@@ -27,10 +27,12 @@ class LossScaler:
         self.state = None      # 8 device floats, created on first use
 
     def _ensure(self, device):
-        if self.state is None or self.state.device != device:
+        if self.state is None:
             s = torch.zeros(8, dtype=torch.float32)
             s[self.SCALE], s[self.INV] = self.init_scale, 1.0 / self.init_scale
             self.state = s.to(device)
+        elif self.state.device != device:
+            self.state = self.state.to(device)   # e.g. restored from a checkpoint on the host
         return self.state
 
     def scale_tensor(self, device):
@@ -58,4 +60,4 @@ class LossScaler:
 
     def load_state_dict(self, sd):
         self.init_scale, self.growth, self.backoff, self.interval = sd["init_scale"], sd["growth"], sd["backoff"], sd["interval"]
-        self.state = None if sd["state"] is None else sd["state"].clone()
+        self.state = None if sd["state"] is None else sd["state"].clone()   # moved to the device by _ensure at the next use

@@ -32,6 +32,12 @@ class FusedAdam(torch.optim.Optimizer):
                                "(or call model._materialize) before the first step")
         if arena is not self._arena:
             self._arena = arena
+            if self._dev_state is not None:
+                self._dev_state = self._dev_state.to(arena.flat.device)
+            amp_sd = getattr(self, "_amp_restore", None)
+            if amp_sd is not None and getattr(arena, "loss_scaler", None) is not None:
+                arena.loss_scaler.load_state_dict(amp_sd)
+                self._amp_restore = None
             loaded = self._m is not None and self._m.numel() == arena.flat.numel()   # moments restored by load_state_dict
             self._m = self._m.to(arena.flat.device) if loaded else torch.zeros_like(arena.flat)
             self._v = self._v.to(arena.flat.device) if loaded else torch.zeros_like(arena.flat)
@@ -84,12 +90,21 @@ class FusedAdam(torch.optim.Optimizer):
     def state_dict(self):
         """Flat first / second moments in arena order (= model.parameters() order, 16-byte padded segments) + the step count.
         The reference saves no optimizer state (util/learn_utils.py:211-241); this is what a resumable checkpoint adds."""
-        return {"step": self._step, "m": self._m, "v": self._v, "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        sd = {"step": self._step, "m": self._m, "v": self._v, "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        # device-side step count (capturable / fp16 steps) and the loss scaler's state, so that a resumed run continues both
+        if self._dev_state is not None:
+            sd["dev_state"] = self._dev_state.detach().cpu().clone()
+        scaler = getattr(self._arena, "loss_scaler", None) if self._arena is not None else None
+        if scaler is not None:
+            sd["amp"] = scaler.state_dict()
+        return sd
 
     def load_state_dict(self, sd):
         self._step = int(sd["step"])
         self._m = None if sd["m"] is None else sd["m"].clone()
         self._v = None if sd["v"] is None else sd["v"].clone()
         self._arena = None   # re-attached (and the moments moved to its device) at the next step
+        self._dev_state = sd["dev_state"].clone() if sd.get("dev_state") is not None else None
+        self._amp_restore = sd.get("amp")   # handed to the model's scaler when the arena is attached
         for g, sg in zip(self.param_groups, sd.get("param_groups", [])):
             g.update({k: v for k, v in sg.items() if k != "params"})

@@ -430,3 +430,40 @@ def test_gradients_accumulate_across_backward_calls(opt_cls):
     assert p.grad is not None and p.grad.data_ptr() == p._rpe_grad.data_ptr()
     g1_again = grad_of(b1)   # zero_grad() in front: fresh
     assert ((g1_again - g1).norm() / g1.norm()).item() < 1e-5
+
+
+def test_fp16_loss_scaling_skips_and_recovers(tmp_path):
+    """fp16 path: an overflowing loss scale makes the device-side protocol skip the step (parameters, moments and the step
+    count untouched, scale halved) without any host synchronisation; the next steps train; scaler + device step count survive
+    an optimizer checkpoint."""
+    from rgb_proprioceptive_pose_estimator_amd import models as M
+    from rgb_proprioceptive_pose_estimator_amd.optim import FusedAdam
+    from rgb_proprioceptive_pose_estimator_amd.util.data_utils import synthetic_batch
+
+    torch.manual_seed(7)
+    model = M.NaiveObjectStateEstimator("cube", [32], 50, 32, False, (9,), False, False, False, compute_dtype=torch.float16).cuda().train()
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    crit = M.PoseDistanceLoss("combined", 1.0, 0.5, 1e-4, "pose")
+    b = synthetic_batch((4,), 3)
+
+    def step():
+        opt.zero_grad()
+        loss = crit(model(b["img"], None, b["x0bar"]), b["obj"])
+        loss.backward()
+        opt.step()
+        return loss.item()
+
+    step()
+    sc = model.loss_scaler
+    assert sc.steps_taken() == 1 and sc.get_scale() == 2.0 ** 12
+    before = model._arena.flat.clone()
+    sc.state[sc.SCALE], sc.state[sc.INV] = 2.0 ** 40, 2.0 ** -40     # guaranteed fp16 overflow in the backward signal
+    step()
+    assert torch.equal(model._arena.flat, before), "a step with non-finite gradients must leave the parameters alone"
+    assert sc.steps_taken() == 1 and sc.get_scale() == 2.0 ** 39
+    sc.state[sc.SCALE], sc.state[sc.INV] = 2.0 ** 12, 2.0 ** -12
+    l1 = step()
+    assert sc.steps_taken() == 2 and not torch.equal(model._arena.flat, before) and l1 == l1
+    torch.save(opt.state_dict(), tmp_path / "o.pt")
+    sd = torch.load(tmp_path / "o.pt")
+    assert sd["amp"]["state"][sc.STEPS].item() == 2.0
