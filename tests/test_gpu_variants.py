@@ -13,16 +13,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 NT = "conv_fwd_and_stats or conv_dgrad or dgrad_with_fused_bn_backward or linear_fwd_layout"
 TN = "conv_wgrad or linear_wgrad"
 
-VARIANTS = [   # (switch, the parity cases of test_gpu_ops.py it can affect)
-    ({"RPE_NT_BIG": "1"}, NT),        # 256-row / 8-wave NT tiles for M >= 4096, K >= 1024
-    ({"RPE_NT_BK64": "1"}, NT),       # 128-byte K rows + 2-slot ring for every K
-    ({"RPE_NT_NOBK64": "1"}, NT),     # ... and for none
-    ({"RPE_NT_W8": "1"}, NT),         # 8 waves on the 128x128 tile of the short-K dense launches
-    ({"RPE_NT_NTSTORE": "1"}, NT),    # non-temporal epilogue stores
-    ({"RPE_NO_PARITY": "1"}, "conv_dgrad or dgrad_with_fused_bn_backward"),   # stride-2 data gradient without the parity-class decomposition
-    ({"RPE_TN_REG": "1"}, TN),        # register staging instead of the LDS-DMA ring in the weight-gradient kernel
-    ({"RPE_TN_WGS": "64"}, TN),       # few, long split-M slices in the weight gradient
-    ({"RPE_TN_RING": "1,4"}, TN),     # 4-slot ring of 32-row steps in the weight-gradient kernel
+ALL = NT + " or " + TN
+
+# Independent switches are grouped per child process (each child pays the interpreter + torch start-up): a failure names the
+# group, the switches in it are then run one by one by hand.
+VARIANTS = [   # (switches, the parity cases of test_gpu_ops.py they can affect)
+    # 256-row / 8-wave NT tiles for M >= 4096, K >= 1024; register staging in the weight-gradient kernel; stride-2 data gradient
+    # without the parity-class decomposition; non-temporal epilogue stores
+    ({"RPE_NT_BIG": "1", "RPE_TN_REG": "1", "RPE_NO_PARITY": "1", "RPE_NT_NTSTORE": "1"}, ALL),
+    # 128-byte K rows + 2-slot ring for every K; few, long split-M slices in the weight gradient; 8 waves on the 128x128 tile
+    ({"RPE_NT_BK64": "1", "RPE_TN_WGS": "64", "RPE_NT_W8": "1"}, ALL),
+    # 64-byte K rows for every K; 4-slot ring of 32-row steps in the weight-gradient kernel
+    ({"RPE_NT_NOBK64": "1", "RPE_TN_RING": "1,4"}, ALL),
     ({"RPE_TN_RING": "2,3"}, TN),     # 3-slot ring of 64-row steps for every shape
 ]
 
@@ -41,12 +43,11 @@ def test_kernel_variant_parity(env, subset):
 # schedule / fusion switches of the trunk engine: one golden train step per model family must still match the reference
 ENGINE_VARIANTS = [
     {"RPE_NO_OVERLAP": "1"},        # everything on one stream
-    {"RPE_NO_FWD_OVERLAP": "1"},    # projection-shortcut branch on the main stream
-    {"RPE_STEM_UNFUSED": "1"},      # dense early-feature gradient + separate pool / BN backward passes for the stem
-    {"RPE_FWD_SPLIT": "1"},         # forward as two concurrent half-batch pipelines joined at the BN statistics
-    {"RPE_NO_BN_FOLD": "1"},        # conv3 backward through a materialised dy (streaming dz, y -> dy pass on the main stream)
-    {"RPE_NO_WGRAD_FOLD": "1"},     # conv3 weight gradient from dy (dz, y -> dy on the side stream) instead of the folded form
-    {"RPE_WGRAD_ATOMIC": "1"},      # fp32 atomics instead of slab + fixed-order sums in the weight gradients
+    # projection-shortcut branch on the main stream; dense early-feature gradient + separate pool / BN backward passes for the
+    # stem; conv3 backward through a materialised dy on the main stream
+    {"RPE_NO_FWD_OVERLAP": "1", "RPE_STEM_UNFUSED": "1", "RPE_NO_BN_FOLD": "1"},
+    # forward as two concurrent half-batch pipelines; conv3 weight gradient from dy; fp32 atomics instead of slabs
+    {"RPE_FWD_SPLIT": "1", "RPE_NO_WGRAD_FOLD": "1", "RPE_WGRAD_ATOMIC": "1"},
     {"RPE_CD_SIDE": "1"},           # projection-shortcut backward on the side stream
 ]
 
