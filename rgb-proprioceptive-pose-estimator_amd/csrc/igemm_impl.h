@@ -18,6 +18,10 @@
 #pragma once
 #include "igemm.h"
 
+#ifndef RPE_EPI_DEPTH
+#define RPE_EPI_DEPTH 4   // epilogue operand prefetch distance of the fused data gradients, in steps (see nt_kernel, PIPE)
+#endif
+
 namespace rpe {
 
 // LDS slot permutation of the [row][KCH x 16 B] staging tiles (slot = chunk ^ f(row)).
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 4 : 2) void 
     // keeps ~1-3 KB per wave in flight; here the operands of the next DEPTH steps are requested ahead (the first DEPTH
     // before the K loop even starts), 16 B per lane and operand, into registers that are recycled step by step.
     constexpr bool PIPE = (ROLE == 1) && (CE == 8);
-    constexpr int DEPTH = PIPE ? (NSTEP < 4 ? NSTEP : 4) : 1;
+    constexpr int DEPTH = PIPE ? (NSTEP < RPE_EPI_DEPTH ? NSTEP : RPE_EPI_DEPTH) : 1;
     u32x4 qd[DEPTH], qy[DEPTH], qa[DEPTH];
     auto step_row = [&](int t) -> long { return out_row(wave_m * WM + (t / NPASS) * 16 + (t % NPASS) * RPP + erow); };
     auto issue = [&](int t) {
