@@ -112,7 +112,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // HBM-bound short-K launches whose workgroups spend most of their life in the load latency and the epilogue: more waves per CU
 // in flight, half the epilogue per wave).
 template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE, int BNM = 0, int WAVES_N = 2>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 4 : 2) void nt_kernel(const NTArgs<T> p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_N == 4 && BN < 256) ? 4 : 2) void nt_kernel(const NTArgs<T> p) {
     constexpr int CE = Elem<T>::kChunk, BK = KCH * CE;
     constexpr int NW = WAVES_N * WAVES_M, NTHR = 64 * NW;
     constexpr int BM = 64 * WAVES_M, WM = 64, WN = BN / WAVES_N, FM = WM / 16, FN = WN / 16;
@@ -1024,6 +1024,11 @@ template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s) 
             if (!a.stats_part && (long)ceil_div(a.M, 128) * ceil_div(a.N, wide ? 128 : 64) < 96) return launch_nt_cfg<T, 1, 64, 4, MODE_DENSE>(a, s);
         }
         if constexpr (MODE == MODE_DENSE) {
+            // 128x256 tiles (8 waves of 64x64) for wide outputs: a 128-column tile writes 256-byte pieces of 512..4096-byte output
+            // rows, and the HBM write rate falls with the fraction of a row one workgroup covers (tools/probe_rows.py: 5.2 TB/s
+            // at N = 64, 4.3 at 128, 3.4 at 256, 3.0 at 512 with 128-column tiles)
+            static const int wide256 = getenv("RPE_NT_WIDE") ? atoi(getenv("RPE_NT_WIDE")) : 0;
+            if (wide256 && (a.role == 0 || (wide256 >= 2 && a.role == 1)) && a.M >= 4096 && a.N >= 256) return launch_nt_cfg<T, 2, 256, 4, MODE, 3, 4>(a, s);
             // 8 waves on the 128x128 tile for the short-K 1x1 layers of the two training roles: an experiment switch (RPE_NT_W8=1).
             // Measured at 256 images: forward launches +3 %, the fused-epilogue data gradients -7 % (128 VGPRs with spills at
             // 4 waves per SIMD), the train step 22.6 vs 22.0 ms -- occupancy is not what bounds these launches.
