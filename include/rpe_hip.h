@@ -70,6 +70,13 @@ int rpe_conv2d_fwd(const rpe_conv_desc* d, int dtype, const void* x, const void*
  * Bottleneck (called at models/naive.py:316 in eval mode / rollout). */
 int rpe_conv2d_fwd_affine(const rpe_conv_desc* d, int dtype, const void* x, const void* w_krsc, void* out, const float* bias, const void* addend,
                           int relu, void* stream);
+/* The same with a caller-provided workspace: launches with few output tiles and a long reduction (one rollout frame through
+ * layer2-4: 4..26 tiles of 64 x 64 walking K = 1152..4608 alone) are split along K over 4..32 workgroups per tile; the
+ * partial fp32 tiles go through the workspace and are added in a fixed order by a second small launch.  The query returns 0
+ * for shapes that are not split (the call then equals rpe_conv2d_fwd_affine); workspace 16-byte aligned, no state kept in it. */
+long rpe_conv2d_fwd_affine_workspace_bytes(const rpe_conv_desc* d, int dtype);
+int rpe_conv2d_fwd_affine_ws(const rpe_conv_desc* d, int dtype, const void* x, const void* w_krsc, void* out, const float* bias, const void* addend,
+                             int relu, void* workspace, long workspace_bytes, void* stream);
 /* dx[B][H][W][in_c] = conv_transpose(dy, w) (+ addend);  w_crsk = [in_c][kh][kw][out_c]. */
 int rpe_conv2d_dgrad(const rpe_conv_desc* d, int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, void* stream);
 /* Data gradient with the BatchNorm-backward reduction of the PRODUCING layer fused into the epilogue:

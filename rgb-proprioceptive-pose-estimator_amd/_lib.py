@@ -46,6 +46,8 @@ _SPEC = {
     "rpe_conv_stats_tiles": (L, [L]),
     "rpe_conv2d_fwd": (I, [PD, I, P, P, P, P, P]),
     "rpe_conv2d_fwd_affine": (I, [PD, I, P, P, P, P, P, I, P]),
+    "rpe_conv2d_fwd_affine_workspace_bytes": (L, [PD, I]),
+    "rpe_conv2d_fwd_affine_ws": (I, [PD, I, P, P, P, P, P, I, P, L, P]),
     "rpe_conv2d_dgrad": (I, [PD, I, P, P, P, P, P]),
     "rpe_conv2d_dgrad_stats_tiles": (L, [PD]),
     "rpe_conv2d_dgrad_bn": (I, [PD, I, P, P, P, P, POINTER(BnBwdEpilogue), P]),

@@ -45,7 +45,7 @@ static inline bool is_dense(const rpe_conv_desc* d) { return d->kh == 1 && d->kw
 
 template <typename T>
 static int conv_fwd_t(const rpe_conv_desc* d, const void* x, const void* w, void* y, float* stats, const float* bias, const void* addend, int relu,
-                      hipStream_t s) {
+                      hipStream_t s, void* ws = nullptr, long ws_bytes = 0, long* ws_query = nullptr) {
     const int Ho = out_dim(d->in_h, d->kh, d->stride, d->pad), Wo = out_dim(d->in_w, d->kw, d->stride, d->pad);
     NTArgs<T> a;
     memset(&a, 0, sizeof(a));
@@ -55,6 +55,16 @@ static int conv_fwd_t(const rpe_conv_desc* d, const void* x, const void* w, void
     a.stats_part = stats;
     a.bias = bias; a.addend = (const T*)addend; a.ld_add = d->out_c; a.relu = relu;
     if (bias || addend || relu) { a.role = 3; a.stats_part = nullptr; }   // inference epilogue (no batch statistics)
+    if (ws_query || ws) {
+        // few output tiles and a long reduction (a rollout frame): split K over grid.y, partial tiles through the workspace
+        const int S = nt_split_plan(a.M, a.N, a.K, 4 * Elem<T>::kChunk, nullptr);
+        const long need = S > 1 ? nt_split_slab_bytes(a.M, a.N, S) : 0;
+        if (ws_query) { *ws_query = need; return 0; }
+        if (S > 1 && a.role == 3) {
+            if (ws_bytes < need || (((uintptr_t)ws) & 15)) return rpe_set_error(RPE_ERR_WORKSPACE, "conv2d_fwd_affine_ws: workspace smaller than rpe_conv2d_fwd_affine_workspace_bytes() or unaligned");
+            a.slab = (float*)ws; a.slab_bytes = ws_bytes; a.splits = S;
+        }
+    }
     if (is_dense(d)) return launch_nt<T>(a, MODE_DENSE, s);
     Gather& g = a.g;
     g.H = d->in_h; g.W = d->in_w; g.C = d->in_c; g.Ho = Ho; g.Wo = Wo; g.R = d->kh; g.S = d->kw;
@@ -346,9 +356,78 @@ static int stem_wgrad_t(const void* x4, const void* dy, float* dw_packed, int B,
     return launch_tn<T>(a, MODE_STEM, s, slab_query);
 }
 
+// Few-row fp32 Linear (a rollout frame is ONE row; the heads' layers are fp32): y[m][n] = x[m][:] . w[n][:] (+bias) (+addend) (relu).
+// The MFMA tile kernel put 8..16 workgroups on the chip for these (135 us for 1 x 3655 -> 1024: 15 MB of weights at 110 GB/s).
+// Here one workgroup per output column: 256 lanes stride over K (coalesced dword loads, any alignment), fixed-order reduction
+// (lane butterfly, then the 4 waves in order) -- the weights stream once at chip rate.
+template <int MT>
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, int ldw,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int ldy, int M, int N, int K,
+                                                          int relu, const float* __restrict__ addend, int ld_add) {
+    __shared__ float red[4][MT];
+    const int n = blockIdx.x, m0 = blockIdx.y * MT;
+    const float* wr = w + (long)n * ldw;
+    const float* xr[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) xr[i] = x + (long)(m0 + i < M ? m0 + i : M - 1) * ldx;   // (rows past M repeat the last one; never stored)
+    float acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = 0.f;
+    int k = threadIdx.x;
+    for (; k + 768 < K; k += 1024) {   // four independent weight loads in flight per lane
+        const float w0 = wr[k], w1 = wr[k + 256], w2 = wr[k + 512], w3 = wr[k + 768];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            acc[i] = fmaf(xr[i][k + 768], w3, fmaf(xr[i][k + 512], w2, fmaf(xr[i][k + 256], w1, fmaf(xr[i][k], w0, acc[i]))));
+    }
+    for (; k < K; k += 256) {
+        const float w0 = wr[k];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i] = fmaf(xr[i][k], w0, acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[i] += __shfl_xor(acc[i], o, 64);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) red[wave][i] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < MT && m0 + (int)threadIdx.x < M) {
+        const int i = threadIdx.x, m = m0 + i;
+        float v = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+        if (bias) v += bias[n];
+        if (addend) v += addend[(long)m * ld_add + n];
+        if (relu) v = fmaxf(v, 0.f);
+        y[(long)m * ldy + n] = v;
+    }
+}
+
+static const int kLinearRowsMax = 8;   // rows up to which the per-column kernel is used (the weights are re-read per group of 8 rows)
+
+static int linear_rows(const float* x, int ldx, const float* w, int ldw, const float* bias, float* y, int ldy, int M, int N, int K, int relu,
+                       const float* addend, int ld_add, hipStream_t s) {
+    note_kernel("linear_rows_kernel");
+    const dim3 block(256);
+    if (M == 1) hipLaunchKernelGGL((linear_rows_kernel<1>), dim3(N, 1), block, 0, s, x, ldx, w, ldw, bias, y, ldy, M, N, K, relu, addend, ld_add);
+    else if (M == 2) hipLaunchKernelGGL((linear_rows_kernel<2>), dim3(N, 1), block, 0, s, x, ldx, w, ldw, bias, y, ldy, M, N, K, relu, addend, ld_add);
+    else if (M <= 4) hipLaunchKernelGGL((linear_rows_kernel<4>), dim3(N, 1), block, 0, s, x, ldx, w, ldw, bias, y, ldy, M, N, K, relu, addend, ld_add);
+    else hipLaunchKernelGGL((linear_rows_kernel<8>), dim3(N, (M + 7) / 8), block, 0, s, x, ldx, w, ldw, bias, y, ldy, M, N, K, relu, addend, ld_add);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
 template <typename T>
 static int linear_fwd_t(const void* x, int ldx, const void* w, int ldw, const float* bias, void* y, int ldy, int M, int N, int K, int relu,
                         const void* addend, int ld_add, hipStream_t s) {
+    if constexpr (sizeof(T) == 4) {
+        static const bool rows_off = getenv("RPE_NO_LINEAR_ROWS") != nullptr;
+        if (!rows_off && x && w && y && M >= 1 && M <= kLinearRowsMax && N >= 1 && K >= 1 && ldx >= K && ldw >= K && ldy >= N)
+            return linear_rows((const float*)x, ldx, (const float*)w, ldw, bias, (float*)y, ldy, M, N, K, relu, (const float*)addend, ld_add, s);
+    }
     NTArgs<T> a;
     memset(&a, 0, sizeof(a));
     a.A = (const T*)x; a.Bw = (const T*)w; a.C = (T*)y;
@@ -404,6 +483,23 @@ int rpe_conv2d_fwd_affine(const rpe_conv_desc* d, int dtype, const void* x, cons
                           int relu, void* stream) {
     if (int e = check_desc(d)) return e;
     DISPATCH(dtype, conv_fwd_t, d, x, w_krsc, out, nullptr, bias, addend, relu, (hipStream_t)stream);
+}
+
+static int fwd_ws_query(const rpe_conv_desc* d, int dtype, long* bytes) {
+    DISPATCH(dtype, conv_fwd_t, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, 0L, bytes);
+}
+
+long rpe_conv2d_fwd_affine_workspace_bytes(const rpe_conv_desc* d, int dtype) {
+    long bytes = 0;
+    if (check_desc(d) || fwd_ws_query(d, dtype, &bytes)) return -1;
+    return bytes;
+}
+
+int rpe_conv2d_fwd_affine_ws(const rpe_conv_desc* d, int dtype, const void* x, const void* w_krsc, void* out, const float* bias, const void* addend,
+                             int relu, void* workspace, long workspace_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    if (!bias && !addend && !relu) return rpe_set_error(RPE_ERR_SHAPE, "conv2d_fwd_affine_ws: the inference epilogue needs a bias, an addend or ReLU");
+    DISPATCH(dtype, conv_fwd_t, d, x, w_krsc, out, nullptr, bias, addend, relu, (hipStream_t)stream, workspace, workspace_bytes, nullptr);
 }
 
 int rpe_conv2d_dgrad(const rpe_conv_desc* d, int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, void* stream) {

@@ -108,6 +108,8 @@ struct rpe_resnet50 {
     // conv/fc weight gradients are accumulated with atomics: when the bound gradient tensors form one contiguous block
     // (they do in the flat arena) it is zeroed by ONE memset per backward instead of 54 (15 us each)
     rpe_pack_desc* pack_tab = nullptr;   // device table for the one-launch weight packing
+    void* sk_ws = nullptr;               // split-K workspace of the inference forward (rpe_conv2d_fwd_affine_ws); 0 bytes when no layer splits
+    long sk_ws_bytes = 0;
     rpe_pack_desc* pack_tab_fold = nullptr;  // ... with the BN scale folded into the forward copy (inference)
     int pack_state = 0;                  // what the forward copies hold: 0 unknown, 1 plain weights, 2 weights * BN scale (eval)
     long pack_total = 0;
@@ -315,6 +317,14 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
         const long fcb = rpe_linear_wgrad_workspace_bytes(RPE_F32, batch, latent_dim, 2048);
         if (fcb > e->main_slab_bytes) e->main_slab_bytes = fcb;
         if (e->main_slab_bytes > 0) want(e, &e->main_slab, e->main_slab_bytes);
+    }
+    // inference forward of few-row layers (rollout frames): split-K partial tiles
+    if (getenv("RPE_NO_SPLITK") == nullptr) {
+        for (size_t i = 1; i < e->convs.size(); ++i) {
+            const long sb = rpe_conv2d_fwd_affine_workspace_bytes(&e->convs[i].d, dtype);
+            if (sb > e->sk_ws_bytes) e->sk_ws_bytes = sb;
+        }
+        if (e->sk_ws_bytes > 0) want(e, &e->sk_ws, e->sk_ws_bytes);
     }
     want(e, (void**)&e->pack_tab, (long)(e->convs.size() + 8) * sizeof(rpe_pack_desc));
     want(e, (void**)&e->pack_tab_fold, (long)(e->convs.size() + 8) * sizeof(rpe_pack_desc));
@@ -593,6 +603,8 @@ static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residua
     if (!train) {
         // folded inference form (fold_for_eval): a = relu(conv(x, w*scale) + shift (+ residual)); y is not written
         if (&c == &e->convs[0]) PROF(e, RPE_PROF_CONV_FWD, stream, rpe_stem_conv_fwd_affine(e->dtype, x, c.wf, c.a, c.shift, relu, e->B, e->H, e->W, stream));
+        else if (e->sk_ws && !second_set)   // (one workspace: the main stream's launches only; the side stream runs the projection shortcuts)
+            PROF(e, RPE_PROF_CONV_FWD, stream, rpe_conv2d_fwd_affine_ws(&c.d, e->dtype, x, c.wf, c.a, c.shift, residual, relu, e->sk_ws, e->sk_ws_bytes, stream));
         else PROF(e, RPE_PROF_CONV_FWD, stream, rpe_conv2d_fwd_affine(&c.d, e->dtype, x, c.wf, c.a, c.shift, residual, relu, stream));
         return 0;
     }

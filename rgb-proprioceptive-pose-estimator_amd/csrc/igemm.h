@@ -60,7 +60,31 @@ template <typename T> struct NTArgs {
                          // selects the epilogue variant compiled into the kernel and tags its symbol in profiles
     long a_elems;        // elements of the tensor behind A (conv modes; 0 = dense, derived from M and lda)
     unsigned a_bytes, b_bytes;   // buffer-descriptor extents of A and Bw (filled by the launcher, < 2 GiB each)
+    // Split-K form of the inference forward (few output tiles, long K: one rollout frame).  role 3 with `slab` set and
+    // splits > 1 runs as role 4: grid.y = splits, workgroup (tile, z) walks K steps [z * split_steps, (z+1) * split_steps)
+    // and stores its raw fp32 accumulators (fragment order) into slab[z][tile]; nt_split_epilogue_kernel then adds the
+    // splits in z order and applies bias / addend / ReLU.  Planned by nt_split_plan().
+    float* slab;
+    long slab_bytes;
+    int splits, split_steps;
 };
+
+// split plan of an inference-forward launch with 64 x 64 tiles and K steps of `bk` elements: number of splits (1 = not
+// split) and K steps per split.  A split launch costs a second (epilogue) launch, so it must buy at least 4x the workgroups.
+static inline int nt_split_plan(long M, int N, int K, int bk, int* steps_per_split) {
+    const long tiles = ((M + 63) / 64) * ((N + 63) / 64);
+    const int nk = (K + bk - 1) / bk;
+    if (steps_per_split) *steps_per_split = nk;
+    if (M > 1024 || tiles >= 64 || nk < 32) return 1;
+    long S = (128 + tiles - 1) / tiles;
+    if (S > nk / 8) S = nk / 8;
+    if (S > 32) S = 32;
+    if (S < 4) return 1;
+    const int steps = (nk + (int)S - 1) / (int)S;
+    if (steps_per_split) *steps_per_split = steps;
+    return (nk + steps - 1) / steps;
+}
+static inline long nt_split_slab_bytes(long M, int N, int splits) { return ((M + 63) / 64) * ((N + 63) / 64) * (long)splits * 64 * 64 * 4; }
 
 template <typename T> struct TNArgs {
     const T* P;     // [M][ldp]   (dy / upstream gradient), columns i (Cout)

@@ -230,6 +230,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_N == 4 && BN < 256) 
         kbase = (tr * g.S + ts) * g.C;
         nk = nr * ns * (g.C / BK);
     }
+    if (ROLE == 4) {   // split-K partial: this workgroup's slice of the K steps (never with parity classes: forward only)
+        const int k0 = (int)blockIdx.y * p.split_steps;
+        nk = nk - k0 < p.split_steps ? nk - k0 : p.split_steps;
+        kbase = k0 * BK;
+        if (MODE == MODE_CONV) {
+            const int tap = kbase / g.C;
+            c0 = kbase - tap * g.C;
+            tr = tap / g.S;
+            ts = tap - tr * g.S;
+        }
+    }
 
     // source address of A chunk i for the current K-step, or nullptr for zero fill
     auto a_src = [&](int i) -> const T* {
@@ -448,6 +459,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_N == 4 && BN < 256) 
         for (int kt = 1; kt < nk; ++kt) k_step(kt, TagNext{});
     }
 
+    if constexpr (ROLE == 4) {
+        // split-K partial: raw accumulators in fragment order, 1 KB per wave store; nt_split_epilogue_kernel finishes the tile
+        float* dst = p.slab + (((size_t)blockIdx.y * ((size_t)p.tiles_m * p.tiles_n) + lb) * NW + wave) * (size_t)(FN * FM * 256);
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+            for (int b = 0; b < FM; ++b) *(f32x4*)(dst + ((a * FM + b) * 64 + lane) * 4) = acc[a][b];
+        return;
+    }
     // ---- epilogue ---------------------------------------------------------------------------------
     // A lane's accumulators hold 4 channels of 16 scattered rows.  They go through LDS once so that every lane
     // ends up with 8 consecutive channels of ONE row: epilogue operands (addend, and for the fused BN-backward
@@ -954,6 +974,62 @@ __global__ __launch_bounds__(512) void tn_reduce_kernel(const float* __restrict_
     }
 }
 
+// Second half of a split-K inference forward (NTArgs::slab): out = relu(sum_z partial[z] + bias + addend).  The partials are
+// the accumulators of nt_kernel<T, 1, 64, 4, ., 3, 4> in fragment order: tile (64 x 64) -> 2 waves (32 columns each) -> fragment
+// (a, b) = 16 columns x 16 rows -> lane (row = lane & 15, 4 columns from 4 * (lane >> 4)).  One thread per 16-byte piece; the
+// splits are added in z order (fixed: the result does not depend on how the workgroups were scheduled).
+template <typename T>
+__global__ __launch_bounds__(256) void nt_split_epilogue_kernel(const float* __restrict__ slab, int splits, int tiles_m, int tiles_n, int M, int N,
+                                                               const float* __restrict__ bias, const T* __restrict__ addend, int ld_add, int relu,
+                                                               T* __restrict__ C, int ldc) {
+    const long piece = (long)blockIdx.x * 256 + threadIdx.x;      // 16-byte piece of one split's slab
+    const long tiles = (long)tiles_m * tiles_n;
+    if (piece >= tiles * 1024) return;
+    const int lane = (int)(piece & 63), frag = (int)((piece >> 6) & 7), wave = (int)((piece >> 9) & 1);
+    const long tile = piece >> 10;
+    const int a = frag >> 2, b = frag & 3;
+    const int tile_n = (int)(tile % tiles_n), tile_m = (int)(tile / tiles_n);
+    const long m = (long)tile_m * 64 + b * 16 + (lane & 15);
+    const int n = tile_n * 64 + wave * 32 + a * 16 + (lane >> 4) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const f32x4* src = (const f32x4*)slab + piece;
+    const long zstride = tiles * 1024;
+    int z = 0;
+    for (; z + 4 <= splits; z += 4) {
+        const f32x4 p0 = src[(long)z * zstride], p1 = src[(long)(z + 1) * zstride], p2 = src[(long)(z + 2) * zstride], p3 = src[(long)(z + 3) * zstride];
+        v += p0; v += p1; v += p2; v += p3;
+    }
+    for (; z < splits; ++z) v += src[(long)z * zstride];
+    if (m >= M || n >= N) return;                                  // (conv outputs: N % 8 == 0, a 4-column piece is in or out as a whole)
+    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (bias) o[j] += bias[n + j];
+        if (addend) o[j] += Elem<T>::to_f(addend[m * ld_add + n + j]);
+        if (relu) o[j] = fmaxf(o[j], 0.f);
+        C[m * ldc + n + j] = Elem<T>::from_f(o[j]);
+    }
+}
+
+template <typename T, int MODE> static int launch_nt_split(NTArgs<T>& a, hipStream_t s) {
+    constexpr int BK = 4 * Elem<T>::kChunk;
+    int steps = 0;
+    const int S = nt_split_plan(a.M, a.N, a.K, BK, &steps);
+    a.tiles_m = ceil_div(a.M, 64);
+    a.tiles_n = ceil_div(a.N, 64);
+    const long tiles = (long)a.tiles_m * a.tiles_n;
+    if (S < 2 || !a.slab || a.slab_bytes < nt_split_slab_bytes(a.M, a.N, S) || (MODE == MODE_CONV && a.g.parity))
+        return rpe_set_error(RPE_ERR_WORKSPACE, "igemm_nt: split-K launch without a plan or with a slab smaller than planned");
+    a.splits = S; a.split_steps = steps;
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "nt_kernel<%s,1,64,4,%d,3,4,0> x%d + nt_split_epilogue_kernel", Elem<T>::kName, MODE, S);
+    hipLaunchKernelGGL((nt_kernel<T, 1, 64, 4, MODE, 3, 4, 0, 2>), dim3((unsigned)tiles, (unsigned)S), dim3(128), 0, s, a);
+    RPE_CHECK_LAUNCH();
+    hipLaunchKernelGGL((nt_split_epilogue_kernel<T>), dim3((unsigned)((tiles * 1024 + 255) / 256)), dim3(256), 0, s, (const float*)a.slab, S, a.tiles_m,
+                       a.tiles_n, a.M, a.N, a.bias, a.addend, a.ld_add, a.relu, a.C, a.ldc);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
 // -----------------------------------------------------------------------------------------------
 // host launchers (templates; instantiated per element type and staging mode in the igemm_*.hip units, which compile in
 // parallel -- one unit with every configuration took 5 minutes)
@@ -1003,6 +1079,7 @@ template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s) 
     if constexpr (MODE == MODE_STEM) {
         return launch_nt_cfg<T, 2, 64, 4, MODE_STEM>(a, s);
     } else {
+        if (a.role == 3 && a.slab && a.splits > 1) return launch_nt_split<T, MODE>(a, s);
         // 256-row / 8-wave tiles (1 workgroup per CU): measured on the ResNet shapes at bs256 they gain 3..10 % in isolation
         // for K >= 1024 and lose 10..25 % for short K, and LOSE overall inside the train step (fused epilogues, 2 waves/SIMD
         // in lockstep): 34.4 vs 32.9 ms/step.  Kept selectable for experiments (RPE_NT_BIG=1), off by default.

@@ -70,14 +70,20 @@ def conv2d_fwd(x, w_krsc, stride, pad, want_stats=False):
     return (y, st) if want_stats else y
 
 
-def conv2d_fwd_affine(x, w_krsc, stride, pad, bias, addend=None, relu=True):
+def conv2d_fwd_affine(x, w_krsc, stride, pad, bias, addend=None, relu=True, split_k=True):
     """Inference form: relu(conv(x, w) + bias (+ addend)) in one launch (BatchNorm folded: w = weight * scale, bias = shift)."""
     _chk(x, "x"), _chk(w_krsc, "w")
     co, k = w_krsc.shape[0], w_krsc.shape[1]
     d = conv_desc(x.shape, co, k, stride, pad)
     ho, wo = conv_out_hw(d)
     out = torch.empty((x.shape[0], ho, wo, co), dtype=x.dtype, device=x.device)
-    lib.rpe_conv2d_fwd_affine(ctypes.byref(d), dtype_code(x), _p(x), _p(w_krsc), _p(out), _p(bias), _p(addend), int(relu), _stream())
+    need = lib.rpe_conv2d_fwd_affine_workspace_bytes(ctypes.byref(d), dtype_code(x)) if split_k else 0
+    if need > 0:   # few output tiles, long K (a rollout frame): split-K through a workspace
+        ws = scratch(need, x.device)
+        lib.rpe_conv2d_fwd_affine_ws(ctypes.byref(d), dtype_code(x), _p(x), _p(w_krsc), _p(out), _p(bias), _p(addend), int(relu), _p(ws), ws.numel(),
+                                     _stream())
+    else:
+        lib.rpe_conv2d_fwd_affine(ctypes.byref(d), dtype_code(x), _p(x), _p(w_krsc), _p(out), _p(bias), _p(addend), int(relu), _stream())
     return out
 
 
@@ -118,6 +124,11 @@ def bn_backward_from_dz(dz, y, mean, invstd, gamma, stats_part):
 
 
 _SCRATCH = {}
+
+
+def last_kernel_name():
+    """Symbol (with its configuration) of the kernel the last implicit-GEMM / BN entry point launched from this thread."""
+    return lib.rpe_last_kernel_name().decode()
 
 
 def scratch(nbytes, device):

@@ -60,6 +60,31 @@ def test_linear_fwd_layout(dtype, m, n, k):
     assert rel_err(out, ref) < tol(dtype)
 
 
+@pytest.mark.parametrize("m,n,k", [(1, 1024, 3655), (1, 7, 64), (2, 130, 259), (3, 64, 1000), (5, 33, 4099), (8, 512, 2048), (7, 9, 1)])
+def test_linear_fwd_few_rows(m, n, k):
+    """Rollout frames: fp32 Linear with <= 8 rows runs on the per-column kernel (any row stride / alignment, bias, addend, ReLU)."""
+    g = torch.Generator().manual_seed(m * 77 + n)
+    xf, wf, af = torch.randn(m, k + 3, generator=g), torch.randn(n, k + 1, generator=g), torch.randn(m, n + 2, generator=g)
+    x, w, add = xf[:, :k], wf[:, :k], af[:, :n]            # row strides that are not multiples of 4 elements
+    b = torch.randn(n, generator=g)
+    xd, wd, ad = xf.to(DEV)[:, :k], wf.to(DEV)[:, :k], af.to(DEV)[:, :n]
+    assert xd.stride(0) == k + 3 and wd.stride(0) == k + 1
+    ref = x.double() @ w.double().t() + b.double()
+    out = ops.linear_fwd(xd, wd, b.to(DEV))
+    assert rel_err(out, ref.float()) < 2e-6
+    out = ops.linear_fwd(xd, wd, b.to(DEV), relu=True, addend=ad)
+    assert rel_err(out, F.relu(ref + add.double()).float()) < 2e-6
+    out = ops.linear_fwd(xd, wd, None)
+    assert rel_err(out, (ref - b.double()).float()) < 2e-6
+    # the same product through the MFMA tile kernel (9 rows: one more than the few-row limit), row by row
+    x9 = torch.cat([x, x[:1].expand(9 - m, k)], 0) if m < 9 else x
+    kp = (k + 7) // 8 * 8
+    xp, wp = torch.zeros(9, kp), torch.zeros(n, kp)
+    xp[:, :k], wp[:, :k] = x9, w
+    tile = ops.linear_fwd(xp.to(DEV), wp.to(DEV), b.to(DEV))[:m]
+    assert rel_err(ops.linear_fwd(xd, wd, b.to(DEV)), tile.cpu()) < 2e-6
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("m,n,k", [(333, 7, 36), (1000, 128, 128), (4096, 64, 200), (50, 130, 64)])
 def test_linear_wgrad(dtype, m, n, k):
@@ -606,6 +631,41 @@ def test_conv_fwd_affine_inference_form(dtype, cfg, residual):
     out = ops.conv2d_fwd_affine(nhwc(x).to(dtype).to(DEV), wq.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV), s, p, shift.to(DEV),
                                 None if add is None else nhwc(add).to(dtype).to(DEV), True)
     assert rel_err(nchw(out), ref) < tol(dtype)
+
+
+SPLITK = [  # rollout-frame shapes (one image through layer2-4): few 64x64 output tiles, long reductions
+    (1, 7, 512, 512, 3, 1, 1), (1, 14, 256, 256, 3, 1, 1), (1, 28, 128, 128, 3, 1, 1), (1, 7, 2048, 512, 1, 1, 0), (1, 14, 1024, 2048, 1, 2, 0),
+    (1, 14, 512, 512, 3, 2, 1), (3, 7, 512, 512, 3, 1, 1), (2, 9, 320, 72, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", SPLITK)
+def test_conv_fwd_affine_split_k(dtype, cfg):
+    """The inference forward splits K over grid.y when a launch has few output tiles (rpe_conv2d_fwd_affine_ws): the planned
+    split must be taken, match the conv -> BN(eval) -> add -> ReLU reference and the unsplit launch, and repeat bitwise."""
+    import ctypes
+    from rgb_proprioceptive_pose_estimator_amd._lib import lib
+    b, h, ci, co, k, s, p = cfg
+    x, w = _conv_inputs(cfg, dtype)
+    g = torch.Generator().manual_seed(7)
+    shift = torch.randn(co, generator=g) * 0.3
+    wq = q(w, dtype)
+    ref = F.conv2d(x, wq, None, s, p) + shift[None, :, None, None]
+    add = q(torch.randn(ref.shape, generator=g), dtype)
+    ref = F.relu(ref + add)
+    xd, wd, ad = nhwc(x).to(dtype).to(DEV), wq.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV), nhwc(add).to(dtype).to(DEV)
+    d = ops.conv_desc(xd.shape, co, k, s, p)
+    assert lib.rpe_conv2d_fwd_affine_workspace_bytes(ctypes.byref(d), ops.dtype_code(xd)) > 0, "this shape is expected to split"
+    out = ops.conv2d_fwd_affine(xd, wd, s, p, shift.to(DEV), ad, True)
+    assert "nt_split_epilogue_kernel" in ops.last_kernel_name()
+    assert rel_err(nchw(out), ref) < tol(dtype)
+    plain = ops.conv2d_fwd_affine(xd, wd, s, p, shift.to(DEV), ad, True, split_k=False)
+    assert "nt_split_epilogue_kernel" not in ops.last_kernel_name()
+    assert rel_err(out, plain) < (2e-6 if dtype == torch.float32 else tol(dtype))
+    for _ in range(3):
+        assert torch.equal(ops.conv2d_fwd_affine(xd, wd, s, p, shift.to(DEV), ad, True), out)
+    nob = ops.conv2d_fwd_affine(xd, wd, s, p, shift.to(DEV), None, False)      # bias only
+    assert rel_err(nchw(nob), F.conv2d(x, wq, None, s, p) + shift[None, :, None, None]) < tol(dtype)
 
 
 def test_bn_reduce_handoff_under_load():

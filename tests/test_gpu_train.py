@@ -1,6 +1,7 @@
 """End-to-end GPU test of the training loop and the script entry points (tiny synthetic episodes)."""
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -68,6 +69,19 @@ def test_train_script_two_arm_smoke():
                         "--n_train_episodes_per_epoch", "2", "--n_val_episodes_per_epoch", "2", "--n_epochs", "1", "--env", "TwoArmHandoff",
                         "--distance_metric", "combined", "--no_save"])
     assert best < float("inf") and model.requires_sequence
+
+
+@pytest.mark.parametrize("kind", ["tdo", "no"])
+def test_rollout_script_graph_replay_matches_eager(kind, tmp_path):
+    """scripts/rollout.py replays one captured hipGraph per frame (split-K convs, few-row Linear kernels, LSTM state carried in
+    place): the dumped model outputs must equal those of the eager frame loop, episode resets included."""
+    from rgb_proprioceptive_pose_estimator_amd.scripts.rollout import main
+    common = ["--model", kind, "--horizon", "3", "--latent_dim", "32", "--hidden_dim", "32", "--n_episodes", "2", "--env", "Lift", "--obj_name", "cube"]
+    main(common + ["--out", str(tmp_path / "g.npy")])
+    main(common + ["--out", str(tmp_path / "e.npy"), "--no_graph"])
+    g, e = np.load(tmp_path / "g.npy"), np.load(tmp_path / "e.npy")
+    assert g.shape == (6, 7) and np.isfinite(g).all()
+    np.testing.assert_allclose(g, e, rtol=1e-5, atol=1e-6)
 
 
 def test_uint8_frames_match_host_transform():
