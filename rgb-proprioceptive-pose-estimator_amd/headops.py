@@ -47,6 +47,15 @@ class LinearOp:
     def fwd(self, x, save=True, out=None, addend=None):
         """x: [M, K] view (row stride multiple of 4, columns K..pad4(K) zero)."""
         n, k = self.weight.shape
+        if x.shape[0] <= ops.LINEAR_ROWS_MAX and self.weight.data.is_contiguous():
+            # few rows (a rollout frame): the per-column kernel reads the weight in place, whatever its row alignment -- no padded
+            # copy (15 MB per frame for the first fusion layer); an inference output's padding columns are never read
+            if out is None:
+                out = new_rows(x.shape[0], n, x.device, zero=save)
+            ops.linear_fwd(x, self.weight.data, None if self.bias is None else self.bias.data, relu=self.relu, addend=addend, out=out, n=n, k=k)
+            if save:
+                self.x, self.y = x, out
+            return out
         w = self._w()
         if out is None:
             out = new_rows(x.shape[0], n, x.device)

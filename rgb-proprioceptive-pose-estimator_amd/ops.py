@@ -6,6 +6,7 @@ current HIP stream to librpe_hip.so, and returns the output tensors.  Activation
 conv trunk are NHWC tensors ([B, H, W, C], contiguous) in fp32 or bf16.
 """
 import ctypes
+import os
 
 import torch
 
@@ -332,6 +333,11 @@ def avgpool_bwd(dout, x_shape, dtype):
     dx = torch.empty(tuple(x_shape), dtype=dtype, device=dout.device)
     lib.rpe_avgpool_bwd(dtype_code(dtype), _p(dout), _p(dx), b, h * w, c, _stream())
     return dx
+
+
+# rows up to which rpe_linear_fwd (fp32) runs one workgroup per output column and accepts any row stride / alignment
+# (csrc/conv_api.hip: linear_rows_kernel); 0 when switched off
+LINEAR_ROWS_MAX = 0 if os.environ.get("RPE_NO_LINEAR_ROWS") else 8
 
 
 def linear_fwd(x, w, bias=None, relu=False, addend=None, out=None, n=None, k=None):

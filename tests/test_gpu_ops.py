@@ -386,6 +386,9 @@ def test_maxpool_avgpool(dtype):
     x2 = q(torch.randn(3, 2048, 7, 7, generator=g), dtype)
     p = ops.avgpool_fwd(nhwc(x2).to(dtype).to(DEV))
     assert rel_err(p, x2.mean((2, 3))) < 1e-5
+    for bb, hw in ((1, 7), (40, 7), (2, 3)):    # one frame (8 lanes per channel chunk) / many images / tiny maps (one lane per chunk)
+        x3 = q(torch.randn(bb, 2048, hw, hw, generator=g), dtype)
+        assert rel_err(ops.avgpool_fwd(nhwc(x3).to(dtype).to(DEV)), x3.mean((2, 3))) < 1e-5
     dp = torch.randn(3, 2048, generator=g)
     dx2 = ops.avgpool_bwd(dp.to(DEV), (3, 7, 7, 2048), dtype)
     assert rel_err(nchw(dx2), (dp / 49)[:, :, None, None].expand(3, 2048, 7, 7)) < tol(dtype)
