@@ -248,6 +248,53 @@ def run_r101():
     print("no_r101 loss", rec["loss_s1"])
 
 
+# BASELINE.json configs[2]: the two-arm TD model on sequences of FOUR frames (lead dims (S, N) = (4, 2); the toy cases above run
+# S = 2).  Pristine eval output, a 4-frame rollout with the LSTM state carried between single-frame calls, step-1 outputs / loss /
+# val metrics / gradient digests.
+TD_S4 = (dict(latent_dim=64, hidden=32, use_depth=False), (4, 2), 51, 501)
+
+
+def run_td_s4():
+    cfg, lead, wseed, dseed = TD_S4
+    torch.manual_seed(0)
+    model = TemporallyDependentStateEstimator(cfg["hidden"], cfg["hidden"], 50, cfg["latent_dim"], 4, 0.1, False, (9,), False, False)
+    sd = po.make_state("td", cfg, wseed)
+    ref_keys = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    assert ref_keys == [(k, tuple(s)) for k, s in po.model_keys("td", cfg) if not k.startswith("~")], "state_dict key table mismatch (TD, S=4)"
+    load_values(model, "td", sd)
+    rec = {"keys": np.array([k for k, _ in ref_keys])}
+    model.eval()
+    model.reset_initial_state(lead[-1])
+    with torch.no_grad():
+        b = po.synth_batch(lead, dseed + 9)
+        blank = torch.empty(*b["img"].shape)
+        out = model(b["img"], blank, b["x0bar"])
+        rec["pre_eval_out0"], rec["pre_eval_out1"] = out[0].numpy(), out[1].numpy()
+        model.rollout = True
+        model.reset_initial_state(lead[-1])
+        frames = [model(b["img"][t:t + 1], blank[t:t + 1], b["x0bar"][t:t + 1])[-1] for t in range(lead[0])]
+        rec["pre_rollout_out"] = torch.cat(frames, 0).numpy()
+        model.rollout = False
+    model.train()
+    model.reset_initial_state(lead[-1])
+    b = po.synth_batch(lead, dseed + 1)
+    out = model(b["img"], torch.empty(*b["img"].shape), b["x0bar"])
+    crit = PoseDistanceLoss(**LOSS_CFG)
+    loss = crit(out[0], b["x0"]) + crit(out[1], b["x1"])
+    pe, oe = PoseDistanceLoss(mode="val")(out[1], b["x1"])
+    loss.backward()
+    rec["out0_s1"], rec["out1_s1"], rec["loss_s1"] = out[0].detach().numpy(), out[1].detach().numpy(), np.array(loss.item())
+    rec["pos_err_s1"], rec["ori_err_s1"] = np.array(float(pe)), np.array(float(oe))
+    gn, gd = [], []
+    for name, p in model.named_parameters():
+        if p.grad is not None:
+            gn.append(name)
+            gd.append(digest(p.grad))
+    rec["grad_keys_s1"], rec["grad_digest_s1"] = np.array(gn), np.stack(gd)
+    np.savez_compressed(os.path.join(OUT, "model_td_s4.npz"), **rec)
+    print("td_s4 loss", rec["loss_s1"], "pos/ori err", rec["pos_err_s1"], rec["ori_err_s1"])
+
+
 def run_loss():
     g = torch.Generator().manual_seed(7)
     rec = {}
@@ -278,7 +325,7 @@ def run_loss():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["loss"] + list(CASES) + ["c1", "r101"]
+    which = sys.argv[1:] or ["loss"] + list(CASES) + ["c1", "r101", "td_s4"]
     for w in which:
         if w == "loss":
             run_loss()
@@ -286,5 +333,7 @@ if __name__ == "__main__":
             run_c1()
         elif w == "r101":
             run_r101()
+        elif w == "td_s4":
+            run_td_s4()
         else:
             run_case(w)

@@ -196,3 +196,41 @@ def test_resnet101_trunk_matches_reference(golden_dir):
     assert np.median(cos) > 0.95 and min(cos) > 0.5, (np.median(cos), min(cos))
     with pytest.raises(NotImplementedError):
         M.NaiveObjectStateEstimator("cube", [32], 18, 64, False, (9,), False, False, False)
+
+
+@pytest.mark.parametrize("dtype,bar", [(torch.float32, 1e-4), (torch.bfloat16, 5e-2), (torch.float16, 1.5e-2)], ids=["f32", "bf16", "f16"])
+def test_td_four_frame_sequences_match_reference(dtype, bar, golden_dir):
+    """BASELINE configs[2]: TemporallyDependentStateEstimator on sequences of FOUR frames (lead dims (4, 2)) against the reference's
+    vectors: pristine eval outputs, a 4-frame rollout with the LSTM state carried on the device, step-1 outputs / loss / val metrics."""
+    from _helpers_cases import TD_S4
+    gold = np.load(os.path.join(golden_dir, "model_td_s4.npz"))
+    cfg, lead, wseed, dseed = TD_S4
+    sd = po.make_state("td", cfg, wseed)
+    model = M.TemporallyDependentStateEstimator(cfg["hidden"], cfg["hidden"], 50, cfg["latent_dim"], 4, 0.1, False, (9,), False, False,
+                                                compute_dtype=dtype)
+    assert model.sequence_length == 4 and list(model.state_dict().keys()) == list(gold["keys"])
+    load_values(model, "td", sd)
+    model.cuda().eval()
+    model.reset_initial_state(lead[-1])
+    ebar = 2e-4 if dtype == torch.float32 else bar
+    b9 = to_dev(po.synth_batch(lead, dseed + 9))
+    with torch.no_grad():
+        pre, post = model(b9["img"], None, b9["x0bar"])
+        assert rel(pre, gold["pre_eval_out0"]) < ebar and rel(post, gold["pre_eval_out1"]) < ebar
+        model.rollout = True
+        model.reset_initial_state(lead[-1])
+        frames = [model(b9["img"][t:t + 1], None, b9["x0bar"][t:t + 1])[-1].clone() for t in range(lead[0])]
+        assert rel(torch.cat(frames, 0), gold["pre_rollout_out"]) < ebar
+        model.rollout = False
+    model.train()
+    model.reset_initial_state(lead[-1])
+    crit = M.PoseDistanceLoss(distance_metric="combined", scale_factor=1.0, alpha=0.5, mode="pose")
+    val = M.PoseDistanceLoss(mode="val")
+    outs, loss, pe, oe = run_step(model, "td", to_dev(po.synth_batch(lead, dseed + 1)), crit, val)
+    assert rel(outs[0], gold["out0_s1"]) < bar and rel(outs[1], gold["out1_s1"]) < bar
+    np.testing.assert_allclose(loss.item(), gold["loss_s1"], rtol=bar)
+    np.testing.assert_allclose(float(pe), gold["pos_err_s1"], rtol=max(bar, 1e-4))
+    if dtype != torch.float16:      # (fp16 gradients carry the loss scale until the optimizer unscales and tests them)
+        for name, p in model.named_parameters():
+            if p.grad is not None:
+                assert torch.isfinite(p.grad).all(), name
