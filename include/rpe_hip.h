@@ -236,6 +236,17 @@ int rpe_aux_head_bwd(int dtype, const float* dout, long ld_dout, const void* a1,
 /* replaces: depth_nets[i] = AvgPool2d(2) x2 -> InstanceNorm2d(1, affine) -> Flatten (models/naive.py:233-240) */
 int rpe_depth_head_fwd(const float* depth, const float* w, const float* b, float* feat, float* xhat, int B, int H, int W, void* stream);
 int rpe_depth_head_bwd(const float* d_feat, const float* xhat, long n, float* dw, float* db, void* stream);
+/* The same two heads on any hooked feature map x[B][H][W][C] (feature_layer_nums other than (9,): conv1's raw output, the layer1..3
+ * outputs; models/naive.py:196-240): C = 64..1024 in whole 16-byte chunks (a power of two of them).  The backward writes a DENSE
+ * gradient d_x (zeroed inside: pixels outside the 2x2 windows and the windows' losers stay zero); the depth head pools
+ * `pools` = int(log4(224^2 / (H W / 4))) times, flooring odd sizes as AvgPool2d does. */
+int rpe_aux_head_fwd_c(int dtype, const void* x, int C, const float* w, const float* bias, const float* depth_feat, float* out, long ld_out,
+                       float* raw, unsigned char* idx, int B, int H, int W, void* stream);
+int rpe_aux_head_bwd_c(int dtype, const float* dout, long ld_dout, const void* x, int C, const float* w, const float* depth_feat, const float* raw,
+                       const unsigned char* idx, void* d_x, float* dw, float* dbias, float* d_depth_feat, int B, int H, int W, void* stream);
+int rpe_depth_head_fwd_pools(const float* depth, const float* w, const float* b, float* feat, float* xhat, int B, int H, int W, int pools, void* stream);
+/* dst += src over n elements of the compute dtype (n a multiple of the 16-byte chunk) */
+int rpe_tensor_add(int dtype, void* dst, const void* src, long n, void* stream);
 
 /* replaces: nn.Linear (+ F.relu) of the proprio-fusion MLP (models/naive.py:343-345), the
  * ResNet fc (util/model_utils.py:141), the LSTM input/recurrent GEMMs and the fc heads
@@ -364,6 +375,13 @@ int rpe_resnet50_set_aux_grad(rpe_resnet50_t* e, const float* aux_dout, long aux
                               const float* aux_w);
 /* debugging / parity: device pointer, rows and channels of a named intermediate (e.g. "layer1.0.y1") */
 int rpe_resnet50_tensor(const rpe_resnet50_t* e, const char* name, const void** ptr, long* rows, int* channels);
+/* Hooks other than bn1.  set_hook_grad: a dense gradient (compute dtype, the tensor's own NHWC shape) of conv1's raw output (layer 0:
+ * `conv1.y`) or of the output of layer1..3 (`layerN.<last>.conv3.a`, see rpe_resnet50_tensor) that the NEXT backward adds where that
+ * tensor's gradient is formed (layer outputs: into the shortcut gradient of the following stage-entry block; conv1: behind BN1's
+ * backward, which then runs unfused); cleared by that backward; the tensor must stay alive until it has been enqueued.
+ * set_stem_raw: the inference forward keeps conv1's raw output (conv and BN as two launches instead of the folded one). */
+int rpe_resnet50_set_hook_grad(rpe_resnet50_t* e, int layer, const void* dense_grad);
+int rpe_resnet50_set_stem_raw(rpe_resnet50_t* e, int on);
 
 #ifdef __cplusplus
 }

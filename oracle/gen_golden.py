@@ -295,6 +295,46 @@ def run_td_s4():
     print("td_s4 loss", rec["loss_s1"], "pos/ori err", rec["pos_err_s1"], rec["ori_err_s1"])
 
 
+# feature_layer_nums other than the scripts' (9,) (models/naive.py:196-240): every hook the reference can run at 224x224 -- conv1's raw
+# output, bn1, layer1..3 (given out of order: aux_nets follow the order the hooks FIRE in) -- with the depth heads on; and None (no
+# early features).  Key table, pristine eval output, step-1 outputs / loss / gradient digests + the head gradients whole.
+HOOKS = (dict(latent_dim=64, hidden=[32], use_depth=True, no_proprioception=False, hooks=(3, 0, 9, 2, 1)), (2,), 61, 601)
+NOHOOK = (dict(latent_dim=64, hidden=[32], use_depth=False, no_proprioception=False, hooks=None), (2,), 62, 602)
+
+
+def run_hooks(tag, case):
+    cfg, lead, wseed, dseed = case
+    torch.manual_seed(0)
+    model = NaiveObjectStateEstimator("cube", list(cfg["hidden"]), 50, cfg["latent_dim"], False, cfg["hooks"], cfg["use_depth"], False, False)
+    sd = po.make_state("no", cfg, wseed)
+    ref_keys = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    assert ref_keys == [(k, tuple(s)) for k, s in po.model_keys("no", cfg)], "state_dict key table mismatch (%s)" % tag
+    load_values(model, "no", sd)
+    rec = {"keys": np.array([k for k, _ in ref_keys])}
+    model.eval()
+    with torch.no_grad():
+        b = po.synth_batch(lead, dseed + 9, with_depth=cfg["use_depth"])
+        depth = b["depth"] if b["depth"] is not None else torch.empty(*b["img"].shape)
+        rec["pre_eval_out0"] = model(b["img"], depth, b["x0bar"]).numpy()
+    model.train()
+    b = po.synth_batch(lead, dseed + 1, with_depth=cfg["use_depth"])
+    depth = b["depth"] if b["depth"] is not None else torch.empty(*b["img"].shape)
+    out = model(b["img"], depth, b["x0bar"])
+    loss = PoseDistanceLoss(**LOSS_CFG)(out, b["obj"])
+    loss.backward()
+    rec["out0_s1"], rec["loss_s1"] = out.detach().numpy(), np.array(loss.item())
+    gn, gd = [], []
+    for name, p in model.named_parameters():
+        if p.grad is not None:
+            gn.append(name)
+            gd.append(digest(p.grad))
+            if name.startswith("aux_nets") or name.startswith("depth_nets") or name.endswith("conv1.weight") and "layer" not in name:
+                rec["grad::" + name] = p.grad.detach().numpy().copy()
+    rec["grad_keys_s1"], rec["grad_digest_s1"] = np.array(gn), np.stack(gd)
+    np.savez_compressed(os.path.join(OUT, "model_no_%s.npz" % tag), **rec)
+    print("no_%s loss" % tag, rec["loss_s1"])
+
+
 def run_loss():
     g = torch.Generator().manual_seed(7)
     rec = {}
@@ -325,7 +365,7 @@ def run_loss():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["loss"] + list(CASES) + ["c1", "r101", "td_s4"]
+    which = sys.argv[1:] or ["loss"] + list(CASES) + ["c1", "r101", "td_s4", "hooks", "nohook"]
     for w in which:
         if w == "loss":
             run_loss()
@@ -335,5 +375,9 @@ if __name__ == "__main__":
             run_r101()
         elif w == "td_s4":
             run_td_s4()
+        elif w == "hooks":
+            run_hooks("hooks", HOOKS)
+        elif w == "nohook":
+            run_hooks("nohook", NOHOOK)
         else:
             run_case(w)

@@ -94,37 +94,61 @@ def _lstm_keys(prefix, inp, hid):
     ]
 
 
+# Hooked feature maps (models/naive.py:196-240): layer number -> (channels, spatial size at 224x224), in the order the forward
+# hooks fire (= the order of aux_nets / depth_nets, whatever the order of the feature_layer_nums tuple).  Layer 4 is left out: the
+# reference sizes its fc input with H*W//4 = 12 columns for the 7x7 map while MaxPool2d(2) yields 3x3 = 9 (its forward raises).
+HOOK_ORDER = (0, 9, 1, 2, 3)
+HOOK_SHAPE = {0: (64, 112), 9: (64, 112), 1: (256, 56), 2: (512, 28), 3: (1024, 14)}
+
+
+def hooks_of(cfg):
+    """cfg['hooks']: the feature_layer_nums tuple (default (9,), None = no early features) -> layers in firing order"""
+    h = cfg.get("hooks", (9,))
+    if h is None:
+        return []
+    h = list(h)
+    assert len(set(h)) == len(h) and all(x in HOOK_SHAPE for x in h), h
+    return [x for x in HOOK_ORDER if x in h]
+
+
+def hook_pools(layer):
+    """number of AvgPool2d(2) steps of the depth head (models/naive.py:235-236)"""
+    c, hw = HOOK_SHAPE[layer]
+    return int(math.log(224 ** 2 / (hw * hw // 4), 4))
+
+
+def aux_dim(cfg):
+    return sum(HOOK_SHAPE[h][1] ** 2 // 4 for h in hooks_of(cfg))
+
+
 def model_keys(kind, cfg):
     """Ordered (key, shape) list of the reference model's state_dict.
 
     cfg: dict(latent_dim, hidden (list for n/no, int otherwise), proprio_hidden,
-              no_proprioception).  Aux dim is fixed to 3136 (bn1 hook at 224x224).
+              no_proprioception).  hooks: the feature_layer_nums tuple (default (9,): aux dim 3136).
     For kind 'td' the aux/depth heads are NOT in the state_dict (plain Python
     lists, models/time_sensitive.py:102-115); they are listed under the
     pseudo-prefix '~' so callers can still carry their values.
     """
     L = cfg["latent_dim"]
-    aux = 3136
+    aux = aux_dim(cfg)
+    hooks = hooks_of(cfg)
     keys = []
     if kind in ("n", "td"):
         fpre = "feature_net."
     else:
         fpre = "feature_net.module."
     keys += [(fpre + k, s) for k, s in resnet_keys(L, cfg.get("depth", 50))]
-    if kind in ("no", "tdo", "tdo_v2"):
-        keys += [
-            ("aux_nets.0.module.0.weight", (1, 64, 1, 1)),
-            ("aux_nets.0.module.0.bias", (1,)),
-            ("depth_nets.0.module.2.weight", (1,)),
-            ("depth_nets.0.module.2.bias", (1,)),
-        ]
+    if kind in ("no", "tdo", "tdo_v2"):   # nn.ModuleList(aux_nets) is registered before nn.ModuleList(depth_nets)
+        for i, h in enumerate(hooks):
+            keys += [("aux_nets.%d.module.0.weight" % i, (1, HOOK_SHAPE[h][0], 1, 1)), ("aux_nets.%d.module.0.bias" % i, (1,))]
+        for i, h in enumerate(hooks):
+            keys += [("depth_nets.%d.module.%d.weight" % (i, hook_pools(h)), (1,)), ("depth_nets.%d.module.%d.bias" % (i, hook_pools(h)), (1,))]
     if kind == "td":
-        keys += [
-            ("~aux_nets.0.0.weight", (1, 64, 1, 1)),
-            ("~aux_nets.0.0.bias", (1,)),
-            ("~depth_nets.0.2.weight", (1,)),
-            ("~depth_nets.0.2.bias", (1,)),
-        ]
+        for i, h in enumerate(hooks):
+            keys += [("~aux_nets.%d.0.weight" % i, (1, HOOK_SHAPE[h][0], 1, 1)), ("~aux_nets.%d.0.bias" % i, (1,))]
+        for i, h in enumerate(hooks):
+            keys += [("~depth_nets.%d.%d.weight" % (i, hook_pools(h)), (1,)), ("~depth_nets.%d.%d.bias" % (i, hook_pools(h)), (1,))]
     if kind == "n":
         pre = [L] + list(cfg["hidden"]) + [7]
         for i in range(len(pre) - 1):
@@ -286,10 +310,12 @@ def _bn(sd, name, x, train):
 
 
 def resnet50_forward(sd, pre, x, train, depth=50):
-    """Returns (latent features (B, L), early feature relu(bn1(conv1 x)) (B,64,H/2,W/2))."""
+    """Returns (latent features (B, L), hooked maps {0: conv1 x, 9: relu(bn1(conv1 x)) (the in-place ReLU reaches the hooked
+    tensor), 1..4: layer outputs})."""
     x = x if EMULATE is None else x.to(EMULATE).to(x.dtype)
     y = _q(F.conv2d(x, _qw(sd[pre + "conv1.weight"]), None, 2, 3))
     early = _q(F.relu(_bn(sd, pre + "bn1", y, train)))
+    maps = {0: y, 9: early}
     y = F.max_pool2d(early, 3, 2, 1)
     for li, (planes, nblk, stride) in enumerate(stages(depth), start=1):
         for b in range(nblk):
@@ -303,8 +329,9 @@ def resnet50_forward(sd, pre, x, train, depth=50):
             else:
                 idn = y
             y = _q(F.relu(o + idn))
+        maps[li] = y
     y = F.adaptive_avg_pool2d(y, 1).flatten(1)
-    return F.linear(y, sd[pre + "fc.weight"], sd[pre + "fc.bias"]), early
+    return F.linear(y, sd[pre + "fc.weight"], sd[pre + "fc.bias"]), maps
 
 
 def aux_head(early, w, b):
@@ -312,9 +339,11 @@ def aux_head(early, w, b):
     return F.max_pool2d(F.conv2d(early, w, b), 2).flatten(1)
 
 
-def depth_head(depth, w, b):
-    """AvgPool2d(2) x2 -> InstanceNorm2d(1, affine) -> Flatten (models/naive.py:233-240)."""
-    d = F.avg_pool2d(F.avg_pool2d(depth, 2), 2)
+def depth_head(depth, w, b, pools=2):
+    """AvgPool2d(2) x pools -> InstanceNorm2d(1, affine) -> Flatten (models/naive.py:233-240)."""
+    d = depth
+    for _ in range(pools):
+        d = F.avg_pool2d(d, 2)
     return F.instance_norm(d, None, None, w, b, True, 0.1, 1e-5).flatten(1)
 
 
@@ -338,19 +367,23 @@ def lstm_forward(x, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None):
 def _features(kind, cfg, sd, img, depth, train):
     """ResNet + aux(+depth) concat shared by no/td/tdo/tdo_v2. img (B,3,H,W)."""
     fpre = "feature_net." if kind in ("n", "td") else "feature_net.module."
-    feat, early = resnet50_forward(sd, fpre, img, train, cfg.get("depth", 50))
+    feat, maps = resnet50_forward(sd, fpre, img, train, cfg.get("depth", 50))
     if kind == "n":
         return feat
-    if kind == "td":
-        aw, ab = sd["~aux_nets.0.0.weight"], sd["~aux_nets.0.0.bias"]
-        dw, db = sd["~depth_nets.0.2.weight"], sd["~depth_nets.0.2.bias"]
-    else:
-        aw, ab = sd["aux_nets.0.module.0.weight"], sd["aux_nets.0.module.0.bias"]
-        dw, db = sd["depth_nets.0.module.2.weight"], sd["depth_nets.0.module.2.bias"]
-    a = aux_head(early, aw, ab)
-    if cfg.get("use_depth"):
-        a = a * depth_head(depth, dw, db)
-    return torch.cat((feat, a), dim=-1)
+    parts = [feat]
+    for i, h in enumerate(hooks_of(cfg)):
+        k = hook_pools(h)
+        if kind == "td":
+            aw, ab = sd["~aux_nets.%d.0.weight" % i], sd["~aux_nets.%d.0.bias" % i]
+            dw, db = sd["~depth_nets.%d.%d.weight" % (i, k)], sd["~depth_nets.%d.%d.bias" % (i, k)]
+        else:
+            aw, ab = sd["aux_nets.%d.module.0.weight" % i], sd["aux_nets.%d.module.0.bias" % i]
+            dw, db = sd["depth_nets.%d.module.%d.weight" % (i, k)], sd["depth_nets.%d.module.%d.bias" % (i, k)]
+        a = aux_head(maps[h], aw, ab)
+        if cfg.get("use_depth"):
+            a = a * depth_head(depth, dw, db, k)
+        parts.append(a)
+    return torch.cat(parts, dim=-1)
 
 
 def model_forward(kind, cfg, sd, img, depth, x0bar, train=True, state=None):

@@ -127,6 +127,12 @@ _SPEC = {
     "rpe_resnet50_profile_kernels": (L, [P, P, L]),
     "rpe_last_kernel_name": (c_char_p, []),
     "rpe_resnet50_tensor": (I, [P, c_char_p, POINTER(c_void_p), POINTER(c_long), POINTER(c_int)]),
+    "rpe_resnet50_set_hook_grad": (I, [P, I, P]),
+    "rpe_resnet50_set_stem_raw": (I, [P, I]),
+    "rpe_aux_head_fwd_c": (I, [I, P, I, P, P, P, P, L, P, P, I, I, I, P]),
+    "rpe_aux_head_bwd_c": (I, [I, P, L, P, I, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "rpe_depth_head_fwd_pools": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "rpe_tensor_add": (I, [I, P, P, L, P]),
 }
 # entry points whose int return value is data, not a status
 _NOT_STATUS = {"rpe_abi_version"}

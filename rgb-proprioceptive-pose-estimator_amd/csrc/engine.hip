@@ -108,6 +108,10 @@ struct rpe_resnet50 {
     // conv/fc weight gradients are accumulated with atomics: when the bound gradient tensors form one contiguous block
     // (they do in the flat arena) it is zeroed by ONE memset per backward instead of 54 (15 us each)
     rpe_pack_desc* pack_tab = nullptr;   // device table for the one-launch weight packing
+    // hooks other than bn1 (models/naive.py:196-211): dense gradients of conv1's raw output ([0]) and of the layer1..3 outputs
+    // ([1..3]) handed over by the host for the next backward; stem_raw: the inference forward keeps conv1's raw output too
+    const void* hook_grad[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool stem_raw = false;
     void* sk_ws = nullptr;               // split-K workspace of the inference forward (rpe_conv2d_fwd_affine_ws); 0 bytes when no layer splits
     long sk_ws_bytes = 0;
     rpe_pack_desc* pack_tab_fold = nullptr;  // ... with the BN scale folded into the forward copy (inference)
@@ -527,7 +531,7 @@ static int fold_for_eval(rpe_resnet50* e, void* stream) {
         if (!rm || !rv) return rpe_set_error(RPE_ERR_STATE, "resnet50_forward: eval mode needs running statistics");
         TRY(rpe_bn_eval_affine(c.d.out_c, e->params[c.p_g], e->params[c.p_b], rm, rv, 1e-5f, c.scale, c.shift, stream));
     }
-    TRY(rpe_pack_stem_weight(e->dtype, e->params[e->convs[0].p_w], e->convs[0].scale, e->convs[0].wf, stream));
+    TRY(rpe_pack_stem_weight(e->dtype, e->params[e->convs[0].p_w], e->stem_raw ? nullptr : e->convs[0].scale, e->convs[0].wf, stream));
     TRY(rpe_pack_conv_weights_multi(e->dtype, e->pack_tab_fold, (int)e->convs.size() - 1, e->pack_total, stream));
     e->pack_state = 2;
     return 0;
@@ -544,6 +548,14 @@ static int ensure_side(rpe_resnet50* e) {
             int least = 0, greatest = 0;
             HIPTRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
             const char* pr = getenv("RPE_SIDE_PRIO");
+            // experiment switch RPE_SIDE_CUS=n: the second stream may only use n of the 256 CUs (the first n mask bits: the driver
+            // deals them round-robin over XCDs and shader engines), leaving the rest to the data-gradient chain alone
+            const int side_cus = getenv("RPE_SIDE_CUS") ? atoi(getenv("RPE_SIDE_CUS")) : 0;
+            if (side_cus > 0 && side_cus < 256) {
+                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < side_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+                HIPTRY(hipExtStreamCreateWithCUMask(&e->side, 8, mask));
+            } else
             if (pr && pr[0] == 'l') HIPTRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, least));
             else if (pr && pr[0] == 'h') HIPTRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, greatest));
             else HIPTRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
@@ -602,6 +614,10 @@ static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residua
     e->pending_bytes = conv_in_bytes(e, c) + conv_out_bytes(e, c);
     if (!train) {
         // folded inference form (fold_for_eval): a = relu(conv(x, w*scale) + shift (+ residual)); y is not written
+        if (&c == &e->convs[0] && e->stem_raw) {   // a hook on conv1: its raw output is kept, BN (running statistics) applied separately
+            PROF(e, RPE_PROF_CONV_FWD, stream, rpe_stem_conv_fwd(e->dtype, x, c.wf, c.y, nullptr, e->B, e->H, e->W, stream));
+            PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_apply(e->dtype, c.y, nullptr, c.a, c.scale, c.shift, c.rows, c.d.out_c, relu, stream));
+        } else
         if (&c == &e->convs[0]) PROF(e, RPE_PROF_CONV_FWD, stream, rpe_stem_conv_fwd_affine(e->dtype, x, c.wf, c.a, c.shift, relu, e->B, e->H, e->W, stream));
         else if (e->sk_ws && !second_set)   // (one workspace: the main stream's launches only; the side stream runs the projection shortcuts)
             PROF(e, RPE_PROF_CONV_FWD, stream, rpe_conv2d_fwd_affine_ws(&c.d, e->dtype, x, c.wf, c.a, c.shift, residual, relu, e->sk_ws, e->sk_ws_bytes, stream));
@@ -902,6 +918,13 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
         // chain, joined in front of the block's last data gradient, which adds G[0] (own partial-sum / counter buffers).
         // Experiment switch RPE_CD_SIDE=1: measured level with the one-stream form (22.0 vs 21.7 ms/step) -- the two streams
         // share one HBM, moving bytes between them does not shorten the step.
+        // a hooked layer output (the input of a stage-entry block) carries one more gradient term: it joins the shortcut gradient
+        const void* hook_in = nullptr;
+        if (b.cd >= 0 && bi > 0) {
+            int layer = 0;
+            for (int j = 0; j <= bi; ++j) layer += e->blocks[j].cd >= 0;
+            if (layer >= 2 && layer <= 4) hook_in = e->hook_grad[layer - 1];
+        }
         static const bool cd_side_ok = getenv("RPE_CD_SIDE") != nullptr;
         const bool cd_on_side = b.cd >= 0 && cd_side_ok && e->overlap && e->side && bi != (int)e->blocks.size() - 1;
         hipEvent_t cd_done = nullptr;
@@ -926,7 +949,7 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
             }
             e->pending_flops = conv_flops(cd);
             e->pending_bytes = conv_in_bytes(e, cd) + conv_out_bytes(e, cd);
-            PROF(e, RPE_PROF_CONV_DGRAD, e->side, rpe_conv2d_dgrad(&cd.d, e->dtype, cd.dy, cd.wd, e->G[0], nullptr, e->side));
+            PROF(e, RPE_PROF_CONV_DGRAD, e->side, rpe_conv2d_dgrad(&cd.d, e->dtype, cd.dy, cd.wd, e->G[0], hook_in, e->side));
         }
         if (e->fold && c3.d.in_c <= 256 && e->train_mode) {   // layers 1-3 (layer4's tensors are small: the unfolded form is faster there)
             TRY(conv1x1_backward_folded(e, c3, gA, c2, stream));                                  // dz2 (dy3 exists on the side stream only)
@@ -951,7 +974,7 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
             } else {
                 TRY(bn_back(e, cd, gA, 0, cd.dy, nullptr, stream));          // no ReLU on the projection shortcut
                 TRY(wgrad(e, cd, x_in, cd.dy, stream));
-                PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&cd.d, e->dtype, cd.dy, cd.wd, e->G[0], nullptr, stream));
+                PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&cd.d, e->dtype, cd.dy, cd.wd, e->G[0], hook_in, stream));
             }
         }
         if (bi > 0) {
@@ -974,11 +997,12 @@ extern "C" int rpe_resnet50_backward_end(rpe_resnet50_t* e, int use_d_early, voi
     // stem: g0 = gradient wrt maxpool output
     ConvL& st = e->convs[0];
     static const bool unfused = getenv("RPE_STEM_UNFUSED") != nullptr;
-    if ((use_d_early && !e->aux_dout) || unfused) {
+    if ((use_d_early && !e->aux_dout) || unfused || e->hook_grad[0]) {
         // dense early-feature gradient supplied by the caller (rpe_resnet50_early_grad): pool backward, then BN backward
-        if (use_d_early && e->aux_dout) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward_end: RPE_STEM_UNFUSED needs the dense early gradient");
+        if (use_d_early && e->aux_dout) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward_end: the unfused stem backward (RPE_STEM_UNFUSED, a hook on conv1) needs the dense early gradient");
         PROF(e, RPE_PROF_OTHER, stream, rpe_maxpool3x3s2_bwd(e->dtype, g0, e->pool_idx, use_d_early ? e->early_grad : nullptr, g1, e->B, st.Ho, st.Wo, 64, stream));
         TRY(bn_back(e, st, g1, 1, g1, nullptr, stream));
+        if (e->hook_grad[0]) TRY(rpe_tensor_add(e->dtype, g1, e->hook_grad[0], st.rows * 64, stream));   // + the gradient of conv1's hooked raw output
     } else {
         const bool aux = use_d_early != 0;
         e->pending_bytes = conv_out_bytes(e, st) * 3.0 + 2.0 * (double)e->B * (st.Ho / 2) * (st.Wo / 2) * 64 * (e->esz + 1);   // y twice -> dy; pooled gradient + index twice
@@ -988,6 +1012,7 @@ extern "C" int rpe_resnet50_backward_end(rpe_resnet50_t* e, int use_d_early, voi
                                                       e->bwd_part, e->bwd_part_floats, e->c1c2, e->dpart, stream));
     }
     e->aux_dout = nullptr;
+    for (int i = 0; i < 4; ++i) e->hook_grad[i] = nullptr;
     if (hipError_t he = hipMemsetAsync(e->stem_dw, 0, 64 * 256 * 4, s)) return rpe_set_error_hip(he, __FILE__, __LINE__);   // (the 8th kernel row stays zero)
     if (e->main_slab) PROF(e, RPE_PROF_CONV_WGRAD, stream, rpe_stem_conv_wgrad_det(e->dtype, e->x4, g1, e->stem_dw, e->B, e->H, e->W, e->main_slab, e->main_slab_bytes, stream));
     else PROF(e, RPE_PROF_CONV_WGRAD, stream, rpe_stem_conv_wgrad(e->dtype, e->x4, g1, e->stem_dw, e->B, e->H, e->W, stream));
@@ -1002,6 +1027,18 @@ extern "C" int rpe_resnet50_set_aux_grad(rpe_resnet50_t* e, const float* aux_dou
     if (!e) return rpe_set_error(RPE_ERR_STATE, "resnet50_set_aux_grad: null engine");
     if (aux_dout && (!aux_idx || !aux_w || aux_ld <= 0)) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_set_aux_grad: winner indices, weight and row pitch are required");
     e->aux_dout = aux_dout; e->aux_ld = aux_ld; e->aux_df = aux_depth_feat; e->aux_idx = aux_idx; e->aux_w = aux_w;
+    return 0;
+}
+
+extern "C" int rpe_resnet50_set_hook_grad(rpe_resnet50_t* e, int layer, const void* dense_grad) {
+    if (!e || layer < 0 || layer > 3) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_set_hook_grad: layer 0 (conv1's raw output) or 1..3 (layer outputs)");
+    e->hook_grad[layer] = dense_grad;
+    return 0;
+}
+
+extern "C" int rpe_resnet50_set_stem_raw(rpe_resnet50_t* e, int on) {
+    if (!e) return rpe_set_error(RPE_ERR_STATE, "resnet50_set_stem_raw: null engine");
+    if (e->stem_raw != (on != 0)) { e->stem_raw = on != 0; if (e->pack_state == 2) e->pack_state = 0; }   // the inference copy of conv1's weight changes
     return 0;
 }
 

@@ -157,6 +157,150 @@ __global__ __launch_bounds__(256) void depth_fwd_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same two heads on ANY hooked feature map (models/naive.py:196-240: feature_layer_nums other than the scripts' (9,)):
+// conv1's raw output, bn1, layer1..layer3 outputs -- C = 64..1024 channels, H x W = 112^2..14^2.  Not a hot path (no reference
+// script hooks anything but bn1): one lane group per output pixel walking the channel chunks, a DENSE feature gradient.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void auxc_fwd_kernel(const T* __restrict__ x, int C, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      const float* __restrict__ depth_feat, float* __restrict__ out, long ld_out,
+                                                      float* __restrict__ raw, unsigned char* __restrict__ idx, int B, int H, int W) {
+    constexpr int CE = Elem<T>::kChunk;
+    const int cpp = C / CE, LPP = cpp < 64 ? cpp : 64;     // chunks per pixel; lanes per output pixel (a power of two)
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)B * Ho * Wo;
+    const int sub = threadIdx.x % LPP, groups = blockDim.x / LPP;
+    const float bv = bias[0];
+    for (long o = (long)blockIdx.x * groups + threadIdx.x / LPP; o < total; o += (long)gridDim.x * groups) {
+        long t = o;
+        const int ow = (int)(t % Wo); t /= Wo;
+        const int oh = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        float best = -INFINITY;
+        int bi = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int ih = oh * 2 + (k >> 1), iw = ow * 2 + (k & 1);
+            const T* px = x + (((long)b * H + ih) * W + iw) * C;
+            float d = 0.f;
+            for (int ch = sub; ch < cpp; ch += LPP) {
+                float v[CE];
+                chunk_to_f<T>(*(const u32x4*)(px + ch * CE), v);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) d += v[e] * w[ch * CE + e];
+            }
+            for (int s = 1; s < LPP; s <<= 1) d += __shfl_xor(d, s);
+            d += bv;
+            if (d > best || d != d) { best = d; bi = k; }
+        }
+        if (sub == 0) {
+            const long pos = (long)oh * Wo + ow;
+            const float df = depth_feat ? depth_feat[(long)b * Ho * Wo + pos] : 1.f;
+            out[(long)b * ld_out + pos] = best * df;
+            raw[(long)b * Ho * Wo + pos] = best;
+            idx[(long)b * Ho * Wo + pos] = (unsigned char)bi;
+        }
+    }
+}
+
+// d_x must be zero on entry (pixels outside the 2x2 windows and the three losers of every window keep a zero gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void auxc_bwd_kernel(const float* __restrict__ dout, long ld_dout, const T* __restrict__ x, int C,
+                                                      const float* __restrict__ w, const float* __restrict__ depth_feat,
+                                                      const float* __restrict__ raw, const unsigned char* __restrict__ idx,
+                                                      T* __restrict__ d_x, float* __restrict__ dw, float* __restrict__ dbias,
+                                                      float* __restrict__ d_depth_feat, int B, int H, int W) {
+    constexpr int CE = Elem<T>::kChunk;
+    extern __shared__ float sh_dwc[];   // [C] + 1
+    for (int i = threadIdx.x; i <= C; i += blockDim.x) sh_dwc[i] = 0.f;
+    __syncthreads();
+    const int cpp = C / CE, LPP = cpp < 64 ? cpp : 64;
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)B * Ho * Wo;
+    const int sub = threadIdx.x % LPP, groups = blockDim.x / LPP;
+    float gb = 0.f;
+    for (long o = (long)blockIdx.x * groups + threadIdx.x / LPP; o < total; o += (long)gridDim.x * groups) {
+        long t = o;
+        const int ow = (int)(t % Wo); t /= Wo;
+        const int oh = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        const long pos = (long)oh * Wo + ow;
+        const long flat = (long)b * Ho * Wo + pos;
+        float d = dout[(long)b * ld_dout + pos];
+        if (depth_feat) {
+            if (sub == 0 && d_depth_feat) d_depth_feat[flat] = d * raw[flat];
+            d *= depth_feat[flat];
+        }
+        const int bi = idx[flat];
+        const long pix = (((long)b * H + oh * 2 + (bi >> 1)) * W + ow * 2 + (bi & 1)) * C;
+        for (int ch = sub; ch < cpp; ch += LPP) {
+            float v[CE], g[CE];
+            chunk_to_f<T>(*(const u32x4*)(x + pix + ch * CE), v);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { g[e] = d * w[ch * CE + e]; atomicAdd(&sh_dwc[ch * CE + e], d * v[e]); }
+            *(u32x4*)(d_x + pix + ch * CE) = f_to_chunk<T>(g);
+        }
+        if (sub == 0) gb += d;
+    }
+    if (sub == 0) atomicAdd(&sh_dwc[C], gb);
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += blockDim.x) atomicAdd(&dw[i], sh_dwc[i]);
+    if (threadIdx.x == 0) atomicAdd(dbias, sh_dwc[C]);
+}
+
+// AvgPool2d(2) x `pools` (each flooring odd sizes, as torch does) -> InstanceNorm2d(1, affine) -> Flatten: an output pixel is the mean
+// of the 2^pools x 2^pools window at (oh, ow) * 2^pools.  One block per image, one wave per output pixel at a time.
+__global__ __launch_bounds__(256) void depth_pools_fwd_kernel(const float* __restrict__ depth, const float* __restrict__ w, const float* __restrict__ b,
+                                                             float* __restrict__ feat, float* __restrict__ xhat, int H, int W, int pools) {
+    extern __shared__ float pooled[];  // Ho*Wo
+    __shared__ double red[2];
+    const int win = 1 << pools, Ho = H >> pools, Wo = W >> pools, n = Ho * Wo;
+    const float* img = depth + (long)blockIdx.x * H * W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv = 1.f / (float)(win * win);
+    for (int o = wave; o < n; o += 4) {
+        const int oh = o / Wo, ow = o - oh * Wo;
+        float acc = 0.f;
+        for (int i = lane; i < win * win; i += 64) {
+            const int r = i >> pools, c = i & (win - 1);
+            acc += img[(long)(oh * win + r) * W + ow * win + c];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) pooled[o] = acc * inv;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {   // n <= 3136 values: one thread sums them in double, in order
+        double s = 0.0, q = 0.0;
+        for (int o = 0; o < n; ++o) { s += pooled[o]; q += (double)pooled[o] * pooled[o]; }
+        red[0] = s; red[1] = q;
+    }
+    __syncthreads();
+    const double mean = red[0] / n;
+    double var = red[1] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float wv = w[0], bv = b[0];
+    for (int o = threadIdx.x; o < n; o += blockDim.x) {
+        const float xh = (pooled[o] - (float)mean) * invstd;
+        xhat[(long)blockIdx.x * n + o] = xh;
+        feat[(long)blockIdx.x * n + o] = xh * wv + bv;
+    }
+}
+
+// dst += src over 16-byte chunks (a hooked feature's gradient joins the trunk's own gradient of that tensor)
+template <typename T>
+__global__ __launch_bounds__(256) void tensor_add_kernel(T* __restrict__ dst, const T* __restrict__ src, long chunks) {
+    constexpr int CE = Elem<T>::kChunk;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (long)gridDim.x * blockDim.x) {
+        float a[CE], b[CE];
+        chunk_to_f<T>(*(const u32x4*)(dst + i * CE), a);
+        chunk_to_f<T>(*(const u32x4*)(src + i * CE), b);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) a[e] += b[e];
+        *(u32x4*)(dst + i * CE) = f_to_chunk<T>(a);
+    }
+}
+
 // dw += sum d*xhat ; db += sum d   (the depth image itself needs no gradient)
 __global__ __launch_bounds__(256) void depth_bwd_kernel(const float* __restrict__ d_feat, const float* __restrict__ xhat, long n, float* dw, float* db) {
     __shared__ float red[2][4];
@@ -583,6 +727,62 @@ int rpe_depth_head_fwd(const float* depth, const float* w, const float* b, float
     if ((H | W) & 3) return rpe_set_error(RPE_ERR_SHAPE, "depth_head: H and W must be multiples of 4");
     const size_t sh = (size_t)(H / 4) * (W / 4) * sizeof(float);
     hipLaunchKernelGGL(depth_fwd_kernel, dim3(B), dim3(256), sh, (hipStream_t)stream, depth, w, b, feat, xhat, H, W);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_tensor_add(int dtype, void* dst, const void* src, long n, void* stream) {
+    const int ce = dtype == RPE_F32 ? 4 : 8;
+    if (n <= 0 || (n % ce) || !dst || !src) return rpe_set_error(RPE_ERR_SHAPE, "tensor_add: n must be a positive multiple of the 16-byte chunk");
+    const int g = ew_grid(n / ce);
+    if (dtype == RPE_F32) hipLaunchKernelGGL((tensor_add_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (float*)dst, (const float*)src, n / ce);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((tensor_add_kernel<bf16>), dim3(g), dim3(256), 0, (hipStream_t)stream, (bf16*)dst, (const bf16*)src, n / ce);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((tensor_add_kernel<f16>), dim3(g), dim3(256), 0, (hipStream_t)stream, (f16*)dst, (const f16*)src, n / ce);
+    else return rpe_set_error(RPE_ERR_DTYPE, "tensor_add: unsupported dtype");
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+static int hook_shape_ok(int dtype, int C, int H, int W) {
+    const int ce = dtype == RPE_F32 ? 4 : 8;
+    if (C < ce || (C % ce) || C > 1024 || H < 2 || W < 2) return 0;
+    const int cpp = C / ce;
+    return (cpp & (cpp - 1)) == 0;   // lanes per pixel = min(64, chunks per pixel) must be a power of two
+}
+
+int rpe_aux_head_fwd_c(int dtype, const void* x, int C, const float* w, const float* bias, const float* depth_feat, float* out, long ld_out,
+                       float* raw, unsigned char* idx, int B, int H, int W, void* stream) {
+    if (!hook_shape_ok(dtype, C, H, W)) return rpe_set_error(RPE_ERR_SHAPE, "aux_head_fwd_c: C must be 16-byte chunks, a power of two of them, <= 1024");
+    const long total = (long)B * (H / 2) * (W / 2);
+    const int g = ew_grid(total, 4);
+    if (dtype == RPE_F32) hipLaunchKernelGGL((auxc_fwd_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, C, w, bias, depth_feat, out, ld_out, raw, idx, B, H, W);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((auxc_fwd_kernel<bf16>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, C, w, bias, depth_feat, out, ld_out, raw, idx, B, H, W);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((auxc_fwd_kernel<f16>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const f16*)x, C, w, bias, depth_feat, out, ld_out, raw, idx, B, H, W);
+    else return rpe_set_error(RPE_ERR_DTYPE, "aux_head_fwd_c: unsupported dtype");
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_aux_head_bwd_c(int dtype, const float* dout, long ld_dout, const void* x, int C, const float* w, const float* depth_feat, const float* raw,
+                       const unsigned char* idx, void* d_x, float* dw, float* dbias, float* d_depth_feat, int B, int H, int W, void* stream) {
+    if (!hook_shape_ok(dtype, C, H, W) || !d_x) return rpe_set_error(RPE_ERR_SHAPE, "aux_head_bwd_c: bad shape or null gradient tensor");
+    const long total = (long)B * (H / 2) * (W / 2);
+    const size_t bytes = (size_t)B * H * W * C * (dtype == RPE_F32 ? 4 : 2);
+    if (hipError_t he = hipMemsetAsync(d_x, 0, bytes, (hipStream_t)stream)) return rpe_set_error_hip(he, __FILE__, __LINE__);
+    const int g = ew_grid(total, 4 * 8);
+    const size_t sh = (size_t)(C + 1) * sizeof(float);
+    if (dtype == RPE_F32) hipLaunchKernelGGL((auxc_bwd_kernel<float>), dim3(g), dim3(256), sh, (hipStream_t)stream, dout, ld_dout, (const float*)x, C, w, depth_feat, raw, idx, (float*)d_x, dw, dbias, d_depth_feat, B, H, W);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((auxc_bwd_kernel<bf16>), dim3(g), dim3(256), sh, (hipStream_t)stream, dout, ld_dout, (const bf16*)x, C, w, depth_feat, raw, idx, (bf16*)d_x, dw, dbias, d_depth_feat, B, H, W);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((auxc_bwd_kernel<f16>), dim3(g), dim3(256), sh, (hipStream_t)stream, dout, ld_dout, (const f16*)x, C, w, depth_feat, raw, idx, (f16*)d_x, dw, dbias, d_depth_feat, B, H, W);
+    else return rpe_set_error(RPE_ERR_DTYPE, "aux_head_bwd_c: unsupported dtype");
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_depth_head_fwd_pools(const float* depth, const float* w, const float* b, float* feat, float* xhat, int B, int H, int W, int pools, void* stream) {
+    if (pools < 1 || pools > 6 || (H >> pools) < 1 || (W >> pools) < 1) return rpe_set_error(RPE_ERR_SHAPE, "depth_head_fwd_pools: 1..6 pooling steps, non-empty output");
+    const size_t sh = (size_t)(H >> pools) * (W >> pools) * sizeof(float);
+    hipLaunchKernelGGL(depth_pools_fwd_kernel, dim3(B), dim3(256), sh, (hipStream_t)stream, depth, w, b, feat, xhat, H, W, pools);
     RPE_CHECK_LAUNCH();
     return 0;
 }

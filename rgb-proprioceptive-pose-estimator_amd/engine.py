@@ -72,6 +72,7 @@ class ResNet50Trunk(nn.Module):
         self._plans = {}      # (B, H, W, dtype, latent, device) -> _Plan, most recently used last
         self.max_plans = 3    # each plan owns a multi-GB workspace: the train plan plus the latest eval / rollout shapes stay
         self._active = None
+        self.keep_stem_raw = False   # a forward hook sits on conv1: inference keeps conv1's raw output too (models/_core.py)
         self._wver = 0        # bumped whenever the fp32 masters or the BN running statistics may have moved
 
     # -- plumbing ---------------------------------------------------------------------------------
@@ -149,6 +150,7 @@ class ResNet50Trunk(nn.Module):
             # possibly through ANOTHER plan (train() runs train and val phases at different batch sizes): rebuild them
             lib.rpe_resnet50_weights_changed(plan.handle)
         plan.wver = self._wver
+        lib.rpe_resnet50_set_stem_raw(plan.handle, int(self.keep_stem_raw))
         if frames:
             F3 = ctypes.c_float * 3
             hr, wr = resized_hw(hs, ws, self.resize_to)
@@ -247,6 +249,21 @@ class _Plan:
     def early_feature(self):
         ptr = lib.rpe_resnet50_early_feature(self.handle)
         return self._alias(ptr, (self.batch, self.h // 2, self.w // 2, 64))
+
+    def hooked_feature(self, layer):
+        """The tensor a forward hook on `layer` sees (models/naive.py:201-211): 0 conv1's raw output, 9 bn1 (after the in-place
+        ReLU), 1..3 the output of layerN -- NHWC, compute dtype, aliasing the workspace."""
+        if layer == 9:
+            return self.early_feature()
+        if layer == 0:
+            return self.tensor("conv1.y").view(self.batch, self.h // 2, self.w // 2, 64)
+        t = self.tensor("layer%d.%d.conv3.a" % (layer, _BLOCKS[self.trunk.depth][layer - 1] - 1))
+        s = 2 << layer   # layer1: 1/4 of the image, layer2: 1/8, layer3: 1/16
+        return t.view(self.batch, self.h // s, self.w // s, t.shape[1])
+
+    def set_hook_grad(self, layer, dense):
+        """dense gradient of hooked_feature(layer) (layer 0..3), added by the next backward; keep it alive until then"""
+        lib.rpe_resnet50_set_hook_grad(self.handle, layer, ops._p(dense))
 
     def early_grad(self):
         ptr = lib.rpe_resnet50_early_grad(self.handle)

@@ -164,15 +164,20 @@ class LSTMOp:
 
 
 class AuxHeadOp:
-    """Conv2d(64->1,1x1)+MaxPool2d(2)+Flatten on the hooked early feature, optionally multiplied by the
-    depth feature (models/naive.py:223-240,318-330)."""
+    """Conv2d(C->1,1x1)+MaxPool2d(2)+Flatten on a hooked feature map, optionally multiplied by the depth feature
+    (models/naive.py:223-240,318-330).  layer 9 (bn1, the hook every reference script uses) runs the 64-channel kernels whose
+    gradient the fused stem backward gathers in compact form; the other hooks (conv1, layer1..3) and `dense` mode (a conv1 hook
+    forces the unfused stem backward) run the general kernels with a dense feature gradient."""
 
-    def __init__(self, conv_w, conv_b, in_w, in_b, trainable=True):
+    def __init__(self, conv_w, conv_b, in_w, in_b, trainable=True, layer=9, pools=2, dense=False):
         self.conv_w, self.conv_b, self.in_w, self.in_b = conv_w, conv_b, in_w, in_b
         self.trainable = trainable
+        self.layer, self.pools, self.dense = layer, pools, dense
 
     def fwd(self, plan, depth, out_cols, use_depth, save=True):
-        """out_cols: [B, 3136] column slice of the fused feature rows."""
+        """out_cols: [B, (H/2)*(W/2)] column slice of the fused feature rows."""
+        if self.layer != 9:
+            return self._fwd_general(plan, depth, out_cols, use_depth, save)
         a1 = plan.early_feature()
         b, h, w, _ = a1.shape
         n = (h // 2) * (w // 2)
@@ -194,14 +199,64 @@ class AuxHeadOp:
             self.saved = (plan, raw, idx, feat, xhat, b, h, w, n)
         return out_cols
 
+    def _fwd_general(self, plan, depth, out_cols, use_depth, save):
+        x = plan.hooked_feature(self.layer)
+        b, h, w, c = x.shape
+        n = (h // 2) * (w // 2)
+        dev = x.device
+        raw = torch.empty((b, n), dtype=torch.float32, device=dev)
+        idx = torch.empty((b, n), dtype=torch.uint8, device=dev)
+        feat = xhat = None
+        s = ops._stream()
+        if use_depth:
+            if depth is None or depth.dim() < 2:
+                raise ValueError("use_depth=True needs a (B,1,H,W) depth batch")
+            hd, wd = depth.shape[-2:]
+            if (hd >> self.pools, wd >> self.pools) != (h // 2, w // 2):
+                raise ValueError("depth batch of %dx%d does not pool to the %dx%d aux feature of layer %d" % (hd, wd, h // 2, w // 2, self.layer))
+            depth = depth.reshape(b, hd, wd).contiguous().float()
+            feat = torch.empty((b, n), dtype=torch.float32, device=dev)
+            xhat = torch.empty((b, n), dtype=torch.float32, device=dev)
+            lib.rpe_depth_head_fwd_pools(ops._p(depth), ops._p(self.in_w.data), ops._p(self.in_b.data), ops._p(feat), ops._p(xhat), b, hd, wd, self.pools, s)
+        lib.rpe_aux_head_fwd_c(ops.dtype_code(x), ops._p(x), c, ops._p(self.conv_w.data), ops._p(self.conv_b.data), ops._p(feat), ops._p(out_cols),
+                               out_cols.stride(0), ops._p(raw), ops._p(idx), b, h, w, s)
+        if save:
+            self.saved = (plan, raw, idx, feat, xhat, b, h, w, n)
+        return out_cols
+
+    def _bwd_general(self, d_cols):
+        plan, raw, idx, feat, xhat, b, h, w, n = self.saved
+        x = plan.hooked_feature(self.layer)
+        c = x.shape[3]
+        dev = x.device
+        if self.trainable:
+            gw, gb = _grad_of(self.conv_w), _grad_of(self.conv_b)
+            gw.zero_(), gb.zero_()
+        else:
+            gw = torch.zeros(c, dtype=torch.float32, device=dev)
+            gb = torch.zeros(1, dtype=torch.float32, device=dev)
+        d_feat = torch.empty((b, n), dtype=torch.float32, device=dev) if feat is not None else None
+        d_x = torch.empty_like(x)                     # dense: zero except the winner pixel of every 2x2 window
+        s = ops._stream()
+        lib.rpe_aux_head_bwd_c(ops.dtype_code(x), ops._p(d_cols), d_cols.stride(0), ops._p(x), c, ops._p(self.conv_w.data), ops._p(feat), ops._p(raw),
+                               ops._p(idx), ops._p(d_x), ops._p(gw), ops._p(gb), ops._p(d_feat), b, h, w, s)
+        self._keep = d_x                              # alive until the trunk backward has been enqueued
+        plan.set_hook_grad(self.layer, d_x)
+        if feat is not None and self.trainable:
+            giw, gib = _grad_of(self.in_w), _grad_of(self.in_b)
+            giw.zero_(), gib.zero_()
+            lib.rpe_depth_head_bwd(ops._p(d_feat), ops._p(xhat), b * n, ops._p(giw), ops._p(gib), s)
+
     def bwd(self, d_cols):
-        """d_cols: [B, 3136] column slice of the feature-row gradient.  Fills the trunk's early-feature
+        """d_cols: [B, (H/2)*(W/2)] column slice of the feature-row gradient.  Fills the trunk's early-feature
         gradient buffer and the head's parameter gradients."""
+        if self.layer != 9:
+            return self._bwd_general(d_cols)
         plan, raw, idx, feat, xhat, b, h, w, n = self.saved
         a1 = plan.early_feature()
         # The gradient of a1 is NOT materialised (a 411 MB tensor at 256 images, zero in 3 of 4 pixels): the trunk's fused stem
         # backward gathers it from (d_cols, depth feature, winner index, conv weight).  RPE_STEM_UNFUSED=1: dense form.
-        dense = os.environ.get("RPE_STEM_UNFUSED") is not None
+        dense = self.dense or os.environ.get("RPE_STEM_UNFUSED") is not None
         d_a1 = plan.early_grad() if dense else None
         dev = a1.device
         if self.trainable:

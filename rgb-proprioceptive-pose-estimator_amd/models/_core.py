@@ -101,6 +101,9 @@ class PoseModelBase(nn.Module):
     """Common state: ``feature_net`` (ResNet-50 trunk), optional ``aux_nets`` / ``depth_nets``."""
 
     EARLY_SHAPE = (64, 112, 112)  # bn1 output for a 224x224 input; what the reference's dummy forward measures
+    # hooked layer -> (C, H, W) of its output for the 224x224 dummy input the reference measures with (models/naive.py:213-216)
+    HOOK_SHAPES = {0: (64, 112, 112), 9: (64, 112, 112), 1: (256, 56, 56), 2: (512, 28, 28), 3: (1024, 14, 14)}
+    HOOK_ORDER = (0, 9, 1, 2, 3)
 
     def _init_features(self, num_resnet_layers, latent_dim, feature_extract, use_pretrained, feature_layer_nums, use_depth,
                        wrap, register_heads, compute_dtype):
@@ -115,27 +118,43 @@ class PoseModelBase(nn.Module):
         trunk, _ = import_resnet(num_resnet_layers, latent_dim, feature_extract, use_pretrained=use_pretrained,
                                  compute_dtype=self.compute_dtype)
         self.feature_net = trunk  # registered first, as in the reference, so state_dict order matches
+        self._hooks = []
         if feature_layer_nums is not None:
-            layers = tuple(feature_layer_nums)
-            if layers != (9,):
-                raise NotImplementedError("only the bn1 hook (feature_layer_nums=(9,)) is on the accelerated path; got %r" % (layers,))
+            layers = list(feature_layer_nums)
+            for layer in layers:
+                if layer == 4:
+                    # the reference sizes its fc input with H*W//4 = 12 columns for layer4's 7x7 map while MaxPool2d(2) yields
+                    # 3x3 = 9 (models/naive.py:243): its own forward raises a shape error for this hook
+                    raise ValueError("feature_layer_nums: a hook on layer4 cannot run in the reference either (aux dim 7*7//4 = 12 vs 9 pooled features)")
+                if layer not in self.HOOK_SHAPES:
+                    raise ValueError("feature_layer_nums: layers 0 (conv1), 9 (bn1) and 1..3 exist; got %r" % (layer,))
+            if len(set(layers)) != len(layers):
+                raise NotImplementedError("feature_layer_nums: one hook per layer (got %r)" % (tuple(layers),))
+            # forward hooks fire in execution order -- conv1, bn1, layer1.. -- whatever the order of the tuple: that is the order of
+            # aux_nets / depth_nets and of the aux columns of the feature rows (models/naive.py:212-241)
+            self._hooks = [layer for layer in self.HOOK_ORDER if layer in layers]
             self.early_features = []
-            c, h, w = self.EARLY_SHAPE
-            aux, dep = _make_aux(c), _make_depth(h, w)
-            if wrap:
-                aux, dep = Replicated(aux), Replicated(dep)
+            auxs, deps = [], []
+            for layer in self._hooks:
+                c, h, w = self.HOOK_SHAPES[layer]
+                aux, dep = _make_aux(c), _make_depth(h, w)
+                if wrap:
+                    aux, dep = Replicated(aux), Replicated(dep)
+                auxs.append(aux)
+                deps.append(dep)
+                self.aux_latent_dim += h * w // 4
             if register_heads:
-                self.aux_nets = nn.ModuleList([aux])
-                self.depth_nets = nn.ModuleList([dep])
+                self.aux_nets = nn.ModuleList(auxs)
+                self.depth_nets = nn.ModuleList(deps)
             else:  # TD model: plain lists, invisible to parameters()/state_dict()/.cuda() (time_sensitive.py:102-115)
-                self.aux_nets = [aux]
-                self.depth_nets = [dep]
-            self.aux_latent_dim += h * w // 4
+                self.aux_nets = auxs
+                self.depth_nets = deps
+            trunk.keep_stem_raw = 0 in self._hooks
         if wrap:
             self.feature_net = Replicated(trunk)
         self._heads_registered = register_heads
         self._arena = None
-        self._aux_op = None
+        self._aux_ops = None
         self._grad_sync = None   # dist.GradSync attached by the data-parallel loop (staged all-reduce under backward)
         self.rollout = False
 
@@ -145,8 +164,8 @@ class PoseModelBase(nn.Module):
         f = self.feature_net
         return f.module if isinstance(f, Replicated) else f
 
-    def _aux_modules(self):
-        aux, dep = self.aux_nets[0], self.depth_nets[0]
+    def _aux_modules(self, i=0):
+        aux, dep = self.aux_nets[i], self.depth_nets[i]
         if isinstance(aux, Replicated):
             aux, dep = aux.module, dep.module
         return aux[0], dep[-2]  # Conv2d, InstanceNorm2d
@@ -163,12 +182,18 @@ class PoseModelBase(nn.Module):
         if self._arena is None or not self._arena.is_current():
             self._arena = ParamArena(self)
         self._arena.loss_scaler = self.loss_scaler   # FusedAdam unscales / skips through it (amp.py)
-        if self.aux_nets is not None and self._aux_op is None or (self._aux_op is not None and self._aux_op.conv_w.device != device):
-            conv, inorm = self._aux_modules()
-            if not self._heads_registered:
-                for m in (conv, inorm):
-                    m.to(device)
-            self._aux_op = AuxHeadOp(conv.weight, conv.bias, inorm.weight, inorm.bias, trainable=self._heads_registered)
+        if self.aux_nets is not None and (self._aux_ops is None or any(op.conv_w.device != device for op in self._aux_ops)):
+            self._aux_ops = []
+            for i, layer in enumerate(self._hooks):
+                conv, inorm = self._aux_modules(i)
+                if not self._heads_registered:
+                    for m in (conv, inorm):
+                        m.to(device)
+                c, h, w = self.HOOK_SHAPES[layer]
+                pools = len(self.depth_nets[i].module if isinstance(self.depth_nets[i], Replicated) else self.depth_nets[i]) - 2
+                # a conv1 hook sends the stem backward down its unfused path, which takes the bn1 hook's gradient as a dense tensor
+                self._aux_ops.append(AuxHeadOp(conv.weight, conv.bias, inorm.weight, inorm.bias, trainable=self._heads_registered, layer=layer,
+                                               pools=pools, dense=0 in self._hooks))
 
     def _anchor(self):
         for p in self.parameters():
@@ -193,17 +218,27 @@ class PoseModelBase(nn.Module):
         """img (B,3,H,W); rows [B, ld] fp32: columns [0,L) <- ResNet latent, [L, L+aux) <- aux head."""
         plan = self.trunk.run(img, rows, self.training)
         if self.aux_nets is not None:
-            L = self.latent_dim
-            self._aux_op.fwd(plan, depth if self.use_depth else None, rows[:, L:L + self.aux_latent_dim], self.use_depth, save=save)
+            off = self.latent_dim
+            for op in self._aux_ops:
+                c, h, w = self.HOOK_SHAPES[op.layer]
+                if (plan.h, plan.w) != (224, 224) and op.layer != 9:
+                    raise ValueError("hooks other than bn1 are sized for 224x224 inputs (as the reference's dummy forward is)")
+                n = h * w // 4
+                op.fwd(plan, depth if self.use_depth else None, rows[:, off:off + n], self.use_depth, save=save)
+                off += n
         self._plan = plan
         return plan
 
     def _features_bwd(self, d_rows):
         """d_rows [B, ld >= L + aux] gradient of the fused feature rows."""
-        use_early = self.aux_nets is not None
-        if use_early:
-            L = self.latent_dim
-            self._aux_op.bwd(d_rows[:, L:L + self.aux_latent_dim])
+        use_early = self.aux_nets is not None and 9 in self._hooks   # (the bn1 hook's gradient enters the stem backward)
+        if self.aux_nets is not None:
+            off = self.latent_dim
+            for op in self._aux_ops:
+                c, h, w = self.HOOK_SHAPES[op.layer]
+                n = h * w // 4
+                op.bwd(d_rows[:, off:off + n])
+                off += n
         sync = getattr(self, "_grad_sync", None)
         self._plan.backward(d_rows, use_early, None if sync is None else sync.stage_done)
 

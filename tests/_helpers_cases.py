@@ -15,3 +15,7 @@ SAMPLE_STRIDE, SAMPLE_MAX = 997, 4096
 R101 = (dict(latent_dim=64, hidden=[32], use_depth=False, no_proprioception=False, depth=101), (2,), 41, 401)
 # BASELINE.json configs[2]: the two-arm TD model on sequences of four frames -- must match oracle/gen_golden.py TD_S4
 TD_S4 = (dict(latent_dim=64, hidden=32, use_depth=False), (4, 2), 51, 501)
+# feature_layer_nums other than (9,): every hook the reference can run at 224x224 (given out of order), depth heads on; and None
+# -- must match oracle/gen_golden.py HOOKS / NOHOOK
+HOOKS = (dict(latent_dim=64, hidden=[32], use_depth=True, no_proprioception=False, hooks=(3, 0, 9, 2, 1)), (2,), 61, 601)
+NOHOOK = (dict(latent_dim=64, hidden=[32], use_depth=False, no_proprioception=False, hooks=None), (2,), 62, 602)

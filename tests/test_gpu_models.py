@@ -234,3 +234,79 @@ def test_td_four_frame_sequences_match_reference(dtype, bar, golden_dir):
         for name, p in model.named_parameters():
             if p.grad is not None:
                 assert torch.isfinite(p.grad).all(), name
+
+
+@pytest.mark.parametrize("tag,dtype,bar", [("hooks", torch.float32, 1e-4), ("hooks", torch.bfloat16, 5e-2), ("hooks", torch.float16, 1.5e-2),
+                                           ("nohook", torch.float32, 1e-4), ("nohook", torch.bfloat16, 5e-2)])
+def test_other_hook_layers_match_reference(tag, dtype, bar, golden_dir):
+    """feature_layer_nums other than the scripts' (9,) (models/naive.py:196-240): hooks on conv1, bn1 and layer1..3 -- given out of
+    order, depth heads on -- and None, against the reference's vectors: state_dict keys (aux_nets in hook FIRING order), pristine
+    eval output, step-1 output / loss; fp32: every gradient's norm and the head gradients element-wise."""
+    import _helpers_cases as hc
+    cfg, lead, wseed, dseed = hc.HOOKS if tag == "hooks" else hc.NOHOOK
+    gold = np.load(os.path.join(golden_dir, "model_no_%s.npz" % tag))
+    sd = po.make_state("no", cfg, wseed)
+    model = M.NaiveObjectStateEstimator("cube", list(cfg["hidden"]), 50, cfg["latent_dim"], False, cfg["hooks"], cfg["use_depth"], False, False,
+                                        compute_dtype=dtype)
+    assert list(model.state_dict().keys()) == list(gold["keys"])
+    load_values(model, "no", sd)
+    model.cuda().eval()
+    b9 = to_dev(po.synth_batch(lead, dseed + 9, with_depth=cfg["use_depth"]))
+    with torch.no_grad():
+        assert rel(model(b9["img"], b9["depth"], b9["x0bar"]), gold["pre_eval_out0"]) < (2e-4 if dtype == torch.float32 else bar)
+    model.train()
+    crit = M.PoseDistanceLoss(distance_metric="combined", scale_factor=1.0, alpha=0.5, mode="pose")
+    b1 = to_dev(po.synth_batch(lead, dseed + 1, with_depth=cfg["use_depth"]))
+    out = model(b1["img"], b1["depth"], b1["x0bar"])
+    loss = crit(out, b1["obj"])
+    loss.backward()
+    assert rel(out, gold["out0_s1"]) < bar
+    np.testing.assert_allclose(loss.item(), gold["loss_s1"], rtol=bar)
+    if dtype != torch.float32:
+        return
+    named = dict(model.named_parameters())
+    # every hooked feature's gradient reached the trunk: all gradient norms as in the reference (noise-amplifying early layers: 5 %)
+    for name, ref in zip(gold["grad_keys_s1"], gold["grad_digest_s1"]):
+        g = named[str(name)].grad
+        assert g is not None, name
+        np.testing.assert_allclose(g.double().norm().item(), ref[1], rtol=5e-2, atol=1e-7, err_msg=str(name))
+    for name in gold.files:
+        if name.startswith("grad::"):
+            g = named[name[6:]].grad.detach().cpu().numpy()
+            scale = max(1e-6, float(np.abs(gold[name]).max()))
+            assert np.abs(g - gold[name]).max() / scale < (3e-2 if "conv1" in name else 2e-3), name
+
+
+def test_hook_on_layer4_is_refused_like_the_reference():
+    """the reference sizes fc0 with 7*7//4 = 12 aux columns for layer4 while its aux head yields 9: its forward raises; so does the constructor here"""
+    with pytest.raises(ValueError):
+        M.NaiveObjectStateEstimator("cube", [32], 50, 64, False, (4,), False, False, False)
+    with pytest.raises(ValueError):
+        M.NaiveObjectStateEstimator("cube", [32], 50, 64, False, (5,), False, False, False)
+
+
+def test_sequence_model_with_extra_hooks_matches_oracle():
+    """The hook wiring is shared by all model classes: TDO (LSTM over 2x2 frames) with hooks on layer1 and bn1 against the oracle
+    (pinned to the reference for these hooks by tests/test_oracle_golden.py), fp32 path."""
+    cfg = dict(latent_dim=64, hidden=32, use_depth=True, no_proprioception=False, hooks=(1, 9))
+    lead, wseed, dseed = (2, 2), 71, 701
+    sd = po.make_state("tdo", cfg, wseed)
+    model = M.TemporallyDependentObjectStateEstimator("hammer", cfg["hidden"], 50, cfg["latent_dim"], 2, 0.1, False, cfg["hooks"], True, False, False,
+                                                      compute_dtype=torch.float32)
+    assert list(model.state_dict().keys()) == [k for k, _ in po.model_keys("tdo", cfg)]
+    load_values(model, "tdo", sd)
+    model.cuda().train()
+    model.reset_initial_state(lead[-1])
+    b1c = po.synth_batch(lead, dseed + 1, with_depth=True)
+    ref = po.train_step("tdo", cfg, {k: v.clone() for k, v in sd.items()}, b1c, LOSS_CFG, {}, lr=1e-3, val_metrics=False)
+    crit = M.PoseDistanceLoss(distance_metric="combined", scale_factor=1.0, alpha=0.5, mode="pose")
+    b1 = to_dev(b1c)
+    out = model(b1["img"], b1["depth"], b1["x0bar"])
+    loss = crit(out, b1["obj"])
+    loss.backward()
+    assert rel(out, ref["outputs"]) < 1e-4
+    np.testing.assert_allclose(loss.item(), ref["loss"].item(), rtol=1e-4)
+    named = dict(model.named_parameters())
+    for name in ("aux_nets.0.module.0.weight", "aux_nets.1.module.0.weight", "depth_nets.1.module.3.weight", "rnn.module.weight_ih_l0"):
+        g, r = named[name].grad.detach().cpu(), ref["grads"][name]
+        assert ((g - r).abs().max() / r.abs().max().clamp_min(1e-12)).item() < 2e-3, name
