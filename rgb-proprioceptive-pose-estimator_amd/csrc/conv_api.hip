@@ -222,23 +222,27 @@ __global__ __launch_bounds__(256) void wgrad_fold_combine_kernel(float* __restri
                                                                 const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                                 const float* __restrict__ mean, const float* __restrict__ c1, const float* __restrict__ c2,
                                                                 int Co, int Ci, int ones_row) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // Ws [16][Ci] | Ss [Ci][64]
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // Ws [16][Ci] | Ss [KC][64], KC = min(Ci, 128) rows of S at a time
     float* Ws = sm;
     float* Ss = sm + 16 * Ci;
+    const int KC = Ci < 128 ? Ci : 128;
     const int c0 = blockIdx.x * 16, n0 = blockIdx.y * 64;
     const float* S = dp + (long)Co * Ci;
     for (int i = threadIdx.x; i < 16 * Ci; i += 256) Ws[i] = w[(long)c0 * Ci + i];
-    for (int i = threadIdx.x; i < Ci * 16; i += 256) {   // 16 float4 per row of the 64-column chunk
-        const int k = i >> 4, q4 = i & 15;
-        *(f32x4*)(Ss + k * 64 + q4 * 4) = (n0 + q4 * 4 < Ci) ? *(const f32x4*)(S + (long)k * Ci + n0 + q4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    __syncthreads();
     const int cl = threadIdx.x >> 4, nq = (threadIdx.x & 15) * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < Ci; ++k) {
-        const float wv = Ws[cl * Ci + k];
-        const f32x4 sv = *(const f32x4*)(Ss + k * 64 + nq);
-        acc[0] = fmaf(wv, sv[0], acc[0]); acc[1] = fmaf(wv, sv[1], acc[1]); acc[2] = fmaf(wv, sv[2], acc[2]); acc[3] = fmaf(wv, sv[3], acc[3]);
+    for (int k0 = 0; k0 < Ci; k0 += KC) {
+        __syncthreads();   // (Ws written / the previous chunk of S consumed)
+        for (int i = threadIdx.x; i < KC * 16; i += 256) {   // 16 float4 per row of the 64-column chunk
+            const int k = i >> 4, q4 = i & 15;
+            *(f32x4*)(Ss + k * 64 + q4 * 4) = (n0 + q4 * 4 < Ci) ? *(const f32x4*)(S + (long)(k0 + k) * Ci + n0 + q4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        for (int k = 0; k < KC; ++k) {
+            const float wv = Ws[cl * Ci + k0 + k];
+            const f32x4 sv = *(const f32x4*)(Ss + k * 64 + nq);
+            acc[0] = fmaf(wv, sv[0], acc[0]); acc[1] = fmaf(wv, sv[1], acc[1]); acc[2] = fmaf(wv, sv[2], acc[2]); acc[3] = fmaf(wv, sv[3], acc[3]);
+        }
     }
     const int c = c0 + cl;
     const float a = gamma[c] * invstd[c];
@@ -279,7 +283,7 @@ static int conv1x1_wgrad_folded_t(const rpe_conv_desc* d, const void* dz, const 
                                   const float* mean, const float* c1c2, float* dw, void* scratch, long scratch_bytes, long* query, hipStream_t s) {
     const long M = (long)d->batch * d->in_h * d->in_w;
     const int Co = d->out_c, Ci = d->in_c;
-    if ((Co % 128) || (Ci % 64) || Ci > 128) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_wgrad_folded: out_c % 128 == 0, in_c in {64, 128}");
+    if ((Co % 128) || (Ci % 64) || Ci > 512 || (Ci > 128 && (Ci % 128))) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_wgrad_folded: out_c % 128 == 0, in_c in {64, 128, 256, 384, 512}");
     WFoldPlan pl;
     if (int e = wfold_plan<T>(M, Co, Ci, pl)) return e;
     if (query) { *query = pl.total; return 0; }
@@ -291,7 +295,7 @@ static int conv1x1_wgrad_folded_t(const rpe_conv_desc* d, const void* dz, const 
     a.P = (const T*)dz; a.P2 = (const T*)a_in; a.Q = (const T*)a_in; a.D = dp;
     a.slab = (float*)(sc + pl.slab_off); a.slab_bytes = scratch_bytes - pl.slab_off;
     if (int e = launch_tn<T>(a, MODE_DENSE, s)) return e;
-    const size_t lds = (size_t)(16 * Ci + Ci * 64) * 4;
+    const size_t lds = (size_t)(16 * Ci + (Ci < 128 ? Ci : 128) * 64) * 4;
     hipLaunchKernelGGL(wgrad_fold_combine_kernel, dim3(Co / 16, (Ci + 63) / 64), dim3(256), lds, s, dw, dp, w_master, gamma, invstd, mean, c1c2, c1c2 + Co, Co, Ci,
                        pl.ones_row);
     RPE_CHECK_LAUNCH();

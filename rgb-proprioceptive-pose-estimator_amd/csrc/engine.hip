@@ -97,6 +97,7 @@ struct rpe_resnet50 {
     void* wfold_scratch = nullptr;   // side-stream scratch of the folded weight gradient (S, colsum, W S, slabs)
     long wfold_scratch_bytes = 0;
     bool fold_w = true;
+    int fold_w_max = 256;   // widest conv3 input the folded weight gradient takes (RPE_WGRAD_FOLD_MAX; measured 128: 21.92, 256: 21.77, 512: 21.80 ms/step)
     void* main_slab = nullptr;   // the same for the two weight gradients that run on the caller's stream (stem conv, fc)
     long main_slab_bytes = 0;
     void* wg_slab = nullptr;     // per-workgroup fp32 tiles of the deterministic weight-gradient form (one launch at a time: side stream order)
@@ -300,8 +301,9 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
         }
         e->fold_w = getenv("RPE_NO_WGRAD_FOLD") == nullptr;
         if (e->fold_w) {
+            if (getenv("RPE_WGRAD_FOLD_MAX")) e->fold_w_max = atoi(getenv("RPE_WGRAD_FOLD_MAX"));
             for (auto& b : e->blocks) {
-                if (e->convs[b.c3].d.in_c > 128) continue;   // layers 1-2: where the 4-planes-wide tensors are big
+                if (e->convs[b.c3].d.in_c > e->fold_w_max) continue;   // (default: layers 1-3)
                 const long sb = rpe_conv1x1_wgrad_folded_scratch_bytes(&e->convs[b.c3].d, dtype);
                 if (sb > e->wfold_scratch_bytes) e->wfold_scratch_bytes = sb;
             }
@@ -819,7 +821,7 @@ static int conv1x1_backward_folded(rpe_resnet50* e, ConvL& c, const void* dz, Co
         run = e->side;
     }
     float* dw = e->grads[c.p_w];
-    if (e->fold_w && e->wfold_scratch && c.d.in_c <= 128) {
+    if (e->fold_w && e->wfold_scratch && c.d.in_c <= e->fold_w_max) {
         // weight gradient from dz and x alone (no dy): dz^T x, x^T x, colsum(x), W (x^T x), combine
         e->pending_flops = conv_flops(c) * (1.0 + (double)c.d.in_c / c.d.out_c);
         e->pending_bytes = conv_out_bytes(e, c) + 3.0 * conv_in_bytes(e, c);
