@@ -191,6 +191,11 @@ int rpe_bn_apply(int dtype, const void* y, const void* residual, void* out, cons
  * (1/16 of the bytes of `out`) instead of `out` to mask the gradient (rpe_bn_bwd_epilogue.a_mask).  C % 8 == 0. */
 int rpe_bn_apply_mask(int dtype, const void* y, const void* residual, void* out, const float* scale, const float* shift, long rows, int C,
                       unsigned char* relu_mask, void* stream);
+/* the same with a residual that is itself a raw conv output under its own BatchNorm (the projection shortcut: downsample.0 ->
+ * downsample.1, no ReLU): out = [relu](y*scale + shift + res_y*res_scale + res_shift), optional packed mask -- the shortcut's own
+ * apply pass and normalised copy disappear (torchvision Bottleneck.forward: `identity = self.downsample(x)`; `out += identity`) */
+int rpe_bn_apply_res_bn(int dtype, const void* y, const void* res_y, const float* res_scale, const float* res_shift, void* out, const float* scale,
+                        const float* shift, long rows, int C, int relu, unsigned char* relu_mask, void* stream);
 /* dz = dA * (a_out > 0) (a_out null: no ReLU); dgamma, dbeta; dy = BN backward of dz; dz_out (nullable) = dz.
  * part: >= 2*1024*C floats of scratch; c1c2: 2*C floats of scratch; dpart: as for rpe_bn_finalize. */
 int rpe_bn_backward(int dtype, const void* dA, const void* a_out, const void* y, const float* mean, const float* invstd,

@@ -78,6 +78,7 @@ _SPEC = {
     "rpe_bn_eval_affine": (I, [I, P, P, P, P, F, P, P, P]),
     "rpe_bn_apply": (I, [I, P, P, P, P, P, L, I, I, P]),
     "rpe_bn_apply_mask": (I, [I, P, P, P, P, P, L, I, P, P]),
+    "rpe_bn_apply_res_bn": (I, [I, P, P, P, P, P, P, P, L, I, I, P, P]),
     "rpe_bn_backward": (I, [I, P, P, P, P, P, P, P, P, P, P, L, I, P, L, P, P, P]),
     "rpe_maxpool3x3s2_fwd": (I, [I, P, P, P, I, I, I, I, P]),
     "rpe_maxpool3x3s2_bwd": (I, [I, P, P, P, P, I, I, I, I, P]),

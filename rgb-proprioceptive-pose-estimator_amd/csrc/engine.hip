@@ -606,8 +606,10 @@ static int conv_bn_split(rpe_resnet50* e, ConvL& c, const void* x, const void* r
     return 0;
 }
 
+// res_bn: the residual is the RAW output of that layer (the projection shortcut) and its BatchNorm is applied inside this layer's
+// apply pass (rpe_bn_apply_res_bn); stats_only: stop after the statistics (the shortcut itself then has no apply pass).
 static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residual, int relu, void* stream, bool second_set = false,
-                   unsigned char* relu_mask = nullptr) {
+                   unsigned char* relu_mask = nullptr, const ConvL* res_bn = nullptr, bool stats_only = false) {
     if (e->split && e->train_mode && !second_set && e->half) return conv_bn_split(e, c, x, residual, relu, stream, relu_mask);
     const bool train = e->train_mode != 0;
     float* stats = second_set ? e->stats_part2 : e->stats_part;
@@ -633,7 +635,13 @@ static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residua
     e->pending_bytes = 0;
     PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_finalize(stats, (int)rpe_conv_stats_tiles(c.rows), c.d.out_c, c.rows, e->params[c.p_g], e->params[c.p_b], rm, rv,
                         e->nbt[c.bn_i], 0.1f, 1e-5f, c.scale, c.shift, c.mean, c.invstd, dpart, stream));
+    if (stats_only) return 0;
     e->pending_bytes = conv_out_bytes(e, c) * (2.0 + (residual ? 1.0 : 0.0) + ((relu_mask && relu) ? 1.0 / 16 : 0.0));   // y (+residual) -> a (+mask)
+    if (res_bn) {
+        PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_apply_res_bn(e->dtype, c.y, res_bn->y, res_bn->scale, res_bn->shift, c.a, c.scale, c.shift, c.rows, c.d.out_c, relu,
+                                                            relu ? relu_mask : nullptr, stream));
+        return 0;
+    }
     if (relu_mask && relu) PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_apply_mask(e->dtype, c.y, residual, c.a, c.scale, c.shift, c.rows, c.d.out_c, relu_mask, stream));
     else PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_apply(e->dtype, c.y, residual, c.a, c.scale, c.shift, c.rows, c.d.out_c, relu, stream));
     return 0;
@@ -680,6 +688,10 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
     }
     const void* x = e->pool;
     static const bool fwd_overlap = getenv("RPE_NO_FWD_OVERLAP") == nullptr;
+    // training: the projection shortcut's BatchNorm is applied inside conv3's apply pass (no pass / normalised copy of its own);
+    // RPE_NO_DS_FUSE=1: the separate pass
+    static const bool ds_fuse_ok = getenv("RPE_NO_DS_FUSE") == nullptr;
+    const bool fuse_ds = ds_fuse_ok && training && !e->split;
     for (auto& b : e->blocks) {
         ConvL &c1 = e->convs[b.c1], &c2 = e->convs[b.c2], &c3 = e->convs[b.c3];
         const void* idn = x;
@@ -698,18 +710,20 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
                 HIPTRY(hipEventRecord(xb_ready, e->half));
                 HIPTRY(hipStreamWaitEvent(e->side, xb_ready, 0));
             }
-            TRY(conv_bn(e, cd, x, nullptr, 0, e->side, true));
+            TRY(conv_bn(e, cd, x, nullptr, 0, e->side, true, nullptr, nullptr, fuse_ds));
             HIPTRY(hipEventRecord(ds_done, e->side));
             idn = cd.a;
         }
         TRY(conv_bn(e, c1, x, nullptr, 1, stream));
         TRY(conv_bn(e, c2, c1.a, nullptr, 1, stream));
-        if (b.cd >= 0 && !ds_done) { ConvL& cd = e->convs[b.cd]; TRY(conv_bn(e, cd, x, nullptr, 0, stream)); idn = cd.a; }
+        if (b.cd >= 0 && !ds_done) { ConvL& cd = e->convs[b.cd]; TRY(conv_bn(e, cd, x, nullptr, 0, stream, false, nullptr, nullptr, fuse_ds)); idn = cd.a; }
         if (ds_done) {
             HIPTRY(hipStreamWaitEvent((hipStream_t)stream, ds_done, 0));
             if (e->split) HIPTRY(hipStreamWaitEvent(e->half, ds_done, 0));
         }
         static const bool use_mask = getenv("RPE_NO_RELU_MASK") == nullptr;
+        if (b.cd >= 0 && fuse_ds) TRY(conv_bn(e, c3, c2.a, e->convs[b.cd].y, 1, stream, false, use_mask ? b.relu_mask : nullptr, &e->convs[b.cd]));
+        else
         TRY(conv_bn(e, c3, c2.a, idn, 1, stream, false, use_mask ? b.relu_mask : nullptr));   // (relu_mask is null for fp32 engines)
         x = c3.a;
     }

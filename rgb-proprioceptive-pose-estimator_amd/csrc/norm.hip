@@ -161,15 +161,22 @@ template <bool NT> __device__ inline void st16(void* p, const u32x4& v) {
 template <typename T, int UNR, bool NT>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ out,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
-                                                      long nchunks, int C, int relu, unsigned char* __restrict__ mask) {
+                                                      long nchunks, int C, int relu, unsigned char* __restrict__ mask,
+                                                      const float* __restrict__ res_scale, const float* __restrict__ res_shift) {
     constexpr int CE = Elem<T>::kChunk;
     const int cpr = C / CE;
     const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
     const int c0 = (int)(i0 % cpr) * CE;
-    float sc[CE], sh[CE];
+    // res_scale / res_shift: the residual is itself a raw conv output whose BatchNorm (the projection shortcut's, no ReLU) is
+    // applied here on the fly -- its own apply pass and the normalised copy it wrote are gone; the shift folds into sh
+    float sc[CE], sh[CE], rs[CE];
 #pragma unroll
-    for (int e = 0; e < CE; ++e) { sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e]; }
+    for (int e = 0; e < CE; ++e) {
+        sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e];
+        rs[e] = res_scale ? res_scale[c0 + e] : 1.f;
+        if (res_scale) sh[e] += res_shift[c0 + e];
+    }
     for (long i = i0; i < nchunks; i += stride * UNR) {
         u32x4 vy[UNR], vr[UNR];
 #pragma unroll
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
 #pragma unroll
             for (int e = 0; e < CE; ++e) {
                 float t = fmaf(v[e], sc[e], sh[e]);  // same expression as the fused dgrad epilogue's mask
-                if (res) t += r[e];
+                if (res) t = res_scale ? fmaf(r[e], rs[e], t) : t + r[e];
                 v[e] = relu ? fmaxf(t, 0.f) : t;
                 bits |= (t > 0.f ? 1u : 0u) << e;
             }
@@ -757,7 +764,7 @@ static int reduce_finalize(const float* part, int tiles, int C, double* dpart, c
 
 template <typename T>
 int bn_apply_launch(const void* y, const void* res, void* out, const float* scale, const float* shift, long M, int C, int relu, unsigned char* mask,
-                    hipStream_t s) {
+                    hipStream_t s, const float* res_scale = nullptr, const float* res_shift = nullptr) {
     constexpr int CE = Elem<T>::kChunk;
     if (C % CE) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply: C must be a multiple of the 16-byte chunk");
     const long n = M * C / CE;
@@ -766,7 +773,7 @@ int bn_apply_launch(const void* y, const void* res, void* out, const float* scal
     const long g = ew_grid_rows(n, cpr, cfg);
     if ((g * 256) % cpr) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply: C/chunk must divide grid*256 (power-of-two channel counts)");
     if (mask && sizeof(T) != 2) return rpe_set_error(RPE_ERR_DTYPE, "bn_apply_mask: the packed ReLU mask is written for 16-bit element types only");
-#define RPE_BN_APPLY(U, N) hipLaunchKernelGGL((bn_apply_kernel<T, U, N>), dim3((unsigned)g), dim3(256), 0, s, (const T*)y, (const T*)res, (T*)out, scale, shift, n, C, relu, mask)
+#define RPE_BN_APPLY(U, N) hipLaunchKernelGGL((bn_apply_kernel<T, U, N>), dim3((unsigned)g), dim3(256), 0, s, (const T*)y, (const T*)res, (T*)out, scale, shift, n, C, relu, mask, res_scale, res_shift)
     if (cfg.nt) { if (cfg.unr == 1) RPE_BN_APPLY(1, true); else if (cfg.unr == 2) RPE_BN_APPLY(2, true); else RPE_BN_APPLY(4, true); }
     else { if (cfg.unr == 1) RPE_BN_APPLY(1, false); else if (cfg.unr == 2) RPE_BN_APPLY(2, false); else RPE_BN_APPLY(4, false); }
 #undef RPE_BN_APPLY
@@ -903,6 +910,18 @@ int rpe_bn_apply_mask(int dtype, const void* y, const void* residual, void* out,
     if (dtype == RPE_BF16) return bn_apply_launch<bf16>(y, residual, out, scale, shift, rows, C, 1, relu_mask, (hipStream_t)stream);
     if (dtype == RPE_F16) return bn_apply_launch<f16>(y, residual, out, scale, shift, rows, C, 1, relu_mask, (hipStream_t)stream);
     return rpe_set_error(RPE_ERR_DTYPE, "bn_apply_mask: 16-bit element types only");
+}
+
+int rpe_bn_apply_res_bn(int dtype, const void* y, const void* res_y, const float* res_scale, const float* res_shift, void* out, const float* scale,
+                        const float* shift, long rows, int C, int relu, unsigned char* relu_mask, void* stream) {
+    note_kernel(relu_mask ? "bn_apply_kernel<mask,res_bn>" : "bn_apply_kernel<res_bn>");
+    if (!res_y || !res_scale || !res_shift) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply_res_bn: the residual and its scale / shift are required");
+    if (relu_mask && (dtype == RPE_F32 || (C % 8) || !relu)) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply_res_bn: the packed mask needs a 16-bit element type, C % 8 == 0 and relu");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == RPE_F32) return bn_apply_launch<float>(y, res_y, out, scale, shift, rows, C, relu, nullptr, s, res_scale, res_shift);
+    if (dtype == RPE_BF16) return bn_apply_launch<bf16>(y, res_y, out, scale, shift, rows, C, relu, relu_mask, s, res_scale, res_shift);
+    if (dtype == RPE_F16) return bn_apply_launch<f16>(y, res_y, out, scale, shift, rows, C, relu, relu_mask, s, res_scale, res_shift);
+    return rpe_set_error(RPE_ERR_DTYPE, "bn_apply_res_bn: unsupported dtype");
 }
 
 int rpe_bn_backward(int dtype, const void* dA, const void* a_out, const void* y, const float* mean, const float* invstd,

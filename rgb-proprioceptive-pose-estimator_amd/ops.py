@@ -290,6 +290,17 @@ def bn_apply_mask(y, scale, shift, residual=None):
     return out, mask
 
 
+def bn_apply_res_bn(y, scale, shift, res_y, res_scale, res_shift, relu=True, want_mask=False):
+    """[relu](y*scale + shift + res_y*res_scale + res_shift): the residual is a raw conv output under its own BatchNorm (the
+    projection shortcut), applied on the fly; want_mask: also the packed ReLU mask (16-bit element types)."""
+    out = torch.empty_like(y)
+    c = y.shape[-1]
+    mask = torch.empty(y.numel() // 8, dtype=torch.uint8, device=y.device) if want_mask else None
+    lib.rpe_bn_apply_res_bn(dtype_code(y), _p(_chk(y, "y")), _p(res_y), _p(res_scale), _p(res_shift), _p(out), _p(scale), _p(shift), y.numel() // c, c,
+                            int(relu), _p(mask), _stream())
+    return (out, mask) if want_mask else out
+
+
 def bn_backward(dA, a_out, y, mean, invstd, gamma, want_dz=False):
     c = y.shape[-1]
     dev = y.device

@@ -634,6 +634,30 @@ def test_conv_fwd_affine_inference_form(dtype, cfg, residual):
     assert rel_err(nchw(out), ref) < tol(dtype)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,c", [(2 * 14 * 14, 256), (3 * 7 * 7, 2048), (1000, 64)])
+def test_bn_apply_with_shortcut_bn_on_the_fly(dtype, rows, c):
+    """rpe_bn_apply_res_bn == BN apply of the projection shortcut (rounded to the compute dtype) followed by the residual BN apply,
+    up to that one rounding; the packed mask marks exactly the positive outputs."""
+    g = torch.Generator().manual_seed(rows + c)
+    y, ry = q(torch.randn(rows, c, generator=g), dtype), q(torch.randn(rows, c, generator=g) * 2 + 0.5, dtype)
+    sc, sh = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    rsc, rsh = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    ref = F.relu(y * sc + sh + ry * rsc + rsh)
+    yd, rd = y.to(dtype).to(DEV), ry.to(dtype).to(DEV)
+    out = ops.bn_apply_res_bn(yd, sc.to(DEV), sh.to(DEV), rd, rsc.to(DEV), rsh.to(DEV))
+    assert rel_err(out, ref) < tol(dtype)
+    two = ops.bn_apply(yd, sc.to(DEV), sh.to(DEV), ops.bn_apply(rd, rsc.to(DEV), rsh.to(DEV), None, relu=False), relu=True)
+    assert rel_err(out, two) < tol(dtype)
+    norelu = ops.bn_apply_res_bn(yd, sc.to(DEV), sh.to(DEV), rd, rsc.to(DEV), rsh.to(DEV), relu=False)
+    assert rel_err(norelu, y * sc + sh + ry * rsc + rsh) < tol(dtype)
+    if dtype != torch.float32:
+        out2, mask = ops.bn_apply_res_bn(yd, sc.to(DEV), sh.to(DEV), rd, rsc.to(DEV), rsh.to(DEV), want_mask=True)
+        assert torch.equal(out2, out)
+        bits = ((mask.cpu()[:, None] >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(rows, c).bool()
+        assert torch.equal(bits, out.cpu().float() > 0)
+
+
 SPLITK = [  # rollout-frame shapes (one image through layer2-4): few 64x64 output tiles, long reductions
     (1, 7, 512, 512, 3, 1, 1), (1, 14, 256, 256, 3, 1, 1), (1, 28, 128, 128, 3, 1, 1), (1, 7, 2048, 512, 1, 1, 0), (1, 14, 1024, 2048, 1, 2, 0),
     (1, 14, 512, 512, 3, 2, 1), (3, 7, 512, 512, 3, 1, 1), (2, 9, 320, 72, 3, 1, 1)]

@@ -48,9 +48,10 @@ ENGINE_VARIANTS = [
     {"RPE_NO_FWD_OVERLAP": "1", "RPE_STEM_UNFUSED": "1", "RPE_NO_BN_FOLD": "1"},
     # forward as two concurrent half-batch pipelines; conv3 weight gradient from dy; fp32 atomics instead of slabs
     {"RPE_FWD_SPLIT": "1", "RPE_NO_WGRAD_FOLD": "1", "RPE_WGRAD_ATOMIC": "1"},
-    # projection-shortcut backward on the side stream; inference convs unsplit and few-row Linear layers on the MFMA tile kernel
+    # projection-shortcut backward on the side stream; its BN as a pass of its own; folded weight gradient for layers 1-2 only;
+    # inference convs unsplit and few-row Linear layers on the MFMA tile kernel
     # (the golden case's eval / rollout outputs run at 2-4 images: the default takes the split-K and per-column kernels there)
-    {"RPE_CD_SIDE": "1", "RPE_NO_SPLITK": "1", "RPE_NO_LINEAR_ROWS": "1"},
+    {"RPE_CD_SIDE": "1", "RPE_NO_SPLITK": "1", "RPE_NO_LINEAR_ROWS": "1", "RPE_NO_DS_FUSE": "1", "RPE_WGRAD_FOLD_MAX": "128"},
 ]
 
 

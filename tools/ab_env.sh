@@ -1,5 +1,5 @@
 #!/bin/bash
-# Diagnostic: A/B one environment switch over bench.py runs on one box.  usage: tools/ab_env.sh VAR v1 v2 ... (results in gpurun_out/ab_VAR.txt)
+# Diagnostic: A/B one environment switch over bench.py runs on one box.  usage: tools/ab_env.sh VAR v1 v2 ... ('-' = unset) (results in gpurun_out/ab_VAR.txt)
 set -e
 var=$1; shift
 mkdir -p gpurun_out
@@ -7,6 +7,7 @@ out=gpurun_out/ab_$var.txt
 : > $out
 for v in "$@"; do
   echo "== $var=$v" >> $out
-  env $var=$v timeout -k 10 200 python bench.py --steps 30 --warmup 8 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])" >> $out
+  if [ "$v" = "-" ]; then unset $var; else export $var=$v; fi   # "-": the variable is unset for this run
+  timeout -k 10 200 python bench.py --steps 30 --warmup 8 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])" >> $out
 done
 cat $out
