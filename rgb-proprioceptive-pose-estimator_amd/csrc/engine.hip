@@ -37,6 +37,7 @@ struct ConvL {
 
 struct Block {
     int c1, c2, c3, cd;  // conv indices (cd = -1: identity shortcut)
+    float* gram = nullptr;   // fp32 [ones_row + 1][planes]: Gram matrix + column sums of conv3's input (BN3 statistics without y3)
     void* dz = nullptr;  // backward: ReLU-masked gradient at the block output (kept as the shortcut gradient)
     unsigned char* relu_mask = nullptr;  // 16-bit element types: packed ReLU mask of the block output (1 bit per element), written by its bn_apply
 };
@@ -113,6 +114,13 @@ struct rpe_resnet50 {
     // ([1..3]) handed over by the host for the next backward; stem_raw: the inference forward keeps conv1's raw output too
     const void* hook_grad[4] = {nullptr, nullptr, nullptr, nullptr};
     bool stem_raw = false;
+    // conv3 -> bn3 -> (+identity) -> ReLU as ONE launch: BN3's batch statistics follow from the Gram matrix of conv3's input
+    // (rpe_gram + rpe_bn_stats_from_gram), so the conv applies BN + residual + ReLU + mask in its own epilogue (16-bit types)
+    bool gram = false;
+    int gram_max = 256;          // widest conv3 input (planes) handled this way
+    bool gram_keep_y = true;     // the raw conv3 output is still written (its backward reads it)
+    void* gram_ws = nullptr;     // slab of the Gram launches (main stream)
+    long gram_ws_bytes = 0;
     void* sk_ws = nullptr;               // split-K workspace of the inference forward (rpe_conv2d_fwd_affine_ws); 0 bytes when no layer splits
     long sk_ws_bytes = 0;
     rpe_pack_desc* pack_tab_fold = nullptr;  // ... with the BN scale folded into the forward copy (inference)
@@ -312,6 +320,23 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
         want(e, &e->w_kcat, wk);
         want(e, (void**)&e->fold_bias, 512L * 4);
         want(e, &e->fold_scratch, e->fold_scratch_bytes);
+    }
+    // Experiment switch RPE_GRAM=1 (default off).  Measured at 256 images: with y3 still written (its backward reads it) 22.17 vs
+    // 21.98 ms/step -- the Gram launch + slab sum + statistics kernel sit on the forward's critical path (~28 us per block) and
+    // conv3 now reads the residual and writes two tensors; with y3 NOT written (RPE_GRAM_NO_Y=1, timing only) 21.87: -0.27 ms net,
+    // which a backward that recomputes y3 tiles in the fused data-gradient epilogue would have to add to -- not pursued.
+    e->gram = dtype != RPE_F32 && getenv("RPE_GRAM") != nullptr;
+    if (e->gram) {
+        if (getenv("RPE_GRAM_MAX")) e->gram_max = atoi(getenv("RPE_GRAM_MAX"));
+        if (getenv("RPE_GRAM_NO_Y")) e->gram_keep_y = false;   // (timing experiment only: the backward still reads y3)
+        for (auto& b : e->blocks) {
+            const ConvL& c3 = e->convs[b.c3];
+            if (c3.d.in_c > e->gram_max) continue;
+            want(e, (void**)&b.gram, (long)(rpe_gram_ones_row(c3.d.in_c) + 1) * c3.d.in_c * 4);
+            const long wsb = rpe_gram_workspace_bytes(dtype, c3.rows, c3.d.in_c);
+            if (wsb > e->gram_ws_bytes) e->gram_ws_bytes = wsb;
+        }
+        if (e->gram_ws_bytes > 0) want(e, &e->gram_ws, e->gram_ws_bytes);
     }
     if (!getenv("RPE_WGRAD_ATOMIC")) {
         for (size_t i = 1; i < e->convs.size(); ++i) {
@@ -722,6 +747,20 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
             if (e->split) HIPTRY(hipStreamWaitEvent(e->half, ds_done, 0));
         }
         static const bool use_mask = getenv("RPE_NO_RELU_MASK") == nullptr;
+        if (e->gram && training && !e->split && b.gram && use_mask && b.relu_mask && (b.cd < 0 || fuse_ds)) {
+            const ConvL* cdp = b.cd >= 0 ? &e->convs[b.cd] : nullptr;
+            e->pending_flops = 2.0 * (double)c3.rows * c3.d.in_c * c3.d.in_c;
+            e->pending_bytes = conv_in_bytes(e, c3);
+            PROF(e, RPE_PROF_BN_FWD, stream, rpe_gram(e->dtype, c2.a, c3.rows, c3.d.in_c, b.gram, e->gram_ws, e->gram_ws_bytes, stream));
+            e->pending_bytes = 0;
+            PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_stats_from_gram(e->dtype, c3.wf, c3.d.out_c, c3.d.in_c, b.gram, rpe_gram_ones_row(c3.d.in_c), c3.rows,
+                                                                    e->params[c3.p_g], e->params[c3.p_b], e->running[2 * c3.bn_i], e->running[2 * c3.bn_i + 1],
+                                                                    e->nbt[c3.bn_i], 0.1f, 1e-5f, c3.scale, c3.shift, c3.mean, c3.invstd, stream));
+            e->pending_flops = conv_flops(c3);
+            e->pending_bytes = conv_in_bytes(e, c3) + conv_out_bytes(e, c3) * (2.0 + (e->gram_keep_y ? 1.0 : 0.0) + 1.0 / 16);   // x, residual -> out (+ y) + mask
+            PROF(e, RPE_PROF_CONV_FWD, stream, rpe_conv1x1_fwd_bn(&c3.d, e->dtype, c2.a, c3.wf, c3.a, e->gram_keep_y ? c3.y : nullptr, c3.scale, c3.shift,
+                                                                 cdp ? cdp->y : idn, cdp ? cdp->scale : nullptr, cdp ? cdp->shift : nullptr, b.relu_mask, stream));
+        } else
         if (b.cd >= 0 && fuse_ds) TRY(conv_bn(e, c3, c2.a, e->convs[b.cd].y, 1, stream, false, use_mask ? b.relu_mask : nullptr, &e->convs[b.cd]));
         else
         TRY(conv_bn(e, c3, c2.a, idn, 1, stream, false, use_mask ? b.relu_mask : nullptr));   // (relu_mask is null for fp32 engines)

@@ -60,6 +60,12 @@ template <typename T> struct NTArgs {
                          // selects the epilogue variant compiled into the kernel and tags its symbol in profiles
     long a_elems;        // elements of the tensor behind A (conv modes; 0 = dense, derived from M and lda)
     unsigned a_bytes, b_bytes;   // buffer-descriptor extents of A and Bw (filled by the launcher, < 2 GiB each)
+    // role 5: training forward of a conv whose BatchNorm statistics are known BEFORE the launch (1x1 convs: from the Gram matrix of
+    // the input, rpe_bn_stats_from_gram): C = relu(acc * fwd_scale + fwd_shift + addend [* res_scale + res_shift]) with the packed
+    // ReLU mask (mask_out, 16-bit element types) -- the raw output is written only when y_out is set
+    const float *fwd_scale, *fwd_shift, *res_scale, *res_shift;
+    unsigned char* mask_out;
+    T* y_out;
     // Split-K form of the inference forward (few output tiles, long K: one rollout frame).  role 3 with `slab` set and
     // splits > 1 runs as role 4: grid.y = splits, workgroup (tile, z) walks K steps [z * split_steps, (z+1) * split_steps)
     // and stores its raw fp32 accumulators (fragment order) into slab[z][tile]; nt_split_epilogue_kernel then adds the
@@ -95,6 +101,7 @@ template <typename T> struct TNArgs {
     // all-ones P: its rows are the column sums of Q.  One launch then yields dz^T x, x^T x and colsum(x) (folded weight gradient).
     const T* P2;
     int ldp2, I1, I2, ones_i0;
+    int p_cols;     // without P2: the columns P really has (rows i >= p_cols of D stay zero up to the all-ones tile); 0 = I
     unsigned p2_bytes;
     float* slab;    // optional workspace of >= slab_bytes (16-byte aligned): per-workgroup fp32 tiles, summed by tn_reduce_kernel in a
     long slab_bytes;  // fixed order (deterministic, no float atomics); null -> atomic accumulation into D

@@ -356,13 +356,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_N == 4 && BN < 256) 
     const T* const e_addend = HAS_ADDEND ? p.addend : nullptr;
     const bool vec_add = VEC_ONLY ? (ncol_ok && e_addend != nullptr) : nfull && e_addend && (p.ld_add % CE == 0) && (((uintptr_t)e_addend) & 15) == 0;
     constexpr int bn_mode = HAS_BN ? BNM : 0;
-    const float* const e_bias = (HAS_AFFINE || ROLE == 1) ? p.bias : nullptr;   // (role 1: the constant term of a folded BN backward)
-    const int e_relu = HAS_AFFINE ? p.relu : 0;
+    const float* const e_bias = ((HAS_AFFINE && ROLE != 5) || ROLE == 1) ? p.bias : nullptr;   // (role 1: the constant term of a folded BN backward)
+    const int e_relu = (HAS_AFFINE && ROLE != 5) ? p.relu : 0;
     // Data-gradient launches with short K are bound by the epilogue's operand stream (residual gradient, y, a_out: up to
     // three reads and one write per output element against K/N-th of that for the GEMM operands).  One step at a time
     // keeps ~1-3 KB per wave in flight; here the operands of the next DEPTH steps are requested ahead (the first DEPTH
     // before the K loop even starts), 16 B per lane and operand, into registers that are recycled step by step.
-    constexpr bool PIPE = (ROLE == 1) && (CE == 8);
+    constexpr bool PIPE = (ROLE == 1 || ROLE == 5) && (CE == 8);
     constexpr int DEPTH = PIPE ? (NSTEP < RPE_EPI_DEPTH ? NSTEP : RPE_EPI_DEPTH) : 1;
     u32x4 qd[DEPTH], qy[DEPTH], qa[DEPTH];
     auto step_row = [&](int t) -> long { return out_row(wave_m * WM + (t / NPASS) * 16 + (t % NPASS) * RPP + erow); };
@@ -483,6 +483,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_N == 4 && BN < 256) 
             if (bn_mode == 2) { csc[j] = p.bn_scale[n + j]; csh[j] = p.bn_shift[n + j]; }
         }
     }
+    float fsc[8], fsh[8], frs[8];   // role 5: BN scale / shift of this layer (the shift carries the residual's shift) and the residual's scale
+    if constexpr (ROLE == 5) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            fsc[j] = 0.f; fsh[j] = 0.f; frs[j] = 1.f;
+            if (n + j < p.N) {
+                fsc[j] = p.fwd_scale[n + j];
+                fsh[j] = p.fwd_shift[n + j] + (p.res_shift ? p.res_shift[n + j] : 0.f);
+                if (p.res_scale) frs[j] = p.res_scale[n + j];
+            }
+        }
+    }
     auto load8 = [&](const T* base, long off, bool vec, float* out) {
         if (VEC_ONLY || vec) {
             if (CE == 8) { chunk_to_f<T>(ld16(base + off), out); }
@@ -526,6 +538,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_N == 4 && BN < 256) 
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += cbias[j];
                 }
+                if constexpr (ROLE == 5) {
+                    if (p.y_out) *(u32x4*)(p.y_out + m * p.ldc + n) = f_to_chunk<T>(v);   // (CE == 8: 16-bit element types only)
+                    float ad[8];
+                    if (e_addend) {
+                        if (PIPE && vec_add) chunk_to_f<T>(qd[sl], ad);
+                        else load8(e_addend, m * p.ld_add + n, vec_add, ad);
+                    }
+                    unsigned bits = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float t = fmaf(v[j], fsc[j], fsh[j]);
+                        if (e_addend) t = fmaf(ad[j], frs[j], t);
+                        bits |= (t > 0.f ? 1u : 0u) << j;
+                        v[j] = fmaxf(t, 0.f);
+                    }
+                    if (p.mask_out) p.mask_out[(m * p.ldc + n) >> 3] = (unsigned char)bits;
+                } else
                 if (e_addend) {
                     float ad[8];
                     if (PIPE && vec_add) chunk_to_f<T>(qd[sl], ad);
@@ -689,7 +718,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
     // which tensor this tile's P columns come from (uniform per workgroup): P, P2 (rows >= I1), or none (the all-ones tile)
     const bool ones_tile = DMA && MODE == MODE_DENSE && p.ones_i0 > 0 && i0 == p.ones_i0;
     const bool second_p = DMA && MODE == MODE_DENSE && p.P2 != nullptr && i0 >= p.I1 && !ones_tile;
-    const int p_col0 = second_p ? i0 - p.I1 : i0, p_cols = ones_tile ? 0 : (second_p ? p.I2 : (p.P2 ? p.I1 : p.I)), p_ld = second_p ? p.ldp2 : p.ldp;
+    const int p_col0 = second_p ? i0 - p.I1 : i0, p_cols = ones_tile ? 0 : (second_p ? p.I2 : (p.P2 ? p.I1 : (p.p_cols > 0 ? p.p_cols : p.I))), p_ld = second_p ? p.ldp2 : p.ldp;
     const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)(second_p ? p.P2 : p.P), 0, (int)(second_p ? p.p2_bytes : p.p_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)p.Q, 0, (int)p.q_bytes, 0x00020000);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -1080,6 +1109,18 @@ template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s) 
         return launch_nt_cfg<T, 2, 64, 4, MODE_STEM>(a, s);
     } else {
         if (a.role == 3 && a.slab && a.splits > 1) return launch_nt_split<T, MODE>(a, s);
+        if (a.role == 5) {   // 1x1 training forward with the BatchNorm apply fused (16-bit element types; rpe_conv1x1_fwd_bn)
+            if constexpr (MODE == MODE_DENSE && sizeof(T) == 2) {
+                if ((long)ceil_div(a.M, 128) * ceil_div(a.N, 128) < 96) {
+                    a.tiles_m = ceil_div(a.M, 64); a.tiles_n = ceil_div(a.N, 64);
+                    return launch_nt_role<T, 1, 64, 4, MODE_DENSE, 3, 5>(a, s, (long)a.tiles_m * a.tiles_n);
+                }
+                a.tiles_m = ceil_div(a.M, 128); a.tiles_n = ceil_div(a.N, 128);
+                return launch_nt_role<T, 2, 128, 4, MODE_DENSE, 3, 5>(a, s, (long)a.tiles_m * a.tiles_n);
+            } else {
+                return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: the fused-BN forward is a dense launch of a 16-bit element type");
+            }
+        }
         // 256-row / 8-wave tiles (1 workgroup per CU): measured on the ResNet shapes at bs256 they gain 3..10 % in isolation
         // for K >= 1024 and lose 10..25 % for short K, and LOSE overall inside the train step (fused epilogues, 2 waves/SIMD
         // in lockstep): 34.4 vs 32.9 ms/step.  Kept selectable for experiments (RPE_NT_BIG=1), off by default.
@@ -1190,6 +1231,10 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
     if (dma && (pb <= 0 || qb <= 0 || pb >= (1L << 31) || qb >= (1L << 31)))
         return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: an operand of 2 GiB or more (split the batch)");
     a.p_bytes = (unsigned)pb; a.q_bytes = (unsigned)qb;
+    if (!a.P2 && a.ones_i0 > 0) {   // P (p_cols columns) + the all-ones tile only: x^T x and colsum(x) in one launch
+        if (!dma || MODE != MODE_DENSE || a.p_cols <= 0 || a.p_cols > a.ones_i0 || (a.ones_i0 % BI))
+            return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: bad all-ones tile (dense DMA path, p_cols <= ones_i0, ones_i0 a multiple of the I tile)");
+    } else
     if (a.P2 || a.ones_i0 > 0) {
         const long p2b = (long)a.M * a.ldp2 * (long)sizeof(T);
         if (!dma || MODE != MODE_DENSE || !a.P2 || (a.I1 % BI) || (a.ones_i0 > 0 && (a.ones_i0 % BI)) || a.I1 <= 0 || a.I2 <= 0 || (a.ldp2 % Elem<T>::kChunk) ||

@@ -134,6 +134,39 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
     if (rl == 0 && c < C) fin(c, s, q);
 }
 
+// Batch statistics of y = x W^T (a 1x1 conv) WITHOUT y: mean_c = w_c . colsum(x) / M,  E[y_c^2] = w_c^T (x^T x) w_c / M.  gram: fp32
+// [rows >= Ci + 1][Ci] with x^T x in rows [0, Ci) and colsum(x) in row `ones_row` (rpe_gram); W is the compute-dtype copy the conv
+// multiplies with.  One block per output channel; the quadratic form is centred (S - s1 s1^T / M) and summed in double, the
+// threads' partial sums meet in a fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_gram_stats_kernel(const T* __restrict__ w, int Ci, const float* __restrict__ gram, int ones_row, const BnFwdFin fin) {
+    __shared__ float ws[1024];
+    __shared__ double red[2][256];
+    const int c = blockIdx.x;
+    for (int i = threadIdx.x; i < Ci; i += 256) ws[i] = Elem<T>::to_f(w[(long)c * Ci + i]);
+    __syncthreads();
+    const float* s1 = gram + (long)ones_row * Ci;
+    double q = 0.0, m = 0.0;
+    for (int i = threadIdx.x; i < Ci; i += 256) m += (double)ws[i] * (double)s1[i];
+    const double inv_count = 1.0 / fin.count;
+    for (int i = threadIdx.x >> 6; i < Ci; i += 4) {          // wave i-th row of S, lanes over its columns: coalesced
+        const float* row = gram + (long)i * Ci;
+        const double wi = ws[i], s1i = s1[i];
+        double r = 0.0;
+        for (int j = threadIdx.x & 63; j < Ci; j += 64) r += (double)ws[j] * ((double)row[j] - s1i * (double)s1[j] * inv_count);
+        q += wi * r;
+    }
+    red[0][threadIdx.x] = m;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sm = 0.0, sq = 0.0;
+        for (int i = 0; i < 256; ++i) { sm += red[0][i]; sq += red[1][i]; }
+        // fin expects (sum y, sum y^2): sum y^2 = centred form + (sum y)^2 / M
+        fin(c, sm, sq + sm * sm * inv_count);
+    }
+}
+
 __global__ void bn_eval_affine_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                       float* scale, float* shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -884,6 +917,21 @@ int rpe_bn_finalize(const float* part, int tiles, int C, long count, const float
     if (tiles <= 0 || C <= 0 || count <= 0) return rpe_set_error(RPE_ERR_SHAPE, "bn_finalize: empty problem");
     return reduce_finalize(part, tiles, C, dpart, BnFwdFin{(double)count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, scale,
                                                            shift, save_mean, save_invstd}, (hipStream_t)stream);
+}
+
+int rpe_bn_stats_from_gram(int dtype, const void* w, int Co, int Ci, const float* gram, int ones_row, long count, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, long long* num_batches, float momentum, float eps, float* scale, float* shift,
+                           float* save_mean, float* save_invstd, void* stream) {
+    note_kernel("bn_gram_stats_kernel");
+    if (!w || !gram || Co <= 0 || Ci <= 0 || Ci > 1024 || count <= 0 || ones_row < Ci) return rpe_set_error(RPE_ERR_SHAPE, "bn_stats_from_gram: bad arguments (in_c <= 1024)");
+    const BnFwdFin fin{(double)count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, scale, shift, save_mean, save_invstd};
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == RPE_F32) hipLaunchKernelGGL((bn_gram_stats_kernel<float>), dim3(Co), dim3(256), 0, s, (const float*)w, Ci, gram, ones_row, fin);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((bn_gram_stats_kernel<bf16>), dim3(Co), dim3(256), 0, s, (const bf16*)w, Ci, gram, ones_row, fin);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((bn_gram_stats_kernel<f16>), dim3(Co), dim3(256), 0, s, (const f16*)w, Ci, gram, ones_row, fin);
+    else return rpe_set_error(RPE_ERR_DTYPE, "bn_stats_from_gram: unsupported dtype");
+    RPE_CHECK_LAUNCH();
+    return 0;
 }
 
 int rpe_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,

@@ -42,7 +42,7 @@ def test_kernel_variant_parity(env, subset):
 
 # schedule / fusion switches of the trunk engine: one golden train step per model family must still match the reference
 ENGINE_VARIANTS = [
-    {"RPE_NO_OVERLAP": "1"},        # everything on one stream
+    {"RPE_NO_OVERLAP": "1", "RPE_GRAM": "1"},        # everything on one stream; BN3 statistics from the Gram matrix of conv3's input (16-bit types)
     # projection-shortcut branch on the main stream; dense early-feature gradient + separate pool / BN backward passes for the
     # stem; conv3 backward through a materialised dy on the main stream
     {"RPE_NO_FWD_OVERLAP": "1", "RPE_STEM_UNFUSED": "1", "RPE_NO_BN_FOLD": "1"},
@@ -60,7 +60,7 @@ def test_engine_variant_parity(env):
     child_env = dict(os.environ)
     child_env.update(env)
     cmd = [sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_models.py"), "-q", "-x", "-p", "no:cacheprovider", "-k",
-           "test_model_fp32_matches_reference_and_oracle and tdo_v2"]
+           "(test_model_fp32_matches_reference_and_oracle and tdo_v2) or test_model_bf16_tracks_fp32_reference"]   # (fp32 golden step + the 16-bit path)
     r = subprocess.run(cmd, env=child_env, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=900)
     tail = (r.stdout or "")[-3000:] + (r.stderr or "")[-1000:]
     assert r.returncode == 0, "variant %r failed:\n%s" % (env, tail)
