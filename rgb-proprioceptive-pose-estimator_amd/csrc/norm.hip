@@ -191,7 +191,7 @@ template <bool NT> __device__ inline void st16(void* p, const u32x4& v) {
 
 // gridDim.x * 256 is a multiple of C/CE (launcher), so a thread's channel chunk is fixed and scale/shift live in registers;
 // UNR independent 16-byte loads per operand are issued before any of them is consumed.
-template <typename T, int UNR, bool NT>
+template <typename T, int UNR, bool NT, bool RESBN = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ out,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
                                                       long nchunks, int C, int relu, unsigned char* __restrict__ mask,
@@ -207,8 +207,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
 #pragma unroll
     for (int e = 0; e < CE; ++e) {
         sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e];
-        rs[e] = res_scale ? res_scale[c0 + e] : 1.f;
-        if (res_scale) sh[e] += res_shift[c0 + e];
+        rs[e] = 1.f;
+        if (RESBN) { rs[e] = res_scale[c0 + e]; sh[e] += res_shift[c0 + e]; }
     }
     for (long i = i0; i < nchunks; i += stride * UNR) {
         u32x4 vy[UNR], vr[UNR];
@@ -231,7 +231,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
 #pragma unroll
             for (int e = 0; e < CE; ++e) {
                 float t = fmaf(v[e], sc[e], sh[e]);  // same expression as the fused dgrad epilogue's mask
-                if (res) t = res_scale ? fmaf(r[e], rs[e], t) : t + r[e];
+                if (RESBN) t = fmaf(r[e], rs[e], t);     // (a compile-time variant: the plain residual add keeps its code)
+                else if (res) t += r[e];
                 v[e] = relu ? fmaxf(t, 0.f) : t;
                 bits |= (t > 0.f ? 1u : 0u) << e;
             }
@@ -806,9 +807,13 @@ int bn_apply_launch(const void* y, const void* res, void* out, const float* scal
     const long g = ew_grid_rows(n, cpr, cfg);
     if ((g * 256) % cpr) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply: C/chunk must divide grid*256 (power-of-two channel counts)");
     if (mask && sizeof(T) != 2) return rpe_set_error(RPE_ERR_DTYPE, "bn_apply_mask: the packed ReLU mask is written for 16-bit element types only");
-#define RPE_BN_APPLY(U, N) hipLaunchKernelGGL((bn_apply_kernel<T, U, N>), dim3((unsigned)g), dim3(256), 0, s, (const T*)y, (const T*)res, (T*)out, scale, shift, n, C, relu, mask, res_scale, res_shift)
-    if (cfg.nt) { if (cfg.unr == 1) RPE_BN_APPLY(1, true); else if (cfg.unr == 2) RPE_BN_APPLY(2, true); else RPE_BN_APPLY(4, true); }
-    else { if (cfg.unr == 1) RPE_BN_APPLY(1, false); else if (cfg.unr == 2) RPE_BN_APPLY(2, false); else RPE_BN_APPLY(4, false); }
+#define RPE_BN_APPLY(U, N, R) hipLaunchKernelGGL((bn_apply_kernel<T, U, N, R>), dim3((unsigned)g), dim3(256), 0, s, (const T*)y, (const T*)res, (T*)out, scale, shift, n, C, relu, mask, res_scale, res_shift)
+    if (res_scale) {   // the residual under its own BatchNorm (rpe_bn_apply_res_bn): one configuration
+        if (!res || !res_shift) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply: the residual and its shift are required with res_scale");
+        RPE_BN_APPLY(4, false, true);
+    }
+    else if (cfg.nt) { if (cfg.unr == 1) RPE_BN_APPLY(1, true, false); else if (cfg.unr == 2) RPE_BN_APPLY(2, true, false); else RPE_BN_APPLY(4, true, false); }
+    else { if (cfg.unr == 1) RPE_BN_APPLY(1, false, false); else if (cfg.unr == 2) RPE_BN_APPLY(2, false, false); else RPE_BN_APPLY(4, false, false); }
 #undef RPE_BN_APPLY
     RPE_CHECK_LAUNCH();
     return 0;
