@@ -176,9 +176,87 @@ __global__ __launch_bounds__(256) void bn_fold_g_kernel(const float* __restrict_
     wk[(long)n * (Co + Ci) + Co + np] = Elem<T>::from_f(g[(long)np * Ci + n]);
 }
 
+// The whole fold preparation in ONE launch (it sits on the data-gradient chain, once per bottleneck block: the four-launch form --
+// scale, G GEMM, slab sum, transpose-convert -- cost ~40 us there).  Blocks [0, (Ci/64)^2): a 64 x 64 tile of
+// G[n][n'] = sum_k wd[n][k] C'_k wd[n'][k] on the matrix cores straight from global memory (the weights are L2-resident; 4 waves
+// of 32 x 32, the C' scaling applied to the n' operand in registers), written as wk[n][Co + n'].  The remaining blocks: four rows n
+// of wk[n][k] = A_k wd[n][k] and bias[n] = sum_k B'_k wd[n][k] each.  wd = [Ci][Co], the data-gradient copy of the weight.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_fold_fused_kernel(const T* __restrict__ wd, const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                           const float* __restrict__ mean, const float* __restrict__ c1, const float* __restrict__ c2,
+                                                           T* __restrict__ wk, float* __restrict__ bias, int Co, int Ci) {
+    constexpr int CE = Elem<T>::kChunk, KS = 4 * CE;
+    extern __shared__ float cp_s[];   // C'_k = -gamma_k invstd_k^2 c2_k
+    const int gt = Ci / 64, nG = gt * gt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long ldk = (long)Co + Ci;
+    if ((int)blockIdx.x < nG) {
+        for (int k = threadIdx.x; k < Co; k += 256) cp_s[k] = -gamma[k] * invstd[k] * invstd[k] * c2[k];
+        __syncthreads();
+        const int bi = blockIdx.x / gt, bj = blockIdx.x - bi * gt;
+        const int i0 = bi * 64 + (wave >> 1) * 32, j0 = bj * 64 + (wave & 1) * 32;   // rows n (plain operand) / columns n' (scaled operand)
+        const int fr = lane & 15, fc = lane >> 4;
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k0 = 0; k0 < Co; k0 += KS) {
+            const int k = k0 + fc * CE;
+            u32x4 am[2], bn[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) am[mi] = *(const u32x4*)(wd + (long)(i0 + mi * 16 + fr) * Co + k);
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) {
+                float v[CE];
+                chunk_to_f<T>(*(const u32x4*)(wd + (long)(j0 + nj * 16 + fr) * Co + k), v);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) v[e] *= cp_s[k + e];
+                bn[nj] = f_to_chunk<T>(v);
+            }
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) Mma<T>::run(bn[nj], am[mi], acc[nj][mi]);
+        }
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                T* dst = wk + (long)(i0 + mi * 16 + fr) * ldk + Co + j0 + nj * 16 + fc * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[e] = Elem<T>::from_f(acc[nj][mi][e]);
+            }
+        return;
+    }
+    const int row = ((int)blockIdx.x - nG) * 4 + wave;
+    if (row >= Ci) return;
+    float acc = 0.f;
+    for (int k = lane; k < Co; k += 64) {
+        const float a = gamma[k] * invstd[k];
+        const float cp = -a * invstd[k] * c2[k];
+        const float bp = -a * c1[k] - cp * mean[k];
+        const float w = Elem<T>::to_f(wd[(long)row * Co + k]);
+        wk[(long)row * ldk + k] = Elem<T>::from_f(a * w);
+        acc = fmaf(bp, w, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) bias[row] = acc;
+}
+
 template <typename T>
 static int bn_fold_t(int Co, int Ci, const void* wf, const void* wd, const float* gamma, const float* invstd, const float* mean, const float* c1c2,
                      void* w_kcat, float* bias, void* scratch, long scratch_bytes, hipStream_t s) {
+    static const bool unfused = getenv("RPE_FOLD_PREP_UNFUSED") != nullptr;
+    if (!unfused && (Ci % 64) == 0 && (Co % (4 * Elem<T>::kChunk)) == 0 && Co <= 8192) {
+        const int gt = Ci / 64;
+        hipLaunchKernelGGL((bn_fold_fused_kernel<T>), dim3(gt * gt + (Ci + 3) / 4), dim3(256), (size_t)Co * 4, s, (const T*)wd, gamma, invstd, mean, c1c2,
+                           c1c2 + Co, (T*)w_kcat, bias, Co, Ci);
+        RPE_CHECK_LAUNCH();
+        note_kernel("bn_fold_fused_kernel");
+        return 0;
+    }
     // scratch: pm [Co][Ci] T | g [Ci][Ci] fp32 | slab of the G GEMM
     const long pm_bytes = ((long)Co * Ci * (long)sizeof(T) + 255) / 256 * 256, g_bytes = ((long)Ci * Ci * 4 + 255) / 256 * 256;
     TNArgs<T> a;

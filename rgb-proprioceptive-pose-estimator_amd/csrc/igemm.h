@@ -6,6 +6,31 @@ namespace rpe {
 
 enum { MODE_DENSE = 0, MODE_CONV = 1, MODE_STEM = 2 };
 
+// one 16 x 16 MFMA step over a 16-byte chunk per lane and operand (32 K elements of a 16-bit type, 16 of fp32): first operand =
+// the N side, second = the M side; acc element e of lane l is (row l & 15 of M, column 4 * (l >> 4) + e of N)
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+    __device__ static __forceinline__ void run(const u32x4& w, const u32x4& a, f32x4& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<f16> {
+    __device__ static __forceinline__ void run(const u32x4& w, const u32x4& a, f32x4& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // lane (row = l&15, g = l>>4) holds k = 4g..4g+3 of its row; step kk multiplies component kk
+    // of both operands, i.e. the K order inside a 16-wide step is permuted identically on both sides.
+    __device__ static __forceinline__ void run(const u32x4& w, const u32x4& a, f32x4& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.x), __uint_as_float(a.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.y), __uint_as_float(a.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.z), __uint_as_float(a.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.w), __uint_as_float(a.w), acc, 0, 0, 0);
+    }
+};
+
+
 // How row m and column k of the implicit "im2col" matrix map onto an NHWC tensor.
 //   m = (b*Ho + oh)*Wo + ow ;  k = (r*S + s)*C + c
 //   numerator  nh = oh*sn + base_h + tap_sign*r   (same for w)

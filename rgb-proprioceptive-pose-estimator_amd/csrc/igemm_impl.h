@@ -39,28 +39,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-template <typename T> struct Mma;
-template <> struct Mma<bf16> {
-    __device__ static __forceinline__ void run(const u32x4& w, const u32x4& a, f32x4& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
-    }
-};
-template <> struct Mma<f16> {
-    __device__ static __forceinline__ void run(const u32x4& w, const u32x4& a, f32x4& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
-    }
-};
-template <> struct Mma<float> {
-    // lane (row = l&15, g = l>>4) holds k = 4g..4g+3 of its row; step kk multiplies component kk
-    // of both operands, i.e. the K order inside a 16-wide step is permuted identically on both sides.
-    __device__ static __forceinline__ void run(const u32x4& w, const u32x4& a, f32x4& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.x), __uint_as_float(a.x), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.y), __uint_as_float(a.y), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.z), __uint_as_float(a.z), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.w), __uint_as_float(a.w), acc, 0, 0, 0);
-    }
-};
-
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *(const u32x4*)p; }
 __device__ __forceinline__ u32x4 zero16() { u32x4 z = {0u, 0u, 0u, 0u}; return z; }
 
