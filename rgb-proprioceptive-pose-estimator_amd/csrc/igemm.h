@@ -60,7 +60,6 @@ template <typename T> struct NTArgs {
     // folded in: dx = [dz | a_in] * [A o W ; G]^T (rpe_bn_bwd_fold_conv1x1).
     const T* A2;
     int lda2, K1;
-    unsigned a2_bytes;
     const T* Bw;    // weights [N][ldb], K contiguous
     T* C;           // output [M][ldc]
     int M, N, K;
@@ -83,8 +82,8 @@ template <typename T> struct NTArgs {
     int nt_store;        // epilogue output stores non-temporal (streamed once, re-read only after >= its own size of other traffic)
     int role;            // 0 conv forward (training), 1 conv data gradient, 2 Linear, 3 conv forward (inference: bias/addend/ReLU):
                          // selects the epilogue variant compiled into the kernel and tags its symbol in profiles
-    long a_elems;        // elements of the tensor behind A (conv modes; 0 = dense, derived from M and lda)
-    unsigned a_bytes, b_bytes;   // buffer-descriptor extents of A and Bw (filled by the launcher, < 2 GiB each)
+    long a_elems;        // elements of the tensor behind A (conv modes: set by the caller; dense: M * lda, filled by the launcher)
+    unsigned b_bytes;    // buffer-descriptor extent of Bw (filled by the launcher, < 2 GiB)
     // role 5: training forward of a conv whose BatchNorm statistics are known BEFORE the launch (1x1 convs: from the Gram matrix of
     // the input, rpe_bn_stats_from_gram): C = relu(acc * fwd_scale + fwd_shift + addend [* res_scale + res_shift]) with the packed
     // ReLU mask (mask_out, 16-bit element types) -- the raw output is written only when y_out is set
@@ -127,7 +126,6 @@ template <typename T> struct TNArgs {
     const T* P2;
     int ldp2, I1, I2, ones_i0;
     int p_cols;     // without P2: the columns P really has (rows i >= p_cols of D stay zero up to the all-ones tile); 0 = I
-    unsigned p2_bytes;
     float* slab;    // optional workspace of >= slab_bytes (16-byte aligned): per-workgroup fp32 tiles, summed by tn_reduce_kernel in a
     long slab_bytes;  // fixed order (deterministic, no float atomics); null -> atomic accumulation into D
     int accumulate;   // slab mode: D += sum instead of D = sum
@@ -136,8 +134,7 @@ template <typename T> struct TNArgs {
     Gather g;
     int tiles_i, tiles_j, splits;
     int rows_per_split;  // multiple of the m-step
-    long q_elems;        // elements of the tensor behind Q (conv modes; dense: derived from M and ldq)
-    unsigned p_bytes, q_bytes;   // buffer-descriptor extents (filled by the launcher, < 2 GiB each)
+    long q_elems;        // elements of the tensor behind Q (conv modes: set by the caller; dense: M * ldq, filled by the launcher)
 };
 
 }  // namespace rpe

@@ -21,16 +21,17 @@ template <typename T> int launch_nt(NTArgs<T>& a, int mode, hipStream_t s) {
     if (mode == MODE_CONV && (a.g.C % (8 * CE))) return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: conv channels must be a multiple of 8 chunks");
     if (mode != MODE_STEM) {
         // buffer-descriptor extents of the two DMA operands; rows that must read as zero use offset 2^31, so both stay below it
-        const long ab = (mode == MODE_DENSE ? (long)a.M * a.lda : a.a_elems) * (long)sizeof(T), bb = (long)a.N * a.ldb * (long)sizeof(T);
-        if (ab <= 0 || bb <= 0 || ab >= (1L << 31) || bb >= (1L << 31))
-            return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: an operand of 2 GiB or more (split the batch)");
-        a.a_bytes = (unsigned)ab; a.b_bytes = (unsigned)bb;
+        // the activation operand may be of any size: the kernel's descriptors start at each tile's first row (dense) / first image
+        // (conv), so only ONE tile's span has to stay below 2 GiB; the weights use one descriptor
+        if (mode == MODE_DENSE) a.a_elems = (long)a.M * a.lda;
+        const long bb = (long)a.N * a.ldb * (long)sizeof(T);
+        const long tile_span = (mode == MODE_DENSE ? 256L * (a.lda > a.lda2 ? a.lda : a.lda2) : (256L / (a.g.Ho * a.g.Wo > 0 ? a.g.Ho * a.g.Wo : 1) + 2) * a.g.img_stride) * (long)sizeof(T);
+        if (a.a_elems <= 0 || bb <= 0 || bb >= (1L << 31) || tile_span >= (1L << 31))
+            return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: the weight operand or one tile of the activation operand spans 2 GiB or more");
+        a.b_bytes = (unsigned)bb;
         if (a.A2) {
-            const long a2b = (long)a.M * a.lda2 * (long)sizeof(T);
-            if (mode != MODE_DENSE || a.role != 1 || a.K1 <= 0 || a.K1 >= a.K || (a.K1 % (8 * CE)) || (a.lda2 % CE) || (((uintptr_t)a.A2) & 15) || a2b <= 0 || a2b >= (1L << 31))
-                return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: bad K-concatenated operand (dense data-gradient role, K1 a multiple of 8 chunks, < 2 GiB)");
-            a.a2_bytes = (unsigned)a2b;
-            if ((long)a.M * a.lda * (long)sizeof(T) >= (1L << 31)) return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: an operand of 2 GiB or more (split the batch)");
+            if (mode != MODE_DENSE || a.role != 1 || a.K1 <= 0 || a.K1 >= a.K || (a.K1 % (8 * CE)) || (a.lda2 % CE) || (((uintptr_t)a.A2) & 15))
+                return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: bad K-concatenated operand (dense data-gradient role, K1 a multiple of 8 chunks)");
         }
     }
     if (a.role != 2) {

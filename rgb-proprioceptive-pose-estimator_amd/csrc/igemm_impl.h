@@ -156,6 +156,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_N == 4 && BN < 256) 
     // get voffset = 0x80000000: beyond num_records (< 2 GiB, checked by the launcher), the hardware range check returns 0.
     constexpr unsigned OOB = 0x80000000u;
     constexpr int ES = (int)sizeof(T);
+    // The A descriptors start at THIS tile's first row (dense) / first image (conv), so the 32-bit offsets span one tile and a
+    // tensor may be of any size (round 1 capped a tensor at 2 GiB = ~1300 images in bf16); num_records = the bytes from there to
+    // the end of the tensor, clamped below 2^31 (a tile never reaches that far, and rows past M are masked by a_ok anyway).
+    const unsigned tile_b0 = (MODE == MODE_CONV) ? (unsigned)__builtin_amdgcn_readfirstlane((int)fd_div((unsigned)(m0 < row_lim ? m0 : 0), g.div_hw)) : 0u;
+    const long tile_a = (MODE == MODE_DENSE) ? (long)m0 * p.lda : (long)tile_b0 * g.img_stride;     // elements
     unsigned a_voff[AR], b_voff[BR], a_vbase[AR];
     long a_base[AR];
     int a_hb[AR], a_wb[AR];
@@ -168,16 +173,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_N == 4 && BN < 256) 
         a_voff[i] = OOB; a_vbase[i] = 0;
         if (MODE == MODE_DENSE) {
             a_base[i] = (long)m * p.lda + a_chunk[i] * CE;
-            if (a_ok[i]) a_voff[i] = (unsigned)(a_base[i] * ES);
+            if (a_ok[i]) a_voff[i] = (unsigned)(((long)a_row[i] * p.lda + a_chunk[i] * CE) * ES);   // relative to the tile's first row (tile_a)
         } else {
-            const unsigned mm = a_ok[i] ? (unsigned)m : 0u;
+            const unsigned mm = a_ok[i] ? (unsigned)m : (unsigned)m0;
             const unsigned b = fd_div(mm, g.div_hw);
             const unsigned rem = mm - b * g.div_hw.d;
             unsigned oh = fd_div(rem, g.div_w);
             unsigned ow = rem - oh * g.div_w.d;
             if (MODE == MODE_CONV && g.parity) { oh = 2 * oh + ph; ow = 2 * ow + pw; }
             a_base[i] = (long)b * g.img_stride;
-            a_vbase[i] = (unsigned)((a_base[i] + a_chunk[i] * CE) * ES);
+            a_vbase[i] = (unsigned)(((long)(b - tile_b0) * g.img_stride + a_chunk[i] * CE) * ES);   // relative to the tile's first image
             a_hb[i] = (int)oh * g.sn + g.base_h;
             a_wb[i] = (int)ow * g.sn + g.base_w;
         }
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_N == 4 && BN < 256) 
     unsigned a_voff2[AR];
     if (KCAT) {
 #pragma unroll
-        for (int i = 0; i < AR; ++i) a_voff2[i] = (a_ok[i] && p.A2) ? (unsigned)(((long)(m0 + a_row[i]) * p.lda2 + a_chunk[i] * CE) * ES) : OOB;
+        for (int i = 0; i < AR; ++i) a_voff2[i] = (a_ok[i] && p.A2) ? (unsigned)(((long)a_row[i] * p.lda2 + a_chunk[i] * CE) * ES) : OOB;
     }
     long b_off[BR];
     bool b_ok[BR];
@@ -262,9 +267,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_N == 4 && BN < 256) 
     typedef __attribute__((address_space(3))) char lds_char;
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void lds_void;
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+    auto clamp31 = [](long bytes) -> int { return (int)(bytes < 0 ? 0 : (bytes > 0x7fffffffL ? 0x7fffffffL : bytes)); };
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + tile_a), 0, clamp31((p.a_elems - tile_a) * ES), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bw, 0, (int)p.b_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(KCAT && p.A2 ? p.A2 : p.A), 0, (int)(KCAT && p.A2 ? p.a2_bytes : p.a_bytes), 0x00020000);
+    const long tile_a2 = (long)m0 * p.lda2;
+    const __amdgpu_buffer_rsrc_t rs_a2 = (KCAT && p.A2) ? __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 + tile_a2), 0, clamp31(((long)p.M * p.lda2 - tile_a2) * ES), 0x00020000) : rs_a;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // provably uniform: the LDS base of a DMA goes through M0
     const bool ktail = (p.K % BK) != 0;                        // dense only (conv: C % BK == 0, checked by the launcher)
     auto dma_tile = [&](int st) {
@@ -697,8 +704,14 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
     const bool ones_tile = DMA && MODE == MODE_DENSE && p.ones_i0 > 0 && i0 == p.ones_i0;
     const bool second_p = DMA && MODE == MODE_DENSE && p.P2 != nullptr && i0 >= p.I1 && !ones_tile;
     const int p_col0 = second_p ? i0 - p.I1 : i0, p_cols = ones_tile ? 0 : (second_p ? p.I2 : (p.P2 ? p.I1 : (p.p_cols > 0 ? p.p_cols : p.I))), p_ld = second_p ? p.ldp2 : p.ldp;
-    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)(second_p ? p.P2 : p.P), 0, (int)(second_p ? p.p2_bytes : p.p_bytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)p.Q, 0, (int)p.q_bytes, 0x00020000);
+    // the descriptors start at this split's first row (dense) / first image (conv operand): 32-bit offsets span one split, tensors may
+    // be of any size; num_records = the bytes from there to the end of the tensor, clamped below 2^31 (see nt_kernel)
+    auto clamp31 = [](long bytes) -> int { return (int)(bytes < 0 ? 0 : (bytes > 0x7fffffffL ? 0x7fffffffL : bytes)); };
+    const long p_tile = (long)m_begin * p_ld;
+    const unsigned q_b0 = (MODE == MODE_CONV) ? (unsigned)__builtin_amdgcn_readfirstlane((int)fd_div((unsigned)m_begin, g.div_hw)) : 0u;
+    const long q_tile = (MODE == MODE_CONV) ? (long)q_b0 * g.img_stride : (long)m_begin * p.ldq;
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)((second_p ? p.P2 : p.P) + p_tile), 0, clamp31(((long)p.M * p_ld - p_tile) * (long)sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Q + q_tile), 0, clamp31((p.q_elems - q_tile) * (long)sizeof(T)), 0x00020000);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     unsigned p_voff[NPI], q_voff[NPJ];
     int q_cc[NPJ];
@@ -720,7 +733,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
         for (int i = 0; i < NPI; ++i) {
             const int row = p_r + i * RPI;
             const int cc = p_slot ^ tn_swz<T, CPI>(row);
-            p_voff[i] = (p_col0 + cc * CE) < p_cols ? (unsigned)(((long)(m_begin + row) * p_ld + p_col0 + cc * CE) * ES) : OOB;
+            p_voff[i] = (p_col0 + cc * CE) < p_cols ? (unsigned)(((long)row * p_ld + p_col0 + cc * CE) * ES) : OOB;
         }
 #pragma unroll
         for (int i = 0; i < NPJ; ++i) {
@@ -729,11 +742,12 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
             q_okc[i] = (j0 + q_cc[i] * CE) < p.J;
             q_voff[i] = OOB;
             q_b[i] = q_oh[i] = q_ow[i] = 0;
-            if (MODE == MODE_DENSE && q_okc[i]) q_voff[i] = (unsigned)(((long)(m_begin + row) * p.ldq + j0 + q_cc[i] * CE) * ES);
+            if (MODE == MODE_DENSE && q_okc[i]) q_voff[i] = (unsigned)(((long)row * p.ldq + j0 + q_cc[i] * CE) * ES);
             if (MODE == MODE_CONV) {
                 const unsigned m = (unsigned)(m_begin + row);
-                q_b[i] = fd_div(m, g.div_hw);
-                const unsigned rem = m - q_b[i] * g.div_hw.d;
+                const unsigned bb = fd_div(m, g.div_hw);
+                q_b[i] = bb - q_b0;                                  // image index relative to the split's first image
+                const unsigned rem = m - bb * g.div_hw.d;
                 q_oh[i] = fd_div(rem, g.div_w);
                 q_ow[i] = rem - q_oh[i] * g.div_w.d;
             }
@@ -1205,10 +1219,13 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
     if (slab_query) { *slab_query = slab_bytes; return 0; }
     if (a.slab && a.slab_bytes < slab_bytes) a.slab = nullptr;   // too small a workspace: atomic accumulation
     // buffer-descriptor extents (DMA path): rows past M must fall outside them, padding uses offset 2^31
-    const long pb = (long)a.M * a.ldp * (long)sizeof(T), qb = (MODE == MODE_DENSE ? (long)a.M * a.ldq : a.q_elems) * (long)sizeof(T);
-    if (dma && (pb <= 0 || qb <= 0 || pb >= (1L << 31) || qb >= (1L << 31)))
-        return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: an operand of 2 GiB or more (split the batch)");
-    a.p_bytes = (unsigned)pb; a.q_bytes = (unsigned)qb;
+    // (tensors of any size: the kernel's descriptors start at each split's first row / image; a split itself must stay below 2 GiB)
+    if (MODE == MODE_DENSE) a.q_elems = (long)a.M * a.ldq;
+    {
+        const long span = (long)a.rows_per_split * (a.ldp > a.ldq ? a.ldp : a.ldq) * (long)sizeof(T);
+        const long span_q = MODE == MODE_DENSE ? 0 : ((long)a.rows_per_split / (a.g.Ho * a.g.Wo) + 2) * a.g.img_stride * (long)sizeof(T);
+        if (dma && (span >= (1L << 31) || span_q >= (1L << 31))) return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: one split of the reduction spans 2 GiB or more");
+    }
     if (!a.P2 && a.ones_i0 > 0) {   // P (p_cols columns) + the all-ones tile only: x^T x and colsum(x) in one launch
         if (!dma || MODE != MODE_DENSE || a.p_cols <= 0 || a.p_cols > a.ones_i0 || (a.ones_i0 % BI))
             return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: bad all-ones tile (dense DMA path, p_cols <= ones_i0, ones_i0 a multiple of the I tile)");
@@ -1216,9 +1233,8 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
     if (a.P2 || a.ones_i0 > 0) {
         const long p2b = (long)a.M * a.ldp2 * (long)sizeof(T);
         if (!dma || MODE != MODE_DENSE || !a.P2 || (a.I1 % BI) || (a.ones_i0 > 0 && (a.ones_i0 % BI)) || a.I1 <= 0 || a.I2 <= 0 || (a.ldp2 % Elem<T>::kChunk) ||
-            (((uintptr_t)a.P2) & 15) || p2b <= 0 || p2b >= (1L << 31))
+            (((uintptr_t)a.P2) & 15) || p2b <= 0)
             return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: bad row-concatenated P operand (dense DMA path, I1 / ones_i0 multiples of the I tile)");
-        a.p2_bytes = (unsigned)p2b;
     }
     snprintf(g_last_kernel, sizeof(g_last_kernel), "tn_kernel<%s,%d,%d,%d,%d,%d,%d,%d>", Elem<T>::kName, BI, BJ, MODE, dma ? 1 : 0, dma ? ksub : 1,
              dma ? nslot : 2, a.slab ? 1 : 0);

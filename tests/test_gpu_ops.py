@@ -704,6 +704,50 @@ def test_conv1x1_forward_with_bn_from_gram(dtype, cfg, shortcut):
     assert none is None and torch.equal(out2, out) and torch.equal(mask2, mask)
 
 
+def test_operands_above_2_gib():
+    """Round 1 capped a tensor at 2 GiB (32-bit byte offsets against one buffer descriptor: ~1300 images per process in bf16).  The
+    descriptors now start at each tile's / split's first row or image: convs whose activation tensors exceed 2 GiB must equal the same
+    convs run on their two halves (forward, data gradient, weight gradient; 1x1 dense and 3x3 gathered)."""
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(3)
+    b, h, ci, co = 1400, 28, 1024, 64                                  # 1x1: x [1400,28,28,1024] = 2.25 GB in, 64 channels out
+    x = torch.randn(b // 2, h, h, ci, generator=g).to(dtype)
+    x = torch.cat([x, x.flip(0)], 0).to(DEV)                          # 2.25 GB on the device
+    assert x.numel() * 2 > (1 << 31)
+    w = (torch.randn(co, 1, 1, ci, generator=g) / ci ** 0.5).to(dtype).to(DEV)
+    y = ops.conv2d_fwd(x, w, 1, 0)
+    hb = b // 2
+    y0 = ops.conv2d_fwd(x[:hb].contiguous(), w, 1, 0)
+    y1 = ops.conv2d_fwd(x[hb:].contiguous(), w, 1, 0)
+    assert torch.equal(y[:hb], y0) and torch.equal(y[hb:], y1)
+    # weight gradient reading the > 2 GiB activation tensor (dense TN): equals the sum of the halves' gradients
+    dy = torch.randn(b, h, h, co, generator=g).to(dtype).to(DEV)
+    dw = ops.conv2d_wgrad(x, dy, 1, 1, 0)
+    dwh = ops.conv2d_wgrad(x[:hb].contiguous(), dy[:hb].contiguous(), 1, 1, 0) + ops.conv2d_wgrad(x[hb:].contiguous(), dy[hb:].contiguous(), 1, 1, 0)
+    assert rel_err(dw, dwh) < 1e-3
+    # data gradient WRITING a > 2 GiB tensor from a small dy (dense NT, role 1)
+    wd = w.reshape(co, ci).t().contiguous().reshape(ci, 1, 1, co)
+    dx = ops.conv2d_dgrad(dy, wd, tuple(x.shape), 1, 0)
+    dx0 = ops.conv2d_dgrad(dy[:hb].contiguous(), wd, (hb, h, h, ci), 1, 0)
+    assert torch.equal(dx[:hb], dx0)
+    assert torch.equal(dx[hb:], ops.conv2d_dgrad(dy[hb:].contiguous(), wd, (hb, h, h, ci), 1, 0))
+    del dx, dx0, x, y, y0, y1, dw, dwh
+    torch.cuda.empty_cache()
+    # 3x3 gathered forward + weight gradient over a > 2 GiB input: [1400,56,56,256] = 2.25 GB
+    ci3, co3, h3 = 256, 64, 56
+    x3 = torch.randn(b // 2, h3, h3, ci3, generator=g).to(dtype)
+    x3 = torch.cat([x3, x3.flip(0)], 0).to(DEV)
+    assert x3.numel() * 2 > (1 << 31)
+    w3 = (torch.randn(co3, 3, 3, ci3, generator=g) / (9 * ci3) ** 0.5).to(dtype).to(DEV)
+    y3 = ops.conv2d_fwd(x3, w3, 1, 1)
+    assert torch.equal(y3[:hb], ops.conv2d_fwd(x3[:hb].contiguous(), w3, 1, 1))
+    assert torch.equal(y3[hb:], ops.conv2d_fwd(x3[hb:].contiguous(), w3, 1, 1))
+    dy3 = torch.randn(b, h3, h3, co3, generator=g).to(dtype).to(DEV)
+    dw3 = ops.conv2d_wgrad(x3, dy3, 3, 1, 1)
+    dw3h = ops.conv2d_wgrad(x3[:hb].contiguous(), dy3[:hb].contiguous(), 3, 1, 1) + ops.conv2d_wgrad(x3[hb:].contiguous(), dy3[hb:].contiguous(), 3, 1, 1)
+    assert rel_err(dw3, dw3h) < 1e-3
+
+
 SPLITK = [  # rollout-frame shapes (one image through layer2-4): few 64x64 output tiles, long reductions
     (1, 7, 512, 512, 3, 1, 1), (1, 14, 256, 256, 3, 1, 1), (1, 28, 128, 128, 3, 1, 1), (1, 7, 2048, 512, 1, 1, 0), (1, 14, 1024, 2048, 1, 2, 0),
     (1, 14, 512, 512, 3, 2, 1), (3, 7, 512, 512, 3, 1, 1), (2, 9, 320, 72, 3, 1, 1)]

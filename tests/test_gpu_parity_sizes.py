@@ -235,3 +235,22 @@ def test_bs64_flat_gradient_matches_cpu_oracle():
         else:
             emu = emulated_grads("no", cfg, sd, batch, dtype)
             check_16bit_against_emulation("bs64[%s]" % dtype, hip, emu, ref["grads"])
+
+
+def test_eval_forward_beyond_the_2_gib_tensor_cap():
+    """1400 images in one call: the stem / layer1 activations are 2.25 GB each, above the 2 GiB a single buffer descriptor could
+    address in round 1.  Eval-mode BatchNorm is per sample, so the outputs must equal those of the two halves run on their own."""
+    from rgb_proprioceptive_pose_estimator_amd import models as M
+    from rgb_proprioceptive_pose_estimator_amd.util.data_utils import synthetic_batch
+    torch.manual_seed(0)
+    model = M.NaiveObjectStateEstimator("cube", [64], 50, 64, False, (9,), False, False, False, compute_dtype=torch.bfloat16).cuda().eval()
+    model.trunk.max_plans = 1                      # one multi-GB workspace at a time
+    b = synthetic_batch((1400,), 77)
+    with torch.no_grad():
+        full = model(b["img"], None, b["x0bar"]).clone()
+        assert torch.isfinite(full).all()
+        lo = model(b["img"][:700].contiguous(), None, b["x0bar"][:700].contiguous()).clone()
+        hi = model(b["img"][700:].contiguous(), None, b["x0bar"][700:].contiguous()).clone()
+    assert torch.equal(full[:700], lo) and torch.equal(full[700:], hi)
+    model.trunk._plans.clear()
+    torch.cuda.empty_cache()
