@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -121,6 +122,11 @@ struct rpe_resnet50 {
     bool gram_keep_y = true;     // the raw conv3 output is still written (its backward reads it)
     void* gram_ws = nullptr;     // slab of the Gram launches (main stream)
     long gram_ws_bytes = 0;
+    // weight-gradient launches collected per bottleneck block and issued on the second stream behind ONE event (every event
+    // recorded on the caller's stream costs a ~6.5 us bubble there: the kernel behind the marker packet cannot be pipelined)
+    std::vector<std::function<int(hipStream_t)>> side_work;
+    bool defer_side = false;
+    int defer_mode = 0;
     void* sk_ws = nullptr;               // split-K workspace of the inference forward (rpe_conv2d_fwd_affine_ws); 0 bytes when no layer splits
     long sk_ws_bytes = 0;
     rpe_pack_desc* pack_tab_fold = nullptr;  // ... with the BN scale folded into the forward copy (inference)
@@ -325,6 +331,10 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
     // 21.98 ms/step -- the Gram launch + slab sum + statistics kernel sit on the forward's critical path (~28 us per block) and
     // conv3 now reads the residual and writes two tensors; with y3 NOT written (RPE_GRAM_NO_Y=1, timing only) 21.87: -0.27 ms net,
     // which a backward that recomputes y3 tiles in the fused data-gradient epilogue would have to add to -- not pursued.
+    // RPE_WGRAD_DEFER: 0 (default) one event per weight gradient, issued as soon as its inputs exist; 1: one event per block;
+    // 2: two per block (behind conv2's and conv1's dy)
+    e->defer_mode = getenv("RPE_WGRAD_DEFER") ? atoi(getenv("RPE_WGRAD_DEFER")) : 0;
+    e->defer_side = e->defer_mode != 0;
     e->gram = dtype != RPE_F32 && getenv("RPE_GRAM") != nullptr;
     if (e->gram) {
         if (getenv("RPE_GRAM_MAX")) e->gram_max = atoi(getenv("RPE_GRAM_MAX"));
@@ -838,16 +848,8 @@ static int bn_from_dz(rpe_resnet50* e, ConvL& c, const void* dz, void* dy, void*
     return 0;
 }
 
-static int wgrad(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, void* stream) {
+static int wgrad_on(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, hipStream_t run) {
     float* dw = e->grads[c.p_w];
-    hipStream_t run = (hipStream_t)stream;
-    if (e->overlap && e->side) {
-        hipEvent_t ready = sync_event(e);
-        if (!ready) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
-        HIPTRY(hipEventRecord(ready, (hipStream_t)stream));
-        HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
-        run = e->side;
-    }
     e->pending_flops = conv_flops(c);
     e->pending_bytes = conv_in_bytes(e, c) + conv_out_bytes(e, c);
     if (e->wg_slab) {   // deterministic: per-workgroup slabs + fixed-order sum, overwrites dw (launches on `run` are ordered: one slab buffer)
@@ -858,6 +860,35 @@ static int wgrad(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, void*
     PROF(e, RPE_PROF_CONV_WGRAD, run, rpe_conv2d_wgrad(&c.d, e->dtype, x, dy, dw, run));
     return 0;
 }
+
+// everything collected in side_work runs on the second stream behind one event on the caller's stream
+static int flush_side(rpe_resnet50* e, void* stream) {
+    if (e->side_work.empty()) return 0;
+    hipEvent_t ready = sync_event(e);
+    if (!ready) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
+    HIPTRY(hipEventRecord(ready, (hipStream_t)stream));
+    HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
+    for (auto& f : e->side_work)
+        if (int err = f(e->side)) { e->side_work.clear(); return err; }
+    e->side_work.clear();
+    return 0;
+}
+
+static int wgrad(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, void* stream) {
+    if (e->overlap && e->side) {
+        if (e->defer_side) {   // (x and dy live in per-layer buffers that nothing rewrites within the step)
+            ConvL* cp = &c;
+            e->side_work.push_back([e, cp, x, dy](hipStream_t run) { return wgrad_on(e, *cp, x, dy, run); });
+            return 0;
+        }
+        hipEvent_t ready = sync_event(e);
+        if (!ready) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
+        HIPTRY(hipEventRecord(ready, (hipStream_t)stream));
+        HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
+        return wgrad_on(e, c, x, dy, e->side);
+    }
+    return wgrad_on(e, c, x, dy, (hipStream_t)stream);
+}
 // Folded form of (BN backward of c.bn -> weight gradient + data gradient of the 1x1 conv c), entered with dz = gradient wrt the BN
 // output and this BN's partial sums in stats_part (left by the data gradient that produced dz):
 //   main: coefficients -> fold (w_kcat, bias) -> K-concatenated data gradient [dz | x] with the epilogue of the layer behind;
@@ -866,14 +897,9 @@ static int conv1x1_backward_folded(rpe_resnet50* e, ConvL& c, const void* dz, Co
     const void* x = behind.a;
     e->pending_bytes = 0;
     PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_backward_coeffs(e->stats_part, e->fused_tiles, c.d.out_c, c.rows, e->grads[c.p_g], e->grads[c.p_b], c.c1c2, e->dpart, stream));
-    hipStream_t run = (hipStream_t)stream;
-    if (e->overlap && e->side) {
-        hipEvent_t ready = sync_event(e);
-        if (!ready) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
-        HIPTRY(hipEventRecord(ready, (hipStream_t)stream));
-        HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
-        run = e->side;
-    }
+    ConvL* cp = &c;
+    auto side_part = [e, cp, dz, x](hipStream_t run) -> int {
+    ConvL& c = *cp;
     float* dw = e->grads[c.p_w];
     if (e->fold_w && e->wfold_scratch && c.d.in_c <= e->fold_w_max) {
         // weight gradient from dz and x alone (no dy): dz^T x, x^T x, colsum(x), W (x^T x), combine
@@ -893,6 +919,20 @@ static int conv1x1_backward_folded(rpe_resnet50* e, ConvL& c, const void* dz, Co
         PROF(e, RPE_PROF_CONV_WGRAD, run, rpe_conv2d_wgrad(&c.d, e->dtype, x, c.dy, dw, run));
     }
     }
+    return 0;
+    };
+    if (e->overlap && e->side) {
+        if (e->defer_side) e->side_work.push_back(side_part);
+        else {
+            hipEvent_t ready = sync_event(e);
+            if (!ready) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
+            HIPTRY(hipEventRecord(ready, (hipStream_t)stream));
+            HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
+            TRY(side_part(e->side));
+        }
+    } else {
+        TRY(side_part((hipStream_t)stream));
+    }
     e->pending_bytes = 0;
     PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_bwd_fold_conv1x1(e->dtype, c.d.out_c, c.d.in_c, fwd_weight(e, c), c.wd, e->params[c.p_g], c.invstd, c.mean, c.c1c2,
                                                               e->w_kcat, e->fold_bias, e->fold_scratch, e->fold_scratch_bytes, stream));
@@ -910,6 +950,7 @@ static int conv1x1_backward_folded(rpe_resnet50* e, ConvL& c, const void* dz, Co
 static int join_side(rpe_resnet50* e, hipStream_t s) {
     // everything the side stream produced so far (weight gradients) is complete before the caller's next launch on s
     if (e->overlap && e->side) {
+        TRY(flush_side(e, s));
         hipEvent_t done = sync_event(e);
         if (!done) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
         HIPTRY(hipEventRecord(done, e->side));
@@ -1017,6 +1058,7 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
         }
         TRY(bn_from_dz(e, c2, c2.dy, c2.dy, stream));
         TRY(wgrad(e, c2, c1.a, c2.dy, stream));
+        if (e->defer_mode == 2 && e->overlap && e->side) TRY(flush_side(e, stream));
         TRY(dgrad_fused(e, c2, c2.dy, c1.dy, nullptr, &c1, 2, stream));   // dz1
         TRY(bn_from_dz(e, c1, c1.dy, c1.dy, stream));
         TRY(wgrad(e, c1, x_in, c1.dy, stream));
@@ -1040,6 +1082,7 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
         } else {
             PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&c1.d, e->dtype, c1.dy, c1.wd, gD, shortcut, stream));
         }
+        if (e->overlap && e->side) TRY(flush_side(e, stream));   // this block's weight gradients: one event, then onto the second stream
     }
     e->bwd_next = bi;
     if (join) TRY(join_side(e, (hipStream_t)stream));

@@ -44,8 +44,8 @@ def test_kernel_variant_parity(env, subset):
 ENGINE_VARIANTS = [
     {"RPE_NO_OVERLAP": "1", "RPE_GRAM": "1"},        # everything on one stream; BN3 statistics from the Gram matrix of conv3's input (16-bit types)
     # projection-shortcut branch on the main stream; dense early-feature gradient + separate pool / BN backward passes for the
-    # stem; conv3 backward through a materialised dy on the main stream
-    {"RPE_NO_FWD_OVERLAP": "1", "RPE_STEM_UNFUSED": "1", "RPE_NO_BN_FOLD": "1"},
+    # stem; conv3 backward through a materialised dy on the main stream; a block's weight gradients issued behind one event
+    {"RPE_NO_FWD_OVERLAP": "1", "RPE_STEM_UNFUSED": "1", "RPE_NO_BN_FOLD": "1", "RPE_WGRAD_DEFER": "1"},
     # forward as two concurrent half-batch pipelines; conv3 weight gradient from dy; fp32 atomics instead of slabs
     {"RPE_FWD_SPLIT": "1", "RPE_NO_WGRAD_FOLD": "1", "RPE_WGRAD_ATOMIC": "1"},
     # projection-shortcut backward on the side stream; its BN as a pass of its own; folded weight gradient for layers 1-2 only;
