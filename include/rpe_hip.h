@@ -274,6 +274,12 @@ int rpe_tensor_add(int dtype, void* dst, const void* src, long n, void* stream);
  * The data gradient is the same call with the transposed weight. */
 int rpe_linear_fwd(int dtype, const void* x, int ldx, const void* w, int ldw, const float* bias, void* y, int ldy, int M, int N, int K,
                    int relu, const void* addend, int ld_add, void* stream);
+/* the same with a caller-provided workspace: launches with few output tiles and a long reduction (the heads' layers at a few hundred
+ * rows: 256 x 3655 -> 1024 is 64 tiles of 64 x 64 walking 229 K steps alone) are split along K, partial tiles added in a fixed order
+ * by a second small launch (as rpe_conv2d_fwd_affine_ws).  The query returns 0 for shapes that are not split. */
+long rpe_linear_fwd_workspace_bytes(int dtype, int M, int N, int K);
+int rpe_linear_fwd_ws(int dtype, const void* x, int ldx, const void* w, int ldw, const float* bias, void* y, int ldy, int M, int N, int K,
+                      int relu, const void* addend, int ld_add, void* workspace, long workspace_bytes, void* stream);
 /* dw[N][K] (fp32, ld lddw) += dy[M][N]^T x[M][K]  (atomic accumulation) */
 int rpe_linear_wgrad(int dtype, const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int M, int N, int K, void* stream);
 /* deterministic form (see rpe_conv2d_wgrad_det): dw = dy^T x, or dw += dy^T x when `accumulate` (one fixed-order add per element) */

@@ -95,6 +95,8 @@ _SPEC = {
     "rpe_depth_head_fwd": (I, [P, P, P, P, P, I, I, I, P]),
     "rpe_depth_head_bwd": (I, [P, P, L, P, P, P]),
     "rpe_linear_fwd": (I, [I, P, I, P, I, P, P, I, I, I, I, I, P, I, P]),
+    "rpe_linear_fwd_workspace_bytes": (L, [I, I, I, I]),
+    "rpe_linear_fwd_ws": (I, [I, P, I, P, I, P, P, I, I, I, I, I, P, I, P, L, P]),
     "rpe_linear_wgrad": (I, [I, P, I, P, I, P, I, I, I, I, P]),
     "rpe_linear_wgrad_workspace_bytes": (L, [I, I, I, I]),
     "rpe_linear_wgrad_det": (I, [I, P, I, P, I, P, I, I, I, I, I, P, L, P]),

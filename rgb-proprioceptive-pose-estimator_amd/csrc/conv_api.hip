@@ -541,7 +541,12 @@ static int linear_rows(const float* x, int ldx, const float* w, int ldw, const f
 
 template <typename T>
 static int linear_fwd_t(const void* x, int ldx, const void* w, int ldw, const float* bias, void* y, int ldy, int M, int N, int K, int relu,
-                        const void* addend, int ld_add, hipStream_t s) {
+                        const void* addend, int ld_add, hipStream_t s, void* ws = nullptr, long ws_bytes = 0, long* ws_query = nullptr) {
+    if (ws_query) {
+        const int S = (M > kLinearRowsMax || sizeof(T) != 4) ? nt_split_plan(M, N, K, 4 * Elem<T>::kChunk, nullptr, true) : 1;
+        *ws_query = S > 1 ? nt_split_slab_bytes(M, N, S) : 0;
+        return 0;
+    }
     if constexpr (sizeof(T) == 4) {
         static const bool rows_off = getenv("RPE_NO_LINEAR_ROWS") != nullptr;
         if (!rows_off && x && w && y && M >= 1 && M <= kLinearRowsMax && N >= 1 && K >= 1 && ldx >= K && ldw >= K && ldy >= N)
@@ -553,6 +558,10 @@ static int linear_fwd_t(const void* x, int ldx, const void* w, int ldw, const fl
     a.M = M; a.N = N; a.K = K; a.lda = ldx; a.ldb = ldw; a.ldc = ldy;
     a.bias = bias; a.addend = (const T*)addend; a.ld_add = ld_add; a.relu = relu;
     a.role = 2;
+    if (ws) {   // few output tiles, long K (the heads' layers at a few hundred rows): split K over grid.y through the workspace
+        const int S = nt_split_plan(M, N, K, 4 * Elem<T>::kChunk, nullptr, true);
+        if (S > 1 && ws_bytes >= nt_split_slab_bytes(M, N, S) && !(((uintptr_t)ws) & 15)) { a.slab = (float*)ws; a.slab_bytes = ws_bytes; a.splits = S; }
+    }
     return launch_nt<T>(a, MODE_DENSE, s);
 }
 
@@ -767,6 +776,22 @@ int rpe_stem_conv_wgrad_det(int dtype, const void* x4, const void* dy, float* dw
 int rpe_linear_fwd(int dtype, const void* x, int ldx, const void* w, int ldw, const float* bias, void* y, int ldy, int M, int N, int K,
                    int relu, const void* addend, int ld_add, void* stream) {
     DISPATCH(dtype, linear_fwd_t, x, ldx, w, ldw, bias, y, ldy, M, N, K, relu, addend, ld_add, (hipStream_t)stream);
+}
+
+long rpe_linear_fwd_workspace_bytes(int dtype, int M, int N, int K) {
+    long bytes = 0;
+    if (M <= 0 || N <= 0 || K <= 0) return -1;
+    int rc;
+    if (dtype == RPE_F32) rc = linear_fwd_t<float>(nullptr, K, nullptr, K, nullptr, nullptr, N, M, N, K, 0, nullptr, 0, nullptr, nullptr, 0, &bytes);
+    else if (dtype == RPE_BF16) rc = linear_fwd_t<bf16>(nullptr, K, nullptr, K, nullptr, nullptr, N, M, N, K, 0, nullptr, 0, nullptr, nullptr, 0, &bytes);
+    else if (dtype == RPE_F16) rc = linear_fwd_t<f16>(nullptr, K, nullptr, K, nullptr, nullptr, N, M, N, K, 0, nullptr, 0, nullptr, nullptr, 0, &bytes);
+    else return -1;
+    return rc ? -1 : bytes;
+}
+
+int rpe_linear_fwd_ws(int dtype, const void* x, int ldx, const void* w, int ldw, const float* bias, void* y, int ldy, int M, int N, int K,
+                      int relu, const void* addend, int ld_add, void* workspace, long workspace_bytes, void* stream) {
+    DISPATCH(dtype, linear_fwd_t, x, ldx, w, ldw, bias, y, ldy, M, N, K, relu, addend, ld_add, (hipStream_t)stream, workspace, workspace_bytes, nullptr);
 }
 
 int rpe_linear_wgrad(int dtype, const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int M, int N, int K, void* stream) {

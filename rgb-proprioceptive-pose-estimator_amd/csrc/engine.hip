@@ -127,6 +127,8 @@ struct rpe_resnet50 {
     std::vector<std::function<int(hipStream_t)>> side_work;
     bool defer_side = false;
     int defer_mode = 0;
+    void* fc_ws = nullptr;               // split-K workspace of the ResNet fc forward / data gradient (rpe_linear_fwd_ws)
+    long fc_ws_bytes = 0;
     void* sk_ws = nullptr;               // split-K workspace of the inference forward (rpe_conv2d_fwd_affine_ws); 0 bytes when no layer splits
     long sk_ws_bytes = 0;
     rpe_pack_desc* pack_tab_fold = nullptr;  // ... with the BN scale folded into the forward copy (inference)
@@ -358,6 +360,11 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
         const long fcb = rpe_linear_wgrad_workspace_bytes(RPE_F32, batch, latent_dim, 2048);
         if (fcb > e->main_slab_bytes) e->main_slab_bytes = fcb;
         if (e->main_slab_bytes > 0) want(e, &e->main_slab, e->main_slab_bytes);
+    }
+    {
+        const long f = rpe_linear_fwd_workspace_bytes(RPE_F32, batch, latent_dim, 2048), d = rpe_linear_fwd_workspace_bytes(RPE_F32, batch, 2048, e->latent_pad);
+        e->fc_ws_bytes = f > d ? f : d;
+        if (e->fc_ws_bytes > 0 && getenv("RPE_NO_LINEAR_SPLITK") == nullptr) want(e, &e->fc_ws, e->fc_ws_bytes);
     }
     // inference forward of few-row layers (rollout frames): split-K partial tiles
     if (getenv("RPE_NO_SPLITK") == nullptr) {
@@ -786,8 +793,8 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
     ConvL& last = e->convs[e->blocks.back().c3];
     TRY(rpe_avgpool_fwd(e->dtype, last.a, e->pooled, e->B, last.Ho * last.Wo, 2048, stream));
     const int np = (int)e->pnames.size();
-    TRY(rpe_linear_fwd(RPE_F32, e->pooled, 2048, e->params[np - 2], 2048, e->params[np - 1], features, (int)ld_features, e->B, e->latent, 2048, 0,
-                       nullptr, 0, stream));
+    TRY(rpe_linear_fwd_ws(RPE_F32, e->pooled, 2048, e->params[np - 2], 2048, e->params[np - 1], features, (int)ld_features, e->B, e->latent, 2048, 0,
+                          nullptr, 0, e->fc_ws, e->fc_ws ? e->fc_ws_bytes : 0, stream));
     e->fwd_done = training != 0;
     return 0;
 }
@@ -982,8 +989,8 @@ extern "C" int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_fea
     // K runs to latent_pad: the extra columns of d_features (whatever the caller keeps there) meet zero weights.
     if ((ld_d_features & 3) || ld_d_features < e->latent_pad)
         return rpe_set_error(RPE_ERR_ALIGN, "resnet50_backward: ld_d_features must be a multiple of 4 and >= pad4(latent_dim)");
-    TRY(rpe_linear_fwd(RPE_F32, d_features, (int)ld_d_features, e->fc_wt, e->latent_pad, nullptr, e->d_pooled, 2048, e->B, 2048, e->latent_pad, 0,
-                       nullptr, 0, stream));
+    TRY(rpe_linear_fwd_ws(RPE_F32, d_features, (int)ld_d_features, e->fc_wt, e->latent_pad, nullptr, e->d_pooled, 2048, e->B, 2048, e->latent_pad, 0,
+                          nullptr, 0, e->fc_ws, e->fc_ws ? e->fc_ws_bytes : 0, stream));
     ConvL& last = e->convs[e->blocks.back().c3];
     TRY(rpe_avgpool_bwd(e->dtype, e->d_pooled, e->blocks.back().dz, e->B, last.Ho * last.Wo, 2048, stream));
     e->bwd_next = (int)e->blocks.size() - 1;

@@ -1021,10 +1021,11 @@ __global__ __launch_bounds__(256) void nt_split_epilogue_kernel(const float* __r
         v += p0; v += p1; v += p2; v += p3;
     }
     for (; z < splits; ++z) v += src[(long)z * zstride];
-    if (m >= M || n >= N) return;                                  // (conv outputs: N % 8 == 0, a 4-column piece is in or out as a whole)
+    if (m >= M || n >= N) return;
     float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+        if (n + j >= N) break;                                     // (Linear layers: any N)
         if (bias) o[j] += bias[n + j];
         if (addend) o[j] += Elem<T>::to_f(addend[m * ld_add + n + j]);
         if (relu) o[j] = fmaxf(o[j], 0.f);
@@ -1035,7 +1036,7 @@ __global__ __launch_bounds__(256) void nt_split_epilogue_kernel(const float* __r
 template <typename T, int MODE> static int launch_nt_split(NTArgs<T>& a, hipStream_t s) {
     constexpr int BK = 4 * Elem<T>::kChunk;
     int steps = 0;
-    const int S = nt_split_plan(a.M, a.N, a.K, BK, &steps);
+    const int S = nt_split_plan(a.M, a.N, a.K, BK, &steps, a.role == 2);
     a.tiles_m = ceil_div(a.M, 64);
     a.tiles_n = ceil_div(a.N, 64);
     const long tiles = (long)a.tiles_m * a.tiles_n;
@@ -1100,7 +1101,7 @@ template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s) 
     if constexpr (MODE == MODE_STEM) {
         return launch_nt_cfg<T, 2, 64, 4, MODE_STEM>(a, s);
     } else {
-        if (a.role == 3 && a.slab && a.splits > 1) return launch_nt_split<T, MODE>(a, s);
+        if ((a.role == 3 || (a.role == 2 && MODE == MODE_DENSE)) && a.slab && a.splits > 1) return launch_nt_split<T, MODE>(a, s);
         if (a.role == 5) {   // 1x1 training forward with the BatchNorm apply fused (16-bit element types; rpe_conv1x1_fwd_bn)
             if constexpr (MODE == MODE_DENSE && sizeof(T) == 2) {
                 if ((long)ceil_div(a.M, 128) * ceil_div(a.N, 128) < 96) {

@@ -383,6 +383,7 @@ def avgpool_bwd(dout, x_shape, dtype):
 # rows up to which rpe_linear_fwd (fp32) runs one workgroup per output column and accepts any row stride / alignment
 # (csrc/conv_api.hip: linear_rows_kernel); 0 when switched off
 LINEAR_ROWS_MAX = 0 if os.environ.get("RPE_NO_LINEAR_ROWS") else 8
+LINEAR_SPLIT_K = not os.environ.get("RPE_NO_LINEAR_SPLITK")   # split-K for Linear launches with few tiles and long K
 
 
 def linear_fwd(x, w, bias=None, relu=False, addend=None, out=None, n=None, k=None):
@@ -392,6 +393,12 @@ def linear_fwd(x, w, bias=None, relu=False, addend=None, out=None, n=None, k=Non
     n = w.shape[0] if n is None else n
     if out is None:
         out = torch.zeros((m, pad4(n)), dtype=x.dtype, device=x.device)[:, :n]
+    need = lib.rpe_linear_fwd_workspace_bytes(dtype_code(x), m, n, k) if LINEAR_SPLIT_K else 0
+    if need > 0:   # few output tiles, long K: split-K through the shared workspace (fixed-order sums)
+        ws = scratch(need, x.device)
+        lib.rpe_linear_fwd_ws(dtype_code(x), _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), m, n, k, int(relu),
+                              _p(addend), 0 if addend is None else addend.stride(0), _p(ws), ws.numel(), _stream())
+        return out
     lib.rpe_linear_fwd(dtype_code(x), _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), m, n, k, int(relu),
                        _p(addend), 0 if addend is None else addend.stride(0), _stream())
     return out

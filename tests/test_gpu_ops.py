@@ -85,6 +85,27 @@ def test_linear_fwd_few_rows(m, n, k):
     assert rel_err(ops.linear_fwd(xd, wd, b.to(DEV)), tile.cpu()) < 2e-6
 
 
+@pytest.mark.parametrize("m,n,k", [(256, 1024, 3656), (256, 512, 2048), (128, 2048, 512), (64, 130, 1000), (300, 7, 4100)])
+def test_linear_fwd_split_k(m, n, k):
+    """fp32 Linear layers with few output tiles and a long reduction (the heads at a few hundred rows) split K over grid.y through a
+    workspace (rpe_linear_fwd_ws): planned split taken, result = reference, repeats bitwise, any N."""
+    from rgb_proprioceptive_pose_estimator_amd._lib import lib, RPE_F32
+    g = torch.Generator().manual_seed(m + n + k)
+    x, w, b = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5, torch.randn(n, generator=g)
+    add = torch.randn(m, ops.pad4(n), generator=g)[:, :n]
+    assert lib.rpe_linear_fwd_workspace_bytes(RPE_F32, m, n, k) > 0, "this shape is expected to split"
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    ad = torch.zeros(m, ops.pad4(n)).to(DEV)
+    ad[:, :n] = add.to(DEV)
+    out = ops.linear_fwd(xd, wd, bd, relu=True, addend=ad[:, :n])
+    assert "nt_split_epilogue_kernel" in ops.last_kernel_name()
+    ref = F.relu(x.double() @ w.double().t() + b.double() + add.double()).float()
+    assert rel_err(out, ref) < 2e-5
+    assert torch.equal(out, ops.linear_fwd(xd, wd, bd, relu=True, addend=ad[:, :n]))
+    plain = ops.linear_fwd(xd, wd, bd)
+    assert rel_err(plain, (x.double() @ w.double().t() + b.double()).float()) < 2e-5
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("m,n,k", [(333, 7, 36), (1000, 128, 128), (4096, 64, 200), (50, 130, 64)])
 def test_linear_wgrad(dtype, m, n, k):
