@@ -251,6 +251,7 @@ def test_eval_forward_beyond_the_2_gib_tensor_cap():
         assert torch.isfinite(full).all()
         lo = model(b["img"][:700].contiguous(), None, b["x0bar"][:700].contiguous()).clone()
         hi = model(b["img"][700:].contiguous(), None, b["x0bar"][700:].contiguous()).clone()
-    assert torch.equal(full[:700], lo) and torch.equal(full[700:], hi)
+    # (the trunk is exact per sample; the fp32 head layers pick their K split by the row count, i.e. another summation order)
+    assert torch.allclose(full[:700], lo, rtol=1e-4, atol=1e-5) and torch.allclose(full[700:], hi, rtol=1e-4, atol=1e-5)   # (measured 1.6e-5; exactly 0 with RPE_NO_LINEAR_SPLITK=1)
     model.trunk._plans.clear()
     torch.cuda.empty_cache()
