@@ -315,7 +315,7 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
             const long w = (long)d.in_c * (d.out_c + d.in_c) * (long)es;
             if (w > wk) wk = w;
         }
-        e->fold_w = getenv("RPE_NO_WGRAD_FOLD") == nullptr;
+        e->fold_w = getenv("RPE_NO_WGRAD_FOLD") == nullptr && getenv("RPE_TN_REG") == nullptr;   // (the row-concatenated operand is an LDS-DMA path feature)
         if (e->fold_w) {
             if (getenv("RPE_WGRAD_FOLD_MAX")) e->fold_w_max = atoi(getenv("RPE_WGRAD_FOLD_MAX"));
             for (auto& b : e->blocks) {
