@@ -403,25 +403,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_N == 4 && BN < 256) 
         // was last read in iteration kt-1, i.e. before the barrier every wave has already passed.
         constexpr int NI = AR + BR;
         constexpr int PF = NSTAGE - 1;  // tiles kept in flight ahead of the one being multiplied
-        // prologue: tiles 0 .. PF-1
+        // a reduction of <= NSTAGE steps never re-uses a slot: all of it is requested up front (the 2-slot / 32-KB form of the K = 64
+        // launches, four workgroups per CU instead of three, lives on this)
+        const bool allin = nk <= NSTAGE;
+        const int pf = allin ? nk : PF;
+        // prologue: tiles 0 .. pf-1
 #pragma unroll
-        for (int t = 0; t < PF; ++t) {
-            if (t < nk) { if (t > 0) advance_k(); dma_tile(t); }
+        for (int t = 0; t < NSTAGE; ++t) {
+            if (t < pf) { if (t > 0) advance_k(); dma_tile(t); }
         }
-        // tile 0 must have landed: allow the (min(PF, nk) - 1) newer tiles to stay in flight
+        // tile 0 must have landed: allow the (pf - 1) newer tiles to stay in flight
         {
-            const int newer = (nk < PF ? nk : PF) - 1;
+            const int newer = (nk < pf ? nk : pf) - 1;
             if (newer >= 4) wait_vmcnt<4 * NI>(); else if (newer == 3) wait_vmcnt<3 * NI>(); else if (newer == 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
         int st = 0;
         auto k_step = [&](int kt, auto first_tag) {
-            const bool pre = kt + PF < nk;
+            const bool pre = !allin && kt + PF < nk;
             if (pre) { advance_k(); int s2 = st + PF; if (s2 >= NSTAGE) s2 -= NSTAGE; dma_tile(s2); }
             compute(st, first_tag);
             // tile kt+1 must be complete; tiles kt+2 .. may still be in flight
             int newer = nk - 2 - kt;               // tiles issued after kt+1
-            if (newer > PF - 1) newer = PF - 1;
+            if (newer > pf - 1) newer = pf - 1;
             if (newer >= 4) wait_vmcnt<4 * NI>(); else if (newer == 3) wait_vmcnt<3 * NI>(); else if (newer == 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             if (++st == NSTAGE) st = 0;
@@ -1145,6 +1149,12 @@ template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s) 
             // 4 waves per SIMD), the train step 22.6 vs 22.0 ms -- occupancy is not what bounds these launches.
             static const int w8 = getenv("RPE_NT_W8") ? atoi(getenv("RPE_NT_W8")) : 0;
             if (w8 && a.role <= 1 && a.M >= 4096 && wide) return launch_nt_cfg<T, 2, 128, 4, MODE, 3, 4>(a, s);
+        }
+        if constexpr (MODE == MODE_DENSE) {
+            // K <= two 64-byte steps (layer1's 64-channel 1x1 convs): a 2-slot ring with both steps requested up front = 32 KB of LDS,
+            // four workgroups per CU instead of three -- more operand bytes in flight for launches that live on them (RPE_NT_K64=0: off)
+            static const bool k64 = !(getenv("RPE_NT_K64") && atoi(getenv("RPE_NT_K64")) == 0);
+            if (k64 && a.role <= 1 && a.K <= 8 * CE && a.M >= 4096 && wide) return launch_nt_cfg<T, 2, 128, 4, MODE, 2>(a, s);
         }
         return wide ? launch_nt_cfg<T, 2, 128, 4, MODE>(a, s) : launch_nt_cfg<T, 2, 64, 4, MODE>(a, s);
     }

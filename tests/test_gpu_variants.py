@@ -22,7 +22,7 @@ VARIANTS = [   # (switches, the parity cases of test_gpu_ops.py they can affect)
     # without the parity-class decomposition; non-temporal epilogue stores
     ({"RPE_NT_BIG": "1", "RPE_TN_REG": "1", "RPE_NO_PARITY": "1", "RPE_NT_NTSTORE": "1"}, ALL),
     # 128-byte K rows + 2-slot ring for every K; few, long split-M slices in the weight gradient; 8 waves on the 128x128 tile
-    ({"RPE_NT_BK64": "1", "RPE_TN_WGS": "64", "RPE_NT_W8": "1"}, ALL),
+    ({"RPE_NT_BK64": "1", "RPE_TN_WGS": "64", "RPE_NT_W8": "1", "RPE_NT_K64": "0"}, ALL),
     # 64-byte K rows for every K; 4-slot ring of 32-row steps in the weight-gradient kernel; 128x256 / 8-wave tiles for N >= 256
     ({"RPE_NT_NOBK64": "1", "RPE_TN_RING": "1,4", "RPE_NT_WIDE": "2"}, ALL),
     ({"RPE_TN_RING": "2,3"}, TN),     # 3-slot ring of 64-row steps for every shape
