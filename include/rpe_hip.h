@@ -253,6 +253,12 @@ int rpe_aux_head_fwd(int dtype, const void* a1, const float* w, const float* bia
 /* d_a1 (dense gradient of a1, zero except the winner pixels) may be NULL when the stem backward gathers it itself (rpe_stem_bwd) */
 int rpe_aux_head_bwd(int dtype, const float* dout, long ld_dout, const void* a1, const float* w, const float* depth_feat, const float* raw,
                      const unsigned char* idx, void* d_a1, float* dw, float* dbias, float* d_depth_feat, int B, int H, int W, void* stream);
+/* deterministic form: the parameter gradients leave every block as plain stores into the workspace and are added in block order by a
+ * second tiny launch (dw[64], dbias OVERWRITTEN, bitwise reproducible; the atomic form above accumulates) */
+long rpe_aux_head_bwd_workspace_floats(int dtype, int B, int H, int W);
+int rpe_aux_head_bwd_det(int dtype, const float* dout, long ld_dout, const void* a1, const float* w, const float* depth_feat, const float* raw,
+                         const unsigned char* idx, void* d_a1, float* dw, float* dbias, float* d_depth_feat, int B, int H, int W, float* workspace,
+                         long workspace_floats, void* stream);
 /* replaces: depth_nets[i] = AvgPool2d(2) x2 -> InstanceNorm2d(1, affine) -> Flatten (models/naive.py:233-240) */
 int rpe_depth_head_fwd(const float* depth, const float* w, const float* b, float* feat, float* xhat, int B, int H, int W, void* stream);
 int rpe_depth_head_bwd(const float* d_feat, const float* xhat, long n, float* dw, float* db, void* stream);

@@ -92,6 +92,8 @@ _SPEC = {
     "rpe_avgpool_bwd": (I, [I, P, P, I, I, I, P]),
     "rpe_aux_head_fwd": (I, [I, P, P, P, P, P, L, P, P, I, I, I, P]),
     "rpe_aux_head_bwd": (I, [I, P, L, P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "rpe_aux_head_bwd_workspace_floats": (L, [I, I, I, I]),
+    "rpe_aux_head_bwd_det": (I, [I, P, L, P, P, P, P, P, P, P, P, P, I, I, I, P, L, P]),
     "rpe_depth_head_fwd": (I, [P, P, P, P, P, I, I, I, P]),
     "rpe_depth_head_bwd": (I, [P, P, L, P, P, P]),
     "rpe_linear_fwd": (I, [I, P, I, P, I, P, P, I, I, I, I, I, P, I, P]),

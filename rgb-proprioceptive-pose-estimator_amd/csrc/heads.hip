@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void aux_bwd_kernel(const float* __restrict__ 
                                                      const float* __restrict__ w, const float* __restrict__ depth_feat,
                                                      const float* __restrict__ raw, const unsigned char* __restrict__ idx,
                                                      T* __restrict__ d_a1, float* __restrict__ dw, float* __restrict__ dbias,
-                                                     float* __restrict__ d_depth_feat, int B, int H, int W) {
+                                                     float* __restrict__ d_depth_feat, int B, int H, int W, float* __restrict__ part) {
     constexpr int CE = Elem<T>::kChunk, LPP = 64 / CE;
     __shared__ float sh_dw[64];
     __shared__ float sh_db;
@@ -106,12 +106,47 @@ __global__ __launch_bounds__(256) void aux_bwd_kernel(const float* __restrict__ 
         }
         if (sub == 0) gb += d;
     }
+    // lanes l, l + LPP, l + 2 LPP, .. of a wave own the same channels: fold them with shuffles first, so that LPP lanes per wave
+    // (not all 64) touch the shared accumulators -- the 2048 same-address LDS atomics per block were most of this kernel's time
 #pragma unroll
-    for (int e = 0; e < CE; ++e) atomicAdd(&sh_dw[sub * CE + e], gw[e]);
-    if (sub == 0) atomicAdd(&sh_db, gb);
+    for (int e = 0; e < CE; ++e) {
+        for (int o = LPP; o < 64; o <<= 1) gw[e] += __shfl_xor(gw[e], o);
+    }
+    for (int o = LPP; o < 64; o <<= 1) gb += __shfl_xor(gb, o);
+    __shared__ float sh_w[4][65];   // per-wave sums, added in wave order below (no shared atomics: the block's sums are order-free)
+    if ((threadIdx.x & 63) < LPP) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) sh_w[threadIdx.x >> 6][sub * CE + e] = gw[e];
+        if (sub == 0) sh_w[threadIdx.x >> 6][64] = gb;
+    }
     __syncthreads();
+    if (threadIdx.x < 64) sh_dw[threadIdx.x] = ((sh_w[0][threadIdx.x] + sh_w[1][threadIdx.x]) + sh_w[2][threadIdx.x]) + sh_w[3][threadIdx.x];
+    if (threadIdx.x == 64) sh_db = ((sh_w[0][64] + sh_w[1][64]) + sh_w[2][64]) + sh_w[3][64];
+    __syncthreads();
+    if (part) {   // deterministic form: this block's 65 sums as plain stores, added in block order by aux_bwd_reduce_kernel
+        if (threadIdx.x < 64) part[(long)threadIdx.x * gridDim.x + blockIdx.x] = sh_dw[threadIdx.x];   // [65][blocks]: a column is contiguous
+        if (threadIdx.x == 64) part[64L * gridDim.x + blockIdx.x] = sh_db;
+        return;
+    }
     if (threadIdx.x < 64) atomicAdd(&dw[threadIdx.x], sh_dw[threadIdx.x]);
     if (threadIdx.x == 0) atomicAdd(dbias, sh_db);
+}
+
+// dw[0..63], dbias = sums over the blocks of part [65][blocks]: one workgroup per column, every lane a strided share of the (contiguous)
+// column, the lanes' sums folded in a fixed order
+__global__ __launch_bounds__(256) void aux_bwd_reduce_kernel(const float* __restrict__ part, int blocks, float* __restrict__ dw, float* __restrict__ dbias) {
+    __shared__ float sh[256];
+    const int c = blockIdx.x;
+    const float* col = part + (long)c * blocks;
+    float s = 0.f;
+    for (int r = threadIdx.x; r < blocks; r += 256) s += col[r];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { if (c < 64) dw[c] = sh[0]; else *dbias = sh[0]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -712,14 +747,46 @@ int rpe_aux_head_fwd(int dtype, const void* a1, const float* w, const float* bia
     return 0;
 }
 
+static int aux_bwd_launch(int dtype, const float* dout, long ld_dout, const void* a1, const float* w, const float* depth_feat, const float* raw,
+                          const unsigned char* idx, void* d_a1, float* dw, float* dbias, float* d_depth_feat, int B, int H, int W, float* part,
+                          long part_floats, void* stream);
+
+long rpe_aux_head_bwd_workspace_floats(int dtype, int B, int H, int W) {
+    const long total = (long)B * (H / 2) * (W / 2);
+    return (long)ew_grid(total, (dtype == RPE_F32 ? 16 : 32) * 4) * 65;
+}
+
+/* deterministic form: per-block partial sums through the workspace, added in a fixed order; dw / dbias are OVERWRITTEN */
+int rpe_aux_head_bwd_det(int dtype, const float* dout, long ld_dout, const void* a1, const float* w, const float* depth_feat, const float* raw,
+                         const unsigned char* idx, void* d_a1, float* dw, float* dbias, float* d_depth_feat, int B, int H, int W, float* workspace,
+                         long workspace_floats, void* stream) {
+    if (!workspace || workspace_floats < rpe_aux_head_bwd_workspace_floats(dtype, B, H, W))
+        return rpe_set_error(RPE_ERR_WORKSPACE, "aux_head_bwd_det: workspace smaller than rpe_aux_head_bwd_workspace_floats()");
+    return aux_bwd_launch(dtype, dout, ld_dout, a1, w, depth_feat, raw, idx, d_a1, dw, dbias, d_depth_feat, B, H, W, workspace, workspace_floats, stream);
+}
+
 int rpe_aux_head_bwd(int dtype, const float* dout, long ld_dout, const void* a1, const float* w, const float* depth_feat, const float* raw,
                      const unsigned char* idx, void* d_a1, float* dw, float* dbias, float* d_depth_feat, int B, int H, int W, void* stream) {
+    return aux_bwd_launch(dtype, dout, ld_dout, a1, w, depth_feat, raw, idx, d_a1, dw, dbias, d_depth_feat, B, H, W, nullptr, 0, stream);
+}
+
+static int aux_bwd_launch(int dtype, const float* dout, long ld_dout, const void* a1, const float* w, const float* depth_feat, const float* raw,
+                          const unsigned char* idx, void* d_a1, float* dw, float* dbias, float* d_depth_feat, int B, int H, int W, float* part,
+                          long part_floats, void* stream) {
     const long total = (long)B * (H / 2) * (W / 2);
-    if (dtype == RPE_F32) hipLaunchKernelGGL((aux_bwd_kernel<float>), dim3(ew_grid(total, 16 * 8)), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, (const float*)a1, w, depth_feat, raw, idx, (float*)d_a1, dw, dbias, d_depth_feat, B, H, W);
-    else if (dtype == RPE_BF16) hipLaunchKernelGGL((aux_bwd_kernel<bf16>), dim3(ew_grid(total, 32 * 8)), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, (const bf16*)a1, w, depth_feat, raw, idx, (bf16*)d_a1, dw, dbias, d_depth_feat, B, H, W);
-    else if (dtype == RPE_F16) hipLaunchKernelGGL((aux_bwd_kernel<f16>), dim3(ew_grid(total, 32 * 8)), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, (const f16*)a1, w, depth_feat, raw, idx, (f16*)d_a1, dw, dbias, d_depth_feat, B, H, W);
+    // the gather is latency-bound (winner index -> winner pixel): many short blocks when their sums leave as plain stores (part);
+    // with global atomics every block ends in 65 adds on the same 65 addresses, which is what then bounds the launch: fewer blocks
+    int g = ew_grid(total, (dtype == RPE_F32 ? 16 : 32) * 4);
+    if (!part && g > 1024) g = 1024;
+    if (dtype == RPE_F32) hipLaunchKernelGGL((aux_bwd_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, (const float*)a1, w, depth_feat, raw, idx, (float*)d_a1, dw, dbias, d_depth_feat, B, H, W, part);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((aux_bwd_kernel<bf16>), dim3(g), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, (const bf16*)a1, w, depth_feat, raw, idx, (bf16*)d_a1, dw, dbias, d_depth_feat, B, H, W, part);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((aux_bwd_kernel<f16>), dim3(g), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, (const f16*)a1, w, depth_feat, raw, idx, (f16*)d_a1, dw, dbias, d_depth_feat, B, H, W, part);
     else return rpe_set_error(RPE_ERR_DTYPE, "aux_head: unsupported dtype");
     RPE_CHECK_LAUNCH();
+    if (part) {
+        hipLaunchKernelGGL(aux_bwd_reduce_kernel, dim3(65), dim3(256), 0, (hipStream_t)stream, (const float*)part, g, dw, dbias);
+        RPE_CHECK_LAUNCH();
+    }
     return 0;
 }
 

@@ -267,8 +267,14 @@ class AuxHeadOp:
             gb = torch.zeros(1, dtype=torch.float32, device=dev)
         d_feat = torch.empty((b, n), dtype=torch.float32, device=dev) if feat is not None else None
         s = ops._stream()
-        lib.rpe_aux_head_bwd(ops.dtype_code(a1), ops._p(d_cols), d_cols.stride(0), ops._p(a1), ops._p(self.conv_w.data), ops._p(feat), ops._p(raw),
-                             ops._p(idx), ops._p(d_a1), ops._p(gw), ops._p(gb), ops._p(d_feat), b, h, w, s)
+        # parameter gradients through per-block partial sums added in a fixed order (bitwise reproducible, and faster than 65 global
+        # atomics per block on the same 65 addresses)
+        code = ops.dtype_code(a1)
+        nws = lib.rpe_aux_head_bwd_workspace_floats(code, b, h, w)
+        if getattr(self, "_part", None) is None or self._part.numel() < nws or self._part.device != dev:
+            self._part = torch.empty(nws, dtype=torch.float32, device=dev)
+        lib.rpe_aux_head_bwd_det(code, ops._p(d_cols), d_cols.stride(0), ops._p(a1), ops._p(self.conv_w.data), ops._p(feat), ops._p(raw),
+                                 ops._p(idx), ops._p(d_a1), ops._p(gw), ops._p(gb), ops._p(d_feat), b, h, w, ops._p(self._part), self._part.numel(), s)
         if not dense:
             self._keep = (d_cols, feat, idx)   # alive until the trunk backward has been enqueued
             plan.set_aux_grad(d_cols, feat, idx, self.conv_w.data)

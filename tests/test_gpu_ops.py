@@ -460,6 +460,16 @@ def test_aux_and_depth_heads(dtype, use_depth):
     t = 1e-4 if dtype == torch.float32 else 2e-2
     assert rel_err(nchw(d_a1), grads[0]) < t
     assert rel_err(gw, grads[1].reshape(64)) < t and rel_err(gb, grads[2]) < t
+    # the deterministic form: per-block partial sums through a workspace, overwriting; repeats bitwise
+    ws = torch.empty(lib.rpe_aux_head_bwd_workspace_floats(code, b, h, h), device=DEV)
+    gw2, gb2 = torch.full((64,), 7.0, device=DEV), torch.full((1,), 7.0, device=DEV)
+    args = (code, P(doutd), ld, P(a1d), P(wd), None if feat is None else P(feat), P(raw), P(idx), None, P(gw2), P(gb2),
+            None if d_feat is None else P(d_feat), b, h, h, P(ws), ws.numel(), S)
+    lib.rpe_aux_head_bwd_det(*args)
+    assert rel_err(gw2, grads[1].reshape(64)) < t and rel_err(gb2, grads[2]) < t
+    first = (gw2.clone(), gb2.clone())
+    lib.rpe_aux_head_bwd_det(*args)
+    assert torch.equal(gw2, first[0]) and torch.equal(gb2, first[1])
     if use_depth:
         gdw, gdb = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
         lib.rpe_depth_head_bwd(P(d_feat), P(xhat), b * n, P(gdw), P(gdb), S)
