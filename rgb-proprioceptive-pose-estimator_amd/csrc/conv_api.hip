@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256) void bn_fold_g_kernel(const float* __restrict_
 
 // The whole fold preparation in ONE launch (it sits on the data-gradient chain, once per bottleneck block: the four-launch form --
 // scale, G GEMM, slab sum, transpose-convert -- cost ~40 us there).  Blocks [0, (Ci/64)^2): a 64 x 64 tile of
-// G[n][n'] = sum_k wd[n][k] C'_k wd[n'][k] on the matrix cores straight from global memory (the weights are L2-resident; 4 waves
-// of 32 x 32, the C' scaling applied to the n' operand in registers), written as wk[n][Co + n'].  The remaining blocks: four rows n
+// G[n][n'] = sum_k wd[n][k] C'_k wd[n'][k] on the matrix cores straight from global memory (the weights are L2-resident; the 4 waves
+// split K, the C' scaling applied to the n' operand in registers), written as wk[n][Co + n'].  The remaining blocks: four rows n
 // of wk[n][k] = A_k wd[n][k] and bias[n] = sum_k B'_k wd[n][k] each.  wd = [Ci][Co], the data-gradient copy of the weight.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_fold_fused_kernel(const T* __restrict__ wd, const float* __restrict__ gamma, const float* __restrict__ invstd,
@@ -191,55 +191,94 @@ __global__ __launch_bounds__(256) void bn_fold_fused_kernel(const T* __restrict_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long ldk = (long)Co + Ci;
     if ((int)blockIdx.x < nG) {
+        // one 64 x 64 tile of G per block; the four waves split K = Co (each walks a quarter: all its loads in flight at once) and
+        // their accumulators meet through LDS in wave order
         for (int k = threadIdx.x; k < Co; k += 256) cp_s[k] = -gamma[k] * invstd[k] * invstd[k] * c2[k];
         __syncthreads();
+        f32x4* red = (f32x4*)(cp_s + Co);                        // [16 fragments][64 lanes]
         const int bi = blockIdx.x / gt, bj = blockIdx.x - bi * gt;
-        const int i0 = bi * 64 + (wave >> 1) * 32, j0 = bj * 64 + (wave & 1) * 32;   // rows n (plain operand) / columns n' (scaled operand)
+        const int i0 = bi * 64, j0 = bj * 64;                    // rows n (plain operand) / columns n' (scaled operand)
         const int fr = lane & 15, fc = lane >> 4;
-        f32x4 acc[2][2];
+        f32x4 acc[4][4];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int kq = Co / 4, kbeg = wave * kq;
 #pragma unroll 4
-        for (int k0 = 0; k0 < Co; k0 += KS) {
+        for (int k0 = kbeg; k0 < kbeg + kq; k0 += KS) {
             const int k = k0 + fc * CE;
-            u32x4 am[2], bn[2];
+            u32x4 am[4], bn[4];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) am[mi] = *(const u32x4*)(wd + (long)(i0 + mi * 16 + fr) * Co + k);
+            for (int mi = 0; mi < 4; ++mi) am[mi] = *(const u32x4*)(wd + (long)(i0 + mi * 16 + fr) * Co + k);
 #pragma unroll
-            for (int nj = 0; nj < 2; ++nj) {
+            for (int nj = 0; nj < 4; ++nj) bn[nj] = *(const u32x4*)(wd + (long)(j0 + nj * 16 + fr) * Co + k);
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) {
                 float v[CE];
-                chunk_to_f<T>(*(const u32x4*)(wd + (long)(j0 + nj * 16 + fr) * Co + k), v);
+                chunk_to_f<T>(bn[nj], v);
 #pragma unroll
                 for (int e = 0; e < CE; ++e) v[e] *= cp_s[k + e];
                 bn[nj] = f_to_chunk<T>(v);
             }
 #pragma unroll
-            for (int nj = 0; nj < 2; ++nj)
+            for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) Mma<T>::run(bn[nj], am[mi], acc[nj][mi]);
+                for (int mi = 0; mi < 4; ++mi) Mma<T>::run(bn[nj], am[mi], acc[nj][mi]);
         }
+        for (int r = 1; r < 4; ++r) {                            // waves 1, 2, 3 hand their tiles to wave 0, in that order
+            if (wave == r) {
 #pragma unroll
-        for (int nj = 0; nj < 2; ++nj)
+                for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                T* dst = wk + (long)(i0 + mi * 16 + fr) * ldk + Co + j0 + nj * 16 + fc * 4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) dst[e] = Elem<T>::from_f(acc[nj][mi][e]);
+                    for (int mi = 0; mi < 4; ++mi) red[(nj * 4 + mi) * 64 + lane] = acc[nj][mi];
             }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) acc[nj][mi] += red[(nj * 4 + mi) * 64 + lane];
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    T* dst = wk + (long)(i0 + mi * 16 + fr) * ldk + Co + j0 + nj * 16 + fc * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dst[e] = Elem<T>::from_f(acc[nj][mi][e]);
+                }
+        }
         return;
     }
+    // rows: the per-channel coefficients once per block (A_k, B'_k in LDS), then one wave per row n, 16-byte chunks per lane
+    float* a_s = cp_s;
+    float* bp_s = cp_s + Co;
+    for (int k = threadIdx.x; k < Co; k += 256) {
+        const float a = gamma[k] * invstd[k];
+        const float cp = -a * invstd[k] * c2[k];
+        a_s[k] = a;
+        bp_s[k] = -a * c1[k] - cp * mean[k];
+    }
+    __syncthreads();
     const int row = ((int)blockIdx.x - nG) * 4 + wave;
     if (row >= Ci) return;
     float acc = 0.f;
-    for (int k = lane; k < Co; k += 64) {
-        const float a = gamma[k] * invstd[k];
-        const float cp = -a * invstd[k] * c2[k];
-        const float bp = -a * c1[k] - cp * mean[k];
-        const float w = Elem<T>::to_f(wd[(long)row * Co + k]);
-        wk[(long)row * ldk + k] = Elem<T>::from_f(a * w);
-        acc = fmaf(bp, w, acc);
+    for (int k = lane * CE; k < Co; k += 64 * CE) {
+        float w[CE];
+        chunk_to_f<T>(*(const u32x4*)(wd + (long)row * Co + k), w);
+        float o[CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { o[e] = a_s[k + e] * w[e]; acc = fmaf(bp_s[k + e], w[e], acc); }
+        T* dst = wk + (long)row * ldk + k;
+        if ((((long)row * ldk + k) * (long)sizeof(T)) % 16 == 0) *(u32x4*)dst = f_to_chunk<T>(o);
+        else {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) dst[e] = Elem<T>::from_f(o[e]);
+        }
     }
     acc = wave_sum(acc);
     if (lane == 0) bias[row] = acc;
@@ -249,9 +288,9 @@ template <typename T>
 static int bn_fold_t(int Co, int Ci, const void* wf, const void* wd, const float* gamma, const float* invstd, const float* mean, const float* c1c2,
                      void* w_kcat, float* bias, void* scratch, long scratch_bytes, hipStream_t s) {
     static const bool unfused = getenv("RPE_FOLD_PREP_UNFUSED") != nullptr;
-    if (!unfused && (Ci % 64) == 0 && (Co % (4 * Elem<T>::kChunk)) == 0 && Co <= 8192) {
+    if (!unfused && (Ci % 64) == 0 && (Co % (16 * Elem<T>::kChunk)) == 0 && Co <= 8192) {
         const int gt = Ci / 64;
-        hipLaunchKernelGGL((bn_fold_fused_kernel<T>), dim3(gt * gt + (Ci + 3) / 4), dim3(256), (size_t)Co * 4, s, (const T*)wd, gamma, invstd, mean, c1c2,
+        hipLaunchKernelGGL((bn_fold_fused_kernel<T>), dim3(gt * gt + (Ci + 3) / 4), dim3(256), (size_t)Co * 8 + 16 * 64 * 16, s, (const T*)wd, gamma, invstd, mean, c1c2,
                            c1c2 + Co, (T*)w_kcat, bias, Co, Ci);
         RPE_CHECK_LAUNCH();
         note_kernel("bn_fold_fused_kernel");
