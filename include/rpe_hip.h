@@ -217,6 +217,10 @@ int rpe_bn_backward(int dtype, const void* dA, const void* a_out, const void* y,
                     const float* gamma, float* dgamma, float* dbeta, void* dy, void* dz_out, long rows, int C, float* part,
                     long part_floats, float* c1c2, double* dpart, void* stream);
 
+/* The reduction half of rpe_bn_backward alone (dgamma, dbeta, c1c2 = mean(dz), mean(dz * xhat)): for a BatchNorm whose apply pass is
+ * folded into its consumers and whose sums no fused data-gradient epilogue has produced (the stride-1 projection shortcut). */
+int rpe_bn_backward_reduce(int dtype, const void* dA, const void* a_out, const void* y, const float* mean, const float* invstd, const float* gamma,
+                           float* dgamma, float* dbeta, long rows, int C, float* part, long part_floats, float* c1c2, double* dpart, void* stream);
 /* second half of the fused form: partial sums -> dgamma, dbeta; dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)).
  * dy may alias dz. */
 int rpe_bn_backward_from_dz(int dtype, const void* dz, const void* y, const float* mean, const float* invstd, const float* gamma,

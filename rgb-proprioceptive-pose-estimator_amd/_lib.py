@@ -51,6 +51,7 @@ _SPEC = {
     "rpe_conv2d_dgrad": (I, [PD, I, P, P, P, P, P]),
     "rpe_conv2d_dgrad_stats_tiles": (L, [PD]),
     "rpe_conv2d_dgrad_bn": (I, [PD, I, P, P, P, P, POINTER(BnBwdEpilogue), P]),
+    "rpe_bn_backward_reduce": (I, [I, P, P, P, P, P, P, P, P, L, I, P, L, P, P, P]),
     "rpe_bn_backward_from_dz": (I, [I, P, P, P, P, P, P, I, P, P, P, L, I, P, P, P]),
     "rpe_bn_bwd_fold_scratch_bytes": (L, [I, I, I]),
     "rpe_bn_bwd_fold_conv1x1": (I, [I, I, I, P, P, P, P, P, P, P, P, P, L, P]),

@@ -1029,6 +1029,7 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
             for (int j = 0; j <= bi; ++j) layer += e->blocks[j].cd >= 0;
             if (layer >= 2 && layer <= 4) hook_in = e->hook_grad[layer - 1];
         }
+        static const bool ds_fold_ok = getenv("RPE_NO_DS_FOLD") == nullptr;
         static const bool cd_side_ok = getenv("RPE_CD_SIDE") != nullptr;
         const bool cd_on_side = b.cd >= 0 && cd_side_ok && e->overlap && e->side && bi != (int)e->blocks.size() - 1;
         hipEvent_t cd_done = nullptr;
@@ -1076,6 +1077,42 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
             if (cd_on_side) {
                 HIPTRY(hipEventRecord(cd_done, e->side));
                 HIPTRY(hipStreamWaitEvent((hipStream_t)stream, cd_done, 0));   // the shortcut gradient is what the block's last data gradient adds
+            } else if (ds_fold_ok && e->fold && e->train_mode && e->fold_w && e->wfold_scratch && !hook_in && cd.d.kh == 1 && cd.d.stride == 1 &&
+                       cd.d.pad == 0 && cd.d.in_c <= e->fold_w_max && (cd.d.out_c % 128) == 0 && (cd.d.in_c % 64) == 0) {
+                // stride-1 projection shortcut (layer1): its BatchNorm backward folds into the 1x1 conv like conv3's -- one reduction pass
+                // (dz = gA, no mask), then the K-concatenated data gradient and the folded weight gradient; no dy, no apply pass
+                e->pending_bytes = conv_out_bytes(e, cd) * 2.0;
+                PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_backward_reduce(e->dtype, gA, nullptr, cd.y, cd.mean, cd.invstd, e->params[cd.p_g], e->grads[cd.p_g],
+                                                                        e->grads[cd.p_b], cd.rows, cd.d.out_c, e->bwd_part, e->bwd_part_floats, cd.c1c2, e->dpart, stream));
+                {
+                    ConvL* cp = &cd;
+                    auto side_part = [e, cp, gA, x_in](hipStream_t run) -> int {
+                        ConvL& c = *cp;
+                        e->pending_flops = conv_flops(c) * (1.0 + (double)c.d.in_c / c.d.out_c);
+                        e->pending_bytes = conv_out_bytes(e, c) + 3.0 * conv_in_bytes(e, c);
+                        PROF(e, RPE_PROF_CONV_WGRAD, run, rpe_conv1x1_wgrad_folded(&c.d, e->dtype, gA, x_in, e->params[c.p_w], e->params[c.p_g], c.invstd, c.mean, c.c1c2,
+                                                                                  e->grads[c.p_w], e->wfold_scratch, e->wfold_scratch_bytes, run));
+                        return 0;
+                    };
+                    if (e->overlap && e->side) {
+                        if (e->defer_side) e->side_work.push_back(side_part);
+                        else {
+                            hipEvent_t ready = sync_event(e);
+                            if (!ready) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
+                            HIPTRY(hipEventRecord(ready, (hipStream_t)stream));
+                            HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
+                            TRY(side_part(e->side));
+                        }
+                    } else {
+                        TRY(side_part((hipStream_t)stream));
+                    }
+                }
+                e->pending_bytes = 0;
+                PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_bwd_fold_conv1x1(e->dtype, cd.d.out_c, cd.d.in_c, fwd_weight(e, cd), cd.wd, e->params[cd.p_g], cd.invstd, cd.mean,
+                                                                          cd.c1c2, e->w_kcat, e->fold_bias, e->fold_scratch, e->fold_scratch_bytes, stream));
+                e->pending_flops = conv_flops(cd) * (1.0 + (double)cd.d.in_c / cd.d.out_c);
+                e->pending_bytes = conv_out_bytes(e, cd) + conv_in_bytes(e, cd) * 2.0;
+                PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv1x1_dgrad_kcat(&cd.d, e->dtype, gA, x_in, e->w_kcat, e->fold_bias, e->G[0], nullptr, stream));
             } else {
                 TRY(bn_back(e, cd, gA, 0, cd.dy, nullptr, stream));          // no ReLU on the projection shortcut
                 TRY(wgrad(e, cd, x_in, cd.dy, stream));

@@ -864,6 +864,7 @@ int bn_bwd_launch(const void* dA, const void* a_out, const void* y, const float*
     float* c1 = c1c2;
     float* c2 = c1c2 + C;
     if (int e = reduce_finalize(part, (int)nb, C, dpart, BnBwdFin{(double)M, dgamma, dbeta, c1, c2}, s)) return e;
+    if (!dy) return 0;   // statistics only (rpe_bn_backward_reduce): the apply pass is folded into the consumers
     // no ReLU in front and no dz wanted (projection-shortcut BNs): dz == dA, the streaming dz -> dy kernel does the third pass
     if (!a_out && !dz_out && (256 % (C / CE) == 0 || (C / CE) % 256 == 0)) return bn_apply_dz_launch<T>(dA, y, mean, invstd, gamma, c1, c2, dy, M, C, s);
     const long n = M * C / CE;
@@ -993,6 +994,17 @@ int rpe_bn_backward(int dtype, const void* dA, const void* a_out, const void* y,
     if (dtype == RPE_F16)
         return bn_bwd_launch<f16>(dA, a_out, y, mean, invstd, gamma, dgamma, dbeta, dy, dz_out, rows, C, part, part_floats, c1c2, dpart, (hipStream_t)stream);
     return rpe_set_error(RPE_ERR_DTYPE, "bn_backward: unsupported dtype");
+}
+
+/* the reduction half alone: dgamma, dbeta and c1c2 = (mean(dz), mean(dz * xhat)) -- for a BatchNorm whose apply pass is folded into
+ * its consumers (rpe_bn_bwd_fold_conv1x1 / rpe_conv1x1_wgrad_folded) and whose sums no fused epilogue has produced */
+int rpe_bn_backward_reduce(int dtype, const void* dA, const void* a_out, const void* y, const float* mean, const float* invstd, const float* gamma,
+                           float* dgamma, float* dbeta, long rows, int C, float* part, long part_floats, float* c1c2, double* dpart, void* stream) {
+    note_kernel("bn_bwd_reduce_kernel + reduce_finalize_kernel<BnBwdFin>");
+    if (dtype == RPE_F32) return bn_bwd_launch<float>(dA, a_out, y, mean, invstd, gamma, dgamma, dbeta, nullptr, nullptr, rows, C, part, part_floats, c1c2, dpart, (hipStream_t)stream);
+    if (dtype == RPE_BF16) return bn_bwd_launch<bf16>(dA, a_out, y, mean, invstd, gamma, dgamma, dbeta, nullptr, nullptr, rows, C, part, part_floats, c1c2, dpart, (hipStream_t)stream);
+    if (dtype == RPE_F16) return bn_bwd_launch<f16>(dA, a_out, y, mean, invstd, gamma, dgamma, dbeta, nullptr, nullptr, rows, C, part, part_floats, c1c2, dpart, (hipStream_t)stream);
+    return rpe_set_error(RPE_ERR_DTYPE, "bn_backward_reduce: unsupported dtype");
 }
 
 int rpe_bn_backward_from_dz(int dtype, const void* dz, const void* y, const float* mean, const float* invstd, const float* gamma,

@@ -51,7 +51,7 @@ ENGINE_VARIANTS = [
     # projection-shortcut backward on the side stream; its BN as a pass of its own; folded weight gradient for layers 1-2 only;
     # inference convs unsplit and few-row Linear layers on the MFMA tile kernel
     # (the golden case's eval / rollout outputs run at 2-4 images: the default takes the split-K and per-column kernels there)
-    {"RPE_CD_SIDE": "1", "RPE_NO_SPLITK": "1", "RPE_NO_LINEAR_ROWS": "1", "RPE_NO_DS_FUSE": "1", "RPE_WGRAD_FOLD_MAX": "128", "RPE_FOLD_PREP_UNFUSED": "1", "RPE_NO_LINEAR_SPLITK": "1"},
+    {"RPE_CD_SIDE": "1", "RPE_NO_SPLITK": "1", "RPE_NO_LINEAR_ROWS": "1", "RPE_NO_DS_FUSE": "1", "RPE_WGRAD_FOLD_MAX": "128", "RPE_FOLD_PREP_UNFUSED": "1", "RPE_NO_LINEAR_SPLITK": "1", "RPE_NO_DS_FOLD": "1"},
 ]
 
 
