@@ -101,16 +101,17 @@ template <typename T> struct NTArgs {
 
 // split plan of an inference-forward launch with 64 x 64 tiles and K steps of `bk` elements: number of splits (1 = not
 // split) and K steps per split.  A split launch costs a second (epilogue) launch, so it must buy at least 4x the workgroups.
-// linear: the few-row fp32 Linear layers of the heads (256 x 3655 -> 1024: 64 tiles walking 229 K steps alone) aim at 256 workgroups.
+// linear: the few-row fp32 Linear layers of the heads (256 x 3655 -> 1024: 64 tiles walking 229 K steps alone; the LSTM input
+// projections 256 x 3648 -> 2048: 128 tiles) aim at 512 workgroups.
 static inline int nt_split_plan(long M, int N, int K, int bk, int* steps_per_split, bool linear = false) {
     const long tiles = ((M + 63) / 64) * ((N + 63) / 64);
     const int nk = (K + bk - 1) / bk;
     if (steps_per_split) *steps_per_split = nk;
-    if (M > 1024 || tiles >= (linear ? 128 : 64) || nk < 32) return 1;
-    long S = ((linear ? 256 : 128) + tiles - 1) / tiles;
+    if (M > 1024 || tiles >= (linear ? 256 : 64) || nk < 32) return 1;
+    long S = ((linear ? 512 : 128) + tiles - 1) / tiles;
     if (S > nk / 8) S = nk / 8;
     if (S > 32) S = 32;
-    if (S < (linear ? 3 : 4)) return 1;
+    if (S < (linear ? 2 : 4)) return 1;
     const int steps = (nk + (int)S - 1) / (int)S;
     if (steps_per_split) *steps_per_split = steps;
     return (nk + steps - 1) / steps;
