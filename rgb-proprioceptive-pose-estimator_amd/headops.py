@@ -140,17 +140,17 @@ class LSTMOp:
         dgates = torch.empty((S, N, 4 * H), dtype=torch.float32, device=dev)
         dc = torch.zeros((N, H), dtype=torch.float32, device=dev)
         whh_t = ops.transpose_f32(self.w_hh.data, ldo=4 * H)  # [H, 4H]
-        dh_rec = None
         s = ops._stream()
-        dh_all = dh_all.reshape(S, N, H)
+        dh_all = dh_all.reshape(S, N, H).contiguous()
+        dh = dh_all[S - 1]
         for t in reversed(range(S)):
-            dh = dh_all[t] if dh_rec is None else dh_all[t] + dh_rec
-            dh = dh.contiguous()
             c_prev = self.c0 if t == 0 else self.cs[t - 1]
             lib.rpe_lstm_cell_bwd(ops._p(self.gates[t]), ops._p(c_prev), ops._p(self.cs[t]), ops._p(dh), ops._p(dc), ops._p(dgates[t]), N, H, s)
-            if t > 0 or self.h0 is not None:
-                dh_rec = new_rows(N, H, dev)
-                ops.linear_fwd(dgates[t], whh_t, None, out=dh_rec, n=H, k=4 * H)
+            if t > 0:
+                # gradient of h_{t-1}: its own output gradient + the recurrent term, in one launch (the GEMM's addend); H % 4 == 0,
+                # so the row buffer has no padding columns to zero
+                dh = new_rows(N, H, dev, zero=False)
+                ops.linear_fwd(dgates[t], whh_t, None, out=dh, addend=dh_all[t - 1], n=H, k=4 * H)
         dg = dgates.view(S * N, 4 * H)
         g_hh = _grad_of(self.w_hh)
         g_hh.zero_()
