@@ -78,9 +78,7 @@ class LinearOp:
             dy = ops.relu_bwd(ypad, dypad)[:, :n]
         gw = _grad_of(self.weight)
         if k % 4 == 0 and gw.is_contiguous():
-            if not accumulate:
-                gw.zero_()
-            ops.linear_wgrad(dy, x, gw, n=n, k=k)
+            ops.linear_wgrad(dy, x, gw, n=n, k=k, overwrite=not accumulate)   # (overwriting: no zero fill in front)
         else:
             tmp = torch.zeros((n, pad4(k)), dtype=torch.float32, device=dy.device)
             ops.linear_wgrad(dy, x, tmp, n=n, k=pad4(k))

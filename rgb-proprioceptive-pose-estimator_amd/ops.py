@@ -404,16 +404,19 @@ def linear_fwd(x, w, bias=None, relu=False, addend=None, out=None, n=None, k=Non
     return out
 
 
-def linear_wgrad(dy, x, dw, n=None, k=None, deterministic=True):
+def linear_wgrad(dy, x, dw, n=None, k=None, deterministic=True, overwrite=False):
     """dw[:N, :K] (fp32) += dy[M, :N]^T @ x[M, :K].  deterministic: per-workgroup slabs summed in a fixed order, then ONE add
-    into dw per element (bitwise reproducible); else fp32 atomics."""
+    into dw per element (bitwise reproducible); else fp32 atomics.  overwrite (deterministic form only): dw = ... instead of +=."""
     m = x.shape[0]
     n = dy.shape[1] if n is None else n
     k = x.shape[1] if k is None else k
     if deterministic:
         ws = scratch(lib.rpe_linear_wgrad_workspace_bytes(dtype_code(x), m, n, k), x.device)
-        lib.rpe_linear_wgrad_det(dtype_code(x), _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw.stride(0), m, n, k, 1, _p(ws), ws.numel(), _stream())
+        lib.rpe_linear_wgrad_det(dtype_code(x), _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw.stride(0), m, n, k, 0 if overwrite else 1, _p(ws),
+                                 ws.numel(), _stream())
         return dw
+    if overwrite:
+        dw.zero_()
     lib.rpe_linear_wgrad(dtype_code(x), _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw.stride(0), m, n, k, _stream())
     return dw
 
