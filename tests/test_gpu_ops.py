@@ -740,6 +740,7 @@ def test_operands_above_2_gib():
     descriptors now start at each tile's / split's first row or image: convs whose activation tensors exceed 2 GiB must equal the same
     convs run on their two halves (forward, data gradient, weight gradient; 1x1 dense and 3x3 gathered)."""
     dtype = torch.bfloat16
+    torch.cuda.empty_cache()
     g = torch.Generator().manual_seed(3)
     b, h, ci, co = 1400, 28, 1024, 64                                  # 1x1: x [1400,28,28,1024] = 2.25 GB in, 64 channels out
     x = torch.randn(b // 2, h, h, ci, generator=g).to(dtype)
