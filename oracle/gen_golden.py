@@ -335,6 +335,79 @@ def run_hooks(tag, case):
     print("no_%s loss" % tag, rec["loss_s1"])
 
 
+# BASELINE.json configs[2..4] at the head sizes the reference's scripts train (scripts/train_model.py:25,180-181 latent 512 / hidden 512;
+# scripts/train_tdo_v2.sbatch:68-70 proprio hidden 64): TD, TDO (+ depth head) and TDO-V2 on sequences of four frames, eight episodes
+# (lead dims (S, N) = (4, 8): 32 images -- what the CPU reference steps through in seconds).  Pristine eval outputs, step-1 outputs /
+# loss / val metrics, a digest of every gradient, the small gradients whole and a strided sample of the large ones (the LSTM input
+# projections are 2048 x 3648..3655: 30 MB each).
+SEQ_CFG = {
+    "td": (dict(latent_dim=512, hidden=512, use_depth=False), (4, 8), 71, 701),
+    "tdo": (dict(latent_dim=512, hidden=512, use_depth=True, no_proprioception=False), (4, 8), 72, 702),
+    "tdo_v2": (dict(latent_dim=512, hidden=512, proprio_hidden=64, use_depth=False), (4, 8), 73, 703),
+}
+SEQ_SAMPLE_STRIDE, SEQ_SAMPLE_MAX = 499, 16384
+
+
+def run_seq_cfg(kind):
+    cfg, lead, wseed, dseed = SEQ_CFG[kind]
+    torch.manual_seed(0)
+    L, S = cfg["latent_dim"], lead[0]
+    if kind == "td":
+        model = TemporallyDependentStateEstimator(cfg["hidden"], cfg["hidden"], 50, L, S, 0.1, False, (9,), cfg["use_depth"], False)
+    elif kind == "tdo":
+        model = TemporallyDependentObjectStateEstimator("hammer", cfg["hidden"], 50, L, S, 0.1, False, (9,), cfg["use_depth"], False, cfg["no_proprioception"])
+    else:
+        model = TemporallyDependentObjectStateEstimatorV2("robot1_eef", cfg["hidden"], cfg["proprio_hidden"], 50, L, S, 0.1, False, (9,), cfg["use_depth"], False)
+    sd = po.make_state(kind, cfg, wseed)
+    ref_keys = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    assert ref_keys == [(k, tuple(s)) for k, s in po.model_keys(kind, cfg) if not k.startswith("~")], "state_dict key table mismatch (%s, config size)" % kind
+    load_values(model, kind, sd)
+    rec = {"keys": np.array([k for k, _ in ref_keys])}
+    use_depth = cfg.get("use_depth", False)
+    model.eval()
+    model.reset_initial_state(lead[-1])
+    with torch.no_grad():
+        b = po.synth_batch(lead, dseed + 9, with_depth=use_depth)
+        depth = b["depth"] if b["depth"] is not None else torch.empty(*b["img"].shape)
+        out = model(b["img"], depth, b["x0bar"])
+        if isinstance(out, tuple):
+            rec["pre_eval_out0"], rec["pre_eval_out1"] = out[0].numpy(), out[1].numpy()
+        else:
+            rec["pre_eval_out0"] = out.numpy()
+    model.train()
+    model.reset_initial_state(lead[-1])
+    b = po.synth_batch(lead, dseed + 1, with_depth=use_depth)
+    depth = b["depth"] if b["depth"] is not None else torch.empty(*b["img"].shape)
+    out = model(b["img"], depth, b["x0bar"])
+    crit = PoseDistanceLoss(**LOSS_CFG)
+    val = PoseDistanceLoss(mode="val")
+    if kind == "td":
+        loss = crit(out[0], b["x0"]) + crit(out[1], b["x1"])
+        pe, oe = val(out[1], b["x1"])
+        rec["out0_s1"], rec["out1_s1"] = out[0].detach().numpy(), out[1].detach().numpy()
+    else:
+        loss = crit(out, b["obj"])
+        pe, oe = val(out, b["obj"])
+        rec["out0_s1"] = out.detach().numpy()
+    loss.backward()
+    rec["loss_s1"], rec["pos_err_s1"], rec["ori_err_s1"] = np.array(loss.item()), np.array(float(pe)), np.array(float(oe))
+    gn, gd = [], []
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        gn.append(name)
+        gd.append(digest(p.grad))
+        g = p.grad.detach().flatten()
+        head = not name.startswith("feature_net") or ".fc." in name
+        if g.numel() <= 4096:
+            rec["grad::" + name] = g.numpy().copy()
+        elif head:
+            rec["gsample::" + name] = g[::SEQ_SAMPLE_STRIDE][:SEQ_SAMPLE_MAX].numpy().copy()
+    rec["grad_keys_s1"], rec["grad_digest_s1"] = np.array(gn), np.stack(gd)
+    np.savez_compressed(os.path.join(OUT, "model_%s_cfg.npz" % kind), **rec)
+    print("%s_cfg loss" % kind, rec["loss_s1"], "pos/ori err", rec["pos_err_s1"], rec["ori_err_s1"])
+
+
 def run_loss():
     g = torch.Generator().manual_seed(7)
     rec = {}
@@ -365,7 +438,7 @@ def run_loss():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["loss"] + list(CASES) + ["c1", "r101", "td_s4", "hooks", "nohook"]
+    which = sys.argv[1:] or ["loss"] + list(CASES) + ["c1", "r101", "td_s4", "hooks", "nohook", "td_cfg", "tdo_cfg", "tdo_v2_cfg"]
     for w in which:
         if w == "loss":
             run_loss()
@@ -379,5 +452,7 @@ if __name__ == "__main__":
             run_hooks("hooks", HOOKS)
         elif w == "nohook":
             run_hooks("nohook", NOHOOK)
+        elif w.endswith("_cfg"):
+            run_seq_cfg(w[:-4])
         else:
             run_case(w)

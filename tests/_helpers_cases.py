@@ -19,3 +19,11 @@ TD_S4 = (dict(latent_dim=64, hidden=32, use_depth=False), (4, 2), 51, 501)
 # -- must match oracle/gen_golden.py HOOKS / NOHOOK
 HOOKS = (dict(latent_dim=64, hidden=[32], use_depth=True, no_proprioception=False, hooks=(3, 0, 9, 2, 1)), (2,), 61, 601)
 NOHOOK = (dict(latent_dim=64, hidden=[32], use_depth=False, no_proprioception=False, hooks=None), (2,), 62, 602)
+# BASELINE.json configs[2..4] at the head sizes the reference's scripts train (latent 512, hidden 512, proprio hidden 64), lead dims
+# (S, N) = (4, 8) -- must match oracle/gen_golden.py SEQ_CFG
+SEQ_CFG = {
+    "td": (dict(latent_dim=512, hidden=512, use_depth=False), (4, 8), 71, 701),
+    "tdo": (dict(latent_dim=512, hidden=512, use_depth=True, no_proprioception=False), (4, 8), 72, 702),
+    "tdo_v2": (dict(latent_dim=512, hidden=512, proprio_hidden=64, use_depth=False), (4, 8), 73, 703),
+}
+SEQ_SAMPLE_STRIDE, SEQ_SAMPLE_MAX = 499, 16384
