@@ -95,21 +95,6 @@ typedef struct {
 long rpe_conv2d_dgrad_stats_tiles(const rpe_conv_desc* d);
 int rpe_conv2d_dgrad_bn(const rpe_conv_desc* d, int dtype, const void* dy, const void* w_crsk, void* dz, const void* addend,
                         const rpe_bn_bwd_epilogue* bn, void* stream);
-/* BatchNorm statistics of a 1x1 conv WITHOUT its output: y = x W^T gives mean_c = w_c . colsum(x) / M and E[y_c^2] = w_c^T (x^T x) w_c / M.
- * rpe_gram: x [M][C] -> out fp32 [rpe_gram_ones_row(C) + 1][C]: x^T x in rows [0, C), colsum(x) in row rpe_gram_ones_row(C) (one
- * weight-gradient-style launch, fixed-order slab sum).  rpe_bn_stats_from_gram: what rpe_bn_finalize produces (scale, shift, saved
- * mean / invstd, running statistics), from the Gram matrix and the compute-dtype weight.  rpe_conv1x1_fwd_bn: the conv with
- * out = relu(acc * scale + shift + residual [* res_scale + res_shift]) and the packed ReLU mask in its epilogue -- the raw output
- * is written only when y_out is given.  Replaces conv3 -> bn3 -> (+identity) -> ReLU of torchvision's Bottleneck in training
- * (16-bit element types; the fp32 parity path keeps conv -> statistics -> apply). */
-long rpe_gram_ones_row(int C);
-long rpe_gram_workspace_bytes(int dtype, long M, int C);
-int rpe_gram(int dtype, const void* x, long M, int C, float* out, void* workspace, long workspace_bytes, void* stream);
-int rpe_bn_stats_from_gram(int dtype, const void* w, int Co, int Ci, const float* gram, int ones_row, long count, const float* gamma, const float* beta,
-                           float* running_mean, float* running_var, long long* num_batches, float momentum, float eps, float* scale, float* shift,
-                           float* save_mean, float* save_invstd, void* stream);
-int rpe_conv1x1_fwd_bn(const rpe_conv_desc* d, int dtype, const void* x, const void* w, void* out, void* y_out, const float* scale, const float* shift,
-                       const void* residual, const float* res_scale, const float* res_shift, unsigned char* relu_mask, void* stream);
 /* BatchNorm backward folded into the data gradient of the 1x1 / stride-1 conv in front of it (y = a_in W^T, z = BN(y)):
  *   dx = dz (A o W) + a_in G + 1 b^T   with A = gamma invstd, G = W^T diag(C') W, b = W^T B'  (C', B' from the BN coefficients),
  * so the data gradient reads dz and the conv's INPUT instead of a materialised dy = BN'(dz, y).

@@ -408,6 +408,49 @@ def run_seq_cfg(kind):
     print("%s_cfg loss" % kind, rec["loss_s1"], "pos/ori err", rec["pos_err_s1"], rec["ori_err_s1"])
 
 
+# models/losses.py:68-69 normalises the predicted quaternion without an epsilon, and NaiveObjectStateEstimator ends in a ReLU
+# (models/naive.py:343-345): a sample whose four quaternion outputs are all clipped to zero makes the LOSS VALUE NaN, while the
+# ReLU's backward (a select on the output sign) keeps every gradient finite and the step is still applied.  Forced here for every
+# sample through the last layer's bias / weights (quaternion rows: zero weights, bias -1); recorded: outputs, the NaN loss, every gradient, the parameters after one Adam step.
+def run_nan_loss():
+    cfg, lead, wseed, dseed = CASES["no"]
+    torch.manual_seed(0)
+    model = build("no", cfg)
+    sd = po.make_state("no", cfg, wseed)
+    last = "fc%d.module" % len(cfg["hidden"])
+    sd[last + ".weight"][3:7] = 0.0
+    sd[last + ".bias"][3:7] = -1.0
+    load_values(model, "no", sd)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    b = po.synth_batch(lead, dseed + 1)
+    out = model(b["img"], torch.empty(*b["img"].shape), b["x0bar"])
+    loss = PoseDistanceLoss(**LOSS_CFG)(out, b["obj"])
+    opt.zero_grad()
+    loss.backward()
+    rec = {"out0_s1": out.detach().numpy(), "loss_s1": np.array(loss.item())}
+    assert np.isnan(rec["loss_s1"]) and float(out[:, 3:].abs().max()) == 0.0
+    gn, gd = [], []
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        assert torch.isfinite(p.grad).all(), name
+        gn.append(name)
+        gd.append(digest(p.grad))
+        if p.numel() <= 4096:
+            rec["grad::" + name] = p.grad.detach().numpy().copy()
+    rec["grad_keys_s1"], rec["grad_digest_s1"] = np.array(gn), np.stack(gd)
+    opt.step()
+    fin = model.state_dict()
+    for k, v in fin.items():
+        if v.dtype.is_floating_point:
+            assert torch.isfinite(v).all(), k
+            if v.numel() <= 4096:
+                rec["final::" + k] = v.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "model_no_nanloss.npz"), **rec)
+    print("no_nanloss loss", rec["loss_s1"], "max |grad|", max(d[2] for d in gd))
+
+
 def run_loss():
     g = torch.Generator().manual_seed(7)
     rec = {}
@@ -438,7 +481,7 @@ def run_loss():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["loss"] + list(CASES) + ["c1", "r101", "td_s4", "hooks", "nohook", "td_cfg", "tdo_cfg", "tdo_v2_cfg"]
+    which = sys.argv[1:] or ["loss"] + list(CASES) + ["c1", "r101", "td_s4", "hooks", "nohook", "td_cfg", "tdo_cfg", "tdo_v2_cfg", "nanloss"]
     for w in which:
         if w == "loss":
             run_loss()
@@ -452,6 +495,8 @@ if __name__ == "__main__":
             run_hooks("hooks", HOOKS)
         elif w == "nohook":
             run_hooks("nohook", NOHOOK)
+        elif w == "nanloss":
+            run_nan_loss()
         elif w.endswith("_cfg"):
             run_seq_cfg(w[:-4])
         else:

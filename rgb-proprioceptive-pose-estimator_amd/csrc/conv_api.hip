@@ -37,10 +37,7 @@ static int check_desc(const rpe_conv_desc* d) {
 }
 static inline int out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
 // stride-2 data gradients with even input dims run in parity-class order (see igemm.h Gather::parity)
-static inline bool dgrad_parity(const rpe_conv_desc* d) {
-    static const bool off = getenv("RPE_NO_PARITY") != nullptr;
-    return !off && d->stride == 2 && !(d->in_h & 1) && !(d->in_w & 1);
-}
+static inline bool dgrad_parity(const rpe_conv_desc* d) { return d->stride == 2 && !(d->in_h & 1) && !(d->in_w & 1); }
 static inline bool is_dense(const rpe_conv_desc* d) { return d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0; }
 
 template <typename T>
@@ -287,8 +284,7 @@ __global__ __launch_bounds__(256) void bn_fold_fused_kernel(const T* __restrict_
 template <typename T>
 static int bn_fold_t(int Co, int Ci, const void* wf, const void* wd, const float* gamma, const float* invstd, const float* mean, const float* c1c2,
                      void* w_kcat, float* bias, void* scratch, long scratch_bytes, hipStream_t s) {
-    static const bool unfused = getenv("RPE_FOLD_PREP_UNFUSED") != nullptr;
-    if (!unfused && (Ci % 64) == 0 && (Co % (16 * Elem<T>::kChunk)) == 0 && Co <= 8192) {
+    if ((Ci % 64) == 0 && (Co % (16 * Elem<T>::kChunk)) == 0 && Co <= 8192) {
         const int gt = Ci / 64;
         hipLaunchKernelGGL((bn_fold_fused_kernel<T>), dim3(gt * gt + (Ci + 3) / 4), dim3(256), (size_t)Co * 8 + 16 * 64 * 16, s, (const T*)wd, gamma, invstd, mean, c1c2,
                            c1c2 + Co, (T*)w_kcat, bias, Co, Ci);
@@ -422,43 +418,6 @@ static int conv1x1_wgrad_folded_t(const rpe_conv_desc* d, const void* dz, const 
     return 0;
 }
 
-// Gram matrix and column sums of x [M][C] in one TN launch (P = Q = x plus the all-ones tile): out [ones_row + 1][C] fp32 with
-// x^T x in rows [0, C) and colsum(x) in row ones_row = roundup(C, 128).  ws: the launch's slab (deterministic fixed-order sum).
-static inline int gram_ones_row(int C) { return (C + 127) / 128 * 128; }
-template <typename T>
-static int gram_t(const void* x, long M, int C, float* out, void* ws, long ws_bytes, long* query, hipStream_t s) {
-    TNArgs<T> a;
-    memset(&a, 0, sizeof(a));
-    a.M = (int)M; a.I = gram_ones_row(C) + 1; a.J = C; a.ldp = C; a.ldq = C; a.ldd = C;
-    a.ones_i0 = gram_ones_row(C); a.p_cols = C;
-    if (query) return launch_tn<T>(a, MODE_DENSE, nullptr, query);
-    a.P = (const T*)x; a.Q = (const T*)x; a.D = out;
-    a.slab = (float*)ws; a.slab_bytes = ws_bytes;
-    long need = 0;
-    {
-        TNArgs<T> q = a;
-        if (int e = launch_tn<T>(q, MODE_DENSE, nullptr, &need)) return e;
-    }
-    if (!ws || ws_bytes < need) return rpe_set_error(RPE_ERR_WORKSPACE, "gram: workspace smaller than rpe_gram_workspace_bytes()");
-    return launch_tn<T>(a, MODE_DENSE, s);
-}
-
-// training forward of a 1x1 / stride-1 conv with its BatchNorm (+ residual [under its own BN]) + ReLU + packed mask fused into the
-// epilogue; scale / shift come from rpe_bn_stats_from_gram
-template <typename T>
-static int conv1x1_fwd_bn_t(const rpe_conv_desc* d, const void* x, const void* w, void* out, void* y_out, const float* scale, const float* shift,
-                            const void* residual, const float* res_scale, const float* res_shift, unsigned char* mask, hipStream_t s) {
-    NTArgs<T> a;
-    memset(&a, 0, sizeof(a));
-    a.A = (const T*)x; a.Bw = (const T*)w; a.C = (T*)out; a.y_out = (T*)y_out;
-    a.M = d->batch * d->in_h * d->in_w; a.N = d->out_c; a.K = d->in_c;
-    a.lda = d->in_c; a.ldb = d->in_c; a.ldc = d->out_c;
-    a.addend = (const T*)residual; a.ld_add = d->out_c;
-    a.fwd_scale = scale; a.fwd_shift = shift; a.res_scale = res_scale; a.res_shift = res_shift; a.mask_out = mask;
-    a.role = 5;
-    return launch_nt<T>(a, MODE_DENSE, s);
-}
-
 // data gradient of a 1x1 / stride-1 conv from A = [dz (M x Co) | a_in (M x Ci)] and the folded weight w_kcat [Ci][Co + Ci]
 template <typename T>
 static int conv1x1_dgrad_kcat_t(const rpe_conv_desc* d, const void* dz, const void* a_in, const void* w_kcat, const float* bias, void* dx,
@@ -587,8 +546,7 @@ static int linear_fwd_t(const void* x, int ldx, const void* w, int ldw, const fl
         return 0;
     }
     if constexpr (sizeof(T) == 4) {
-        static const bool rows_off = getenv("RPE_NO_LINEAR_ROWS") != nullptr;
-        if (!rows_off && x && w && y && M >= 1 && M <= kLinearRowsMax && N >= 1 && K >= 1 && ldx >= K && ldw >= K && ldy >= N)
+        if (x && w && y && M >= 1 && M <= kLinearRowsMax && N >= 1 && K >= 1 && ldx >= K && ldw >= K && ldy >= N)
             return linear_rows((const float*)x, ldx, (const float*)w, ldw, bias, (float*)y, ldy, M, N, K, relu, (const float*)addend, ld_add, s);
     }
     NTArgs<T> a;
@@ -718,33 +676,6 @@ int rpe_conv1x1_wgrad_folded(const rpe_conv_desc* d, int dtype, const void* dz, 
     return wfold_dispatch(d, dtype, dz, a_in, w_master, gamma, invstd, mean, c1c2, dw, scratch, scratch_bytes, nullptr, (hipStream_t)stream);
 }
 
-long rpe_gram_ones_row(int C) { return gram_ones_row(C); }
-
-long rpe_gram_workspace_bytes(int dtype, long M, int C) {
-    long bytes = 0;
-    int rc;
-    if (M <= 0 || C <= 0 || (C % 64)) return -1;
-    if (dtype == RPE_F32) rc = gram_t<float>(nullptr, M, C, nullptr, nullptr, 0, &bytes, nullptr);
-    else if (dtype == RPE_BF16) rc = gram_t<bf16>(nullptr, M, C, nullptr, nullptr, 0, &bytes, nullptr);
-    else if (dtype == RPE_F16) rc = gram_t<f16>(nullptr, M, C, nullptr, nullptr, 0, &bytes, nullptr);
-    else return -1;
-    return rc ? -1 : bytes;
-}
-
-int rpe_gram(int dtype, const void* x, long M, int C, float* out, void* workspace, long workspace_bytes, void* stream) {
-    if (!x || !out || M <= 0 || C <= 0 || (C % 64)) return rpe_set_error(RPE_ERR_SHAPE, "gram: x [M][C] with C % 64 == 0");
-    DISPATCH(dtype, gram_t, x, M, C, out, workspace, workspace_bytes, nullptr, (hipStream_t)stream);
-}
-
-int rpe_conv1x1_fwd_bn(const rpe_conv_desc* d, int dtype, const void* x, const void* w, void* out, void* y_out, const float* scale, const float* shift,
-                       const void* residual, const float* res_scale, const float* res_shift, unsigned char* relu_mask, void* stream) {
-    if (int e = check_desc(d)) return e;
-    if (d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_fwd_bn: 1x1 / stride 1 / no padding only");
-    if (dtype == RPE_F32) return rpe_set_error(RPE_ERR_DTYPE, "conv1x1_fwd_bn: 16-bit element types only (the fp32 path keeps the two-pass form)");
-    if (!x || !w || !out || !scale || !shift || (res_scale && (!res_shift || !residual)) || (d->out_c % 8))
-        return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_fwd_bn: bad arguments");
-    DISPATCH(dtype, conv1x1_fwd_bn_t, d, x, w, out, y_out, scale, shift, residual, res_scale, res_shift, relu_mask, (hipStream_t)stream);
-}
 
 int rpe_conv1x1_dgrad_kcat(const rpe_conv_desc* d, int dtype, const void* dz, const void* a_in, const void* w_kcat, const float* bias, void* dx,
                            const rpe_bn_bwd_epilogue* bn, void* stream) {

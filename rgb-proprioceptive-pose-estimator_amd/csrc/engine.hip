@@ -9,7 +9,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <functional>
 #include <string>
 #include <vector>
 
@@ -38,7 +37,6 @@ struct ConvL {
 
 struct Block {
     int c1, c2, c3, cd;  // conv indices (cd = -1: identity shortcut)
-    float* gram = nullptr;   // fp32 [ones_row + 1][planes]: Gram matrix + column sums of conv3's input (BN3 statistics without y3)
     void* dz = nullptr;  // backward: ReLU-masked gradient at the block output (kept as the shortcut gradient)
     unsigned char* relu_mask = nullptr;  // 16-bit element types: packed ReLU mask of the block output (1 bit per element), written by its bn_apply
 };
@@ -84,7 +82,6 @@ struct rpe_resnet50 {
     float* bwd_part = nullptr;
     long bwd_part_floats = 0;
     float* c1c2 = nullptr;
-    float* bwd_part2 = nullptr;
     double* dpart = nullptr;     // staged BN partial-sum reduction scratch
     double* dpart2 = nullptr;    // ... of the projection-shortcut branch
     // aux-head gradient in compact form for the fused stem backward (rpe_resnet50_set_aux_grad)
@@ -115,18 +112,6 @@ struct rpe_resnet50 {
     // ([1..3]) handed over by the host for the next backward; stem_raw: the inference forward keeps conv1's raw output too
     const void* hook_grad[4] = {nullptr, nullptr, nullptr, nullptr};
     bool stem_raw = false;
-    // conv3 -> bn3 -> (+identity) -> ReLU as ONE launch: BN3's batch statistics follow from the Gram matrix of conv3's input
-    // (rpe_gram + rpe_bn_stats_from_gram), so the conv applies BN + residual + ReLU + mask in its own epilogue (16-bit types)
-    bool gram = false;
-    int gram_max = 256;          // widest conv3 input (planes) handled this way
-    bool gram_keep_y = true;     // the raw conv3 output is still written (its backward reads it)
-    void* gram_ws = nullptr;     // slab of the Gram launches (main stream)
-    long gram_ws_bytes = 0;
-    // weight-gradient launches collected per bottleneck block and issued on the second stream behind ONE event (every event
-    // recorded on the caller's stream costs a ~6.5 us bubble there: the kernel behind the marker packet cannot be pipelined)
-    std::vector<std::function<int(hipStream_t)>> side_work;
-    bool defer_side = false;
-    int defer_mode = 0;
     void* fc_ws = nullptr;               // split-K workspace of the ResNet fc forward / data gradient (rpe_linear_fwd_ws)
     long fc_ws_bytes = 0;
     void* sk_ws = nullptr;               // split-K workspace of the inference forward (rpe_conv2d_fwd_affine_ws); 0 bytes when no layer splits
@@ -145,15 +130,9 @@ struct rpe_resnet50 {
     std::vector<hipEvent_t> ev_pool;
     size_t ev_next = 0;
     // weight-gradient GEMMs run on a second stream, overlapping the data-gradient / BN chain (they only feed Adam)
-    // Experiment (RPE_FWD_SPLIT=1, off by default): the training forward as two concurrent half-batch pipelines (caller's stream +
-    // `half`): every conv / BN-apply / pooling launch is issued once per half, and only the BN statistics, which need the whole
-    // batch, join them (per layer: half B's conv -> event -> finalize on the caller's stream -> event -> half B's apply).  The
-    // partial-sum rows of the two halves are adjacent, so the statistics are bitwise those of the unsplit form.  Not captured
-    // into a hipGraph (util.learn_utils.GraphedTrainStep assumes the default schedule).
-    hipStream_t half = nullptr;
-    bool split = false;
     hipStream_t side = nullptr;
     bool overlap = true;
+    bool capturing = false;              // the caller's stream is being captured into a hipGraph (capture_guard)
     std::vector<hipEvent_t> sync_pool;
     size_t sync_next = 0;
     double flops[RPE_PROF_NUM] = {0};   // algorithmic FLOPs per pass, per category
@@ -276,7 +255,7 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
         want(e, (void**)&c.mean, c.d.out_c * 4L);
         want(e, (void**)&c.invstd, c.d.out_c * 4L);
         want(e, (void**)&c.c1c2, 2L * c.d.out_c * 4);
-        const long sf = (rpe_conv_stats_tiles(c.rows) + 2) * 2 * c.d.out_c;   // (+2: the two halves of a split forward round up separately)
+        const long sf = (rpe_conv_stats_tiles(c.rows) + 2) * 2 * c.d.out_c;
         if (sf > e->stats_floats) e->stats_floats = sf;
         const long sf2 = (rpe_conv2d_dgrad_stats_tiles(&c.d) + 4) * 2 * c.d.in_c;  // fused dgrad partials (parity classes round up)
         if (sf2 > e->stats_floats) e->stats_floats = sf2;
@@ -301,7 +280,6 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
     e->bwd_part_floats = 1024L * 2 * 2048;
     want(e, (void**)&e->bwd_part, e->bwd_part_floats * 4);
     want(e, (void**)&e->c1c2, 2 * 2048 * 4L);
-    want(e, (void**)&e->bwd_part2, e->bwd_part_floats * 4);   // the projection-shortcut backward runs on the side stream
     want(e, (void**)&e->dpart, RPE_BN_DPART_DOUBLES(2048) * 8);
     want(e, (void**)&e->dpart2, RPE_BN_DPART_DOUBLES(2048) * 8);
     want(e, (void**)&e->stem_dw, 64L * 256 * 4);
@@ -328,27 +306,6 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
         want(e, &e->w_kcat, wk);
         want(e, (void**)&e->fold_bias, 512L * 4);
         want(e, &e->fold_scratch, e->fold_scratch_bytes);
-    }
-    // Experiment switch RPE_GRAM=1 (default off).  Measured at 256 images: with y3 still written (its backward reads it) 22.17 vs
-    // 21.98 ms/step -- the Gram launch + slab sum + statistics kernel sit on the forward's critical path (~28 us per block) and
-    // conv3 now reads the residual and writes two tensors; with y3 NOT written (RPE_GRAM_NO_Y=1, timing only) 21.87: -0.27 ms net,
-    // which a backward that recomputes y3 tiles in the fused data-gradient epilogue would have to add to -- not pursued.
-    // RPE_WGRAD_DEFER: 0 (default) one event per weight gradient, issued as soon as its inputs exist; 1: one event per block;
-    // 2: two per block (behind conv2's and conv1's dy)
-    e->defer_mode = getenv("RPE_WGRAD_DEFER") ? atoi(getenv("RPE_WGRAD_DEFER")) : 0;
-    e->defer_side = e->defer_mode != 0;
-    e->gram = dtype != RPE_F32 && getenv("RPE_GRAM") != nullptr;
-    if (e->gram) {
-        if (getenv("RPE_GRAM_MAX")) e->gram_max = atoi(getenv("RPE_GRAM_MAX"));
-        if (getenv("RPE_GRAM_NO_Y")) e->gram_keep_y = false;   // (timing experiment only: the backward still reads y3)
-        for (auto& b : e->blocks) {
-            const ConvL& c3 = e->convs[b.c3];
-            if (c3.d.in_c > e->gram_max) continue;
-            want(e, (void**)&b.gram, (long)(rpe_gram_ones_row(c3.d.in_c) + 1) * c3.d.in_c * 4);
-            const long wsb = rpe_gram_workspace_bytes(dtype, c3.rows, c3.d.in_c);
-            if (wsb > e->gram_ws_bytes) e->gram_ws_bytes = wsb;
-        }
-        if (e->gram_ws_bytes > 0) want(e, &e->gram_ws, e->gram_ws_bytes);
     }
     if (!getenv("RPE_WGRAD_ATOMIC")) {
         for (size_t i = 1; i < e->convs.size(); ++i) {
@@ -441,7 +398,6 @@ extern "C" void rpe_resnet50_destroy(rpe_resnet50_t* e) {
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     for (auto ev : e->sync_pool) (void)hipEventDestroy(ev);
     if (e->side) (void)hipStreamDestroy(e->side);
-    if (e->half) (void)hipStreamDestroy(e->half);
     delete e;
 }
 extern "C" long rpe_resnet50_workspace_bytes(const rpe_resnet50_t* e) { return e ? e->ws_bytes : 0; }
@@ -531,8 +487,14 @@ extern "C" int rpe_resnet50_bind(rpe_resnet50_t* e, void* workspace, long worksp
 #define TRY(x) do { if (int err__ = (x)) return err__; } while (0)
 #define HIPTRY(x) do { hipError_t he__ = (x); if (he__ != hipSuccess) return rpe_set_error_hip(he__, __FILE__, __LINE__); } while (0)
 
+// what a failed sync_event() returns to the caller: RPE_ERR_STATE (message already set) under capture, else the HIP failure
+static int event_error(const rpe_resnet50* e) {
+    return e->capturing ? RPE_ERR_STATE : rpe_set_error(RPE_ERR_HIP, "trunk engine: hipEventCreate failed");
+}
+
 static hipEvent_t sync_event(rpe_resnet50* e) {
     if (e->sync_next == e->sync_pool.size()) {
+        if (e->capturing) { rpe_set_error(RPE_ERR_STATE, "trunk engine: the cross-stream event pool would grow inside a stream capture (warm up eagerly with the same schedule first)"); return nullptr; }
         hipEvent_t ev;
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
         e->sync_pool.push_back(ev);
@@ -588,63 +550,11 @@ static int ensure_side(rpe_resnet50* e) {
         if (getenv("RPE_NO_OVERLAP")) e->overlap = false;
         else {
             // weight gradients are off the critical path (the data-gradient chain is): the second stream gets the LOWEST dispatch
-            // priority (measured on one box, three alternations: 20.86 vs 20.98 ms/step at equal priority, 21.41 at high);
-            // RPE_SIDE_PRIO=normal|high for the other settings
+            // priority (measured on one box, three alternations: 20.86 vs 20.98 ms/step at equal priority, 21.41 at high)
             int least = 0, greatest = 0;
             HIPTRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            const char* pr = getenv("RPE_SIDE_PRIO");
-            // experiment switch RPE_SIDE_CUS=n: the second stream may only use n of the 256 CUs (the first n mask bits: the driver
-            // deals them round-robin over XCDs and shader engines), leaving the rest to the data-gradient chain alone
-            const int side_cus = getenv("RPE_SIDE_CUS") ? atoi(getenv("RPE_SIDE_CUS")) : 0;
-            if (side_cus > 0 && side_cus < 256) {
-                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int i = 0; i < side_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
-                HIPTRY(hipExtStreamCreateWithCUMask(&e->side, 8, mask));
-            } else
-            if (pr && pr[0] == 'n') HIPTRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-            else if (pr && pr[0] == 'h') HIPTRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, greatest));
-            else HIPTRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, least));
+            HIPTRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, least));
         }
-    }
-    return 0;
-}
-
-// conv -> batch statistics -> BN apply of one layer with the batch split in two halves over (stream, e->half); see rpe_resnet50::half
-static int conv_bn_split(rpe_resnet50* e, ConvL& c, const void* x, const void* residual, int relu, void* stream, unsigned char* relu_mask) {
-    const int Bh = e->B / 2;
-    const long Mh = c.rows / 2;
-    const bool stem = &c == &e->convs[0];
-    const long xoff = stem ? (long)Bh * e->H * e->W * 4 * (long)e->esz : (long)Bh * c.d.in_h * c.d.in_w * c.d.in_c * (long)e->esz;
-    const long yoff = Mh * c.d.out_c * (long)e->esz;
-    const long tiles_h = rpe_conv_stats_tiles(Mh);
-    rpe_conv_desc dh = c.d;
-    dh.batch = Bh;
-    hipStream_t ss[2] = {(hipStream_t)stream, e->half};
-    for (int h = 0; h < 2; ++h) {
-        const char* xh = (const char*)x + h * xoff;
-        char* yh = (char*)c.y + h * yoff;
-        float* sth = e->stats_part + h * tiles_h * 2 * c.d.out_c;
-        e->pending_flops = conv_flops(c) * 0.5;
-        e->pending_bytes = (conv_in_bytes(e, c) + conv_out_bytes(e, c)) * 0.5;
-        if (stem) PROF(e, RPE_PROF_CONV_FWD, ss[h], rpe_stem_conv_fwd(e->dtype, xh, c.wf, yh, sth, Bh, e->H, e->W, ss[h]));
-        else PROF(e, RPE_PROF_CONV_FWD, ss[h], rpe_conv2d_fwd(&dh, e->dtype, xh, fwd_weight(e, c), yh, sth, ss[h]));
-    }
-    hipEvent_t b_done = sync_event(e), fin_done = sync_event(e);
-    if (!b_done || !fin_done) return rpe_set_error(RPE_ERR_HIP, "resnet50_forward: hipEventCreate failed");
-    HIPTRY(hipEventRecord(b_done, e->half));
-    HIPTRY(hipStreamWaitEvent((hipStream_t)stream, b_done, 0));
-    e->pending_bytes = 0;
-    PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_finalize(e->stats_part, (int)(2 * tiles_h), c.d.out_c, c.rows, e->params[c.p_g], e->params[c.p_b], e->running[2 * c.bn_i],
-                        e->running[2 * c.bn_i + 1], e->nbt[c.bn_i], 0.1f, 1e-5f, c.scale, c.shift, c.mean, c.invstd, e->dpart, stream));
-    HIPTRY(hipEventRecord(fin_done, (hipStream_t)stream));
-    HIPTRY(hipStreamWaitEvent(e->half, fin_done, 0));
-    for (int h = 0; h < 2; ++h) {
-        const char* yh = (const char*)c.y + h * yoff;
-        const char* rh = residual ? (const char*)residual + h * yoff : nullptr;
-        char* ah = (char*)c.a + h * yoff;
-        e->pending_bytes = conv_out_bytes(e, c) * 0.5 * (2.0 + (residual ? 1.0 : 0.0) + ((relu_mask && relu) ? 1.0 / 16 : 0.0));
-        if (relu_mask && relu) PROF(e, RPE_PROF_BN_FWD, ss[h], rpe_bn_apply_mask(e->dtype, yh, rh, ah, c.scale, c.shift, Mh, c.d.out_c, relu_mask + h * (Mh * c.d.out_c / 8), ss[h]));
-        else PROF(e, RPE_PROF_BN_FWD, ss[h], rpe_bn_apply(e->dtype, yh, rh, ah, c.scale, c.shift, Mh, c.d.out_c, relu, ss[h]));
     }
     return 0;
 }
@@ -653,7 +563,6 @@ static int conv_bn_split(rpe_resnet50* e, ConvL& c, const void* x, const void* r
 // apply pass (rpe_bn_apply_res_bn); stats_only: stop after the statistics (the shortcut itself then has no apply pass).
 static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residual, int relu, void* stream, bool second_set = false,
                    unsigned char* relu_mask = nullptr, const ConvL* res_bn = nullptr, bool stats_only = false) {
-    if (e->split && e->train_mode && !second_set && e->half) return conv_bn_split(e, c, x, residual, relu, stream, relu_mask);
     const bool train = e->train_mode != 0;
     float* stats = second_set ? e->stats_part2 : e->stats_part;
     double* dpart = second_set ? e->dpart2 : e->dpart;
@@ -690,6 +599,26 @@ static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residua
     return 0;
 }
 
+// A stream capture (util.learn_utils.GraphedTrainStep / GraphedRolloutFrame, bench.py --graph) may only replay what exists before it
+// starts: the second stream and every cross-stream event must have been created by an eager pass over the same schedule (the
+// Graphed* classes warm up eagerly first).  Creating a stream or growing the event pool inside a capture is refused with
+// RPE_ERR_STATE instead of being attempted: round 2 lost a whole test process to a segmentation fault inside hipStreamEndCapture
+// (gpurun_out/t12.log) while the since-removed split-forward schedule forked a lazily created third stream and recycled its
+// join events (sync_next = 0 in the forward AND in the backward of one capture) under capture.
+static int capture_guard(rpe_resnet50* e, void* stream, const char* who) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    e->capturing = st != hipStreamCaptureStatusNone;
+    if (!e->capturing) return 0;
+    if (e->profiling) return rpe_set_error(RPE_ERR_STATE, "trunk engine: per-launch profiling events cannot be recorded inside a stream capture");
+    if (e->overlap && !e->side && !getenv("RPE_NO_OVERLAP")) {
+        char msg[160];
+        snprintf(msg, sizeof(msg), "%s: called under stream capture before any eager pass created the second stream -- run the step eagerly once, then capture", who);
+        return rpe_set_error(RPE_ERR_STATE, msg);
+    }
+    return 0;
+}
+
 static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned char* frames, int Hs, int Ws, const float* mean3, const float* std3,
                         float* features, long ld_features, int training, void* stream, const rpe_resize_plan* rs = nullptr) {
     if (!e || !e->bound) return rpe_set_error(RPE_ERR_STATE, "resnet50_forward: engine not bound");
@@ -702,39 +631,18 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
     else if (frames) PROF(e, RPE_PROF_OTHER, stream, rpe_stage_frames_u8(e->dtype, frames, e->x4, e->B, Hs, Ws, e->H, e->W, mean3, std3, stream));
     else PROF(e, RPE_PROF_OTHER, stream, rpe_stage_image_nhwc4(e->dtype, img_nchw, e->x4, e->B, e->H, e->W, stream));
     ConvL& st = e->convs[0];
+    TRY(capture_guard(e, stream, "resnet50_forward"));
     TRY(ensure_side(e));
     e->sync_next = 0;
-    // experiment switch RPE_FWD_SPLIT=1 (default off): measured 22.6 vs 21.9 ms/step at 256 images -- the per-layer joins at the BN
-    // statistics and the halved launches cost more than the overlap of two latency-bound launches returns
-    static const bool split_ok = getenv("RPE_FWD_SPLIT") != nullptr;
-    e->split = split_ok && training && e->overlap && (e->B % 2) == 0;
-    if (e->split) {
-        if (!e->half) HIPTRY(hipStreamCreateWithFlags(&e->half, hipStreamNonBlocking));
-        hipEvent_t staged = sync_event(e);
-        if (!staged) return rpe_set_error(RPE_ERR_HIP, "resnet50_forward: hipEventCreate failed");
-        HIPTRY(hipEventRecord(staged, (hipStream_t)stream));   // weights packed, image staged
-        HIPTRY(hipStreamWaitEvent(e->half, staged, 0));
-    }
     TRY(conv_bn(e, st, e->x4, nullptr, 1, stream));
-    if (e->split) {
-        const int Bh = e->B / 2;
-        const long aoff = (long)Bh * st.Ho * st.Wo * 64 * (long)e->esz, poff = (long)Bh * (st.Ho / 2) * (st.Wo / 2) * 64;
-        hipStream_t ss[2] = {(hipStream_t)stream, e->half};
-        for (int h = 0; h < 2; ++h) {
-            e->pending_bytes = (conv_out_bytes(e, st) * 1.25 + (double)e->B * (st.Ho / 2) * (st.Wo / 2) * 64) * 0.5;
-            PROF(e, RPE_PROF_OTHER, ss[h], rpe_maxpool3x3s2_fwd(e->dtype, (const char*)st.a + h * aoff, (char*)e->pool + h * poff * (long)e->esz, e->pool_idx + h * poff,
-                                                                Bh, st.Ho, st.Wo, 64, ss[h]));
-        }
-    } else {
-        e->pending_bytes = conv_out_bytes(e, st) * 1.25 + (double)e->B * (st.Ho / 2) * (st.Wo / 2) * 64;   // a1 -> pool + winner index
-        PROF(e, RPE_PROF_OTHER, stream, rpe_maxpool3x3s2_fwd(e->dtype, st.a, e->pool, e->pool_idx, e->B, st.Ho, st.Wo, 64, stream));
-    }
+    e->pending_bytes = conv_out_bytes(e, st) * 1.25 + (double)e->B * (st.Ho / 2) * (st.Wo / 2) * 64;   // a1 -> pool + winner index
+    PROF(e, RPE_PROF_OTHER, stream, rpe_maxpool3x3s2_fwd(e->dtype, st.a, e->pool, e->pool_idx, e->B, st.Ho, st.Wo, 64, stream));
     const void* x = e->pool;
     static const bool fwd_overlap = getenv("RPE_NO_FWD_OVERLAP") == nullptr;
     // training: the projection shortcut's BatchNorm is applied inside conv3's apply pass (no pass / normalised copy of its own);
     // RPE_NO_DS_FUSE=1: the separate pass
     static const bool ds_fuse_ok = getenv("RPE_NO_DS_FUSE") == nullptr;
-    const bool fuse_ds = ds_fuse_ok && training && !e->split;
+    const bool fuse_ds = ds_fuse_ok && training;
     for (auto& b : e->blocks) {
         ConvL &c1 = e->convs[b.c1], &c2 = e->convs[b.c2], &c3 = e->convs[b.c3];
         const void* idn = x;
@@ -744,15 +652,9 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
             ConvL& cd = e->convs[b.cd];
             hipEvent_t x_ready = sync_event(e);
             ds_done = sync_event(e);
-            if (!x_ready || !ds_done) return rpe_set_error(RPE_ERR_HIP, "resnet50_forward: hipEventCreate failed");
+            if (!x_ready || !ds_done) return event_error(e);
             HIPTRY(hipEventRecord(x_ready, (hipStream_t)stream));
             HIPTRY(hipStreamWaitEvent(e->side, x_ready, 0));
-            if (e->split) {   // the other half of x comes from the second data stream
-                hipEvent_t xb_ready = sync_event(e);
-                if (!xb_ready) return rpe_set_error(RPE_ERR_HIP, "resnet50_forward: hipEventCreate failed");
-                HIPTRY(hipEventRecord(xb_ready, e->half));
-                HIPTRY(hipStreamWaitEvent(e->side, xb_ready, 0));
-            }
             TRY(conv_bn(e, cd, x, nullptr, 0, e->side, true, nullptr, nullptr, fuse_ds));
             HIPTRY(hipEventRecord(ds_done, e->side));
             idn = cd.a;
@@ -760,35 +662,12 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
         TRY(conv_bn(e, c1, x, nullptr, 1, stream));
         TRY(conv_bn(e, c2, c1.a, nullptr, 1, stream));
         if (b.cd >= 0 && !ds_done) { ConvL& cd = e->convs[b.cd]; TRY(conv_bn(e, cd, x, nullptr, 0, stream, false, nullptr, nullptr, fuse_ds)); idn = cd.a; }
-        if (ds_done) {
-            HIPTRY(hipStreamWaitEvent((hipStream_t)stream, ds_done, 0));
-            if (e->split) HIPTRY(hipStreamWaitEvent(e->half, ds_done, 0));
-        }
+        if (ds_done) HIPTRY(hipStreamWaitEvent((hipStream_t)stream, ds_done, 0));
         static const bool use_mask = getenv("RPE_NO_RELU_MASK") == nullptr;
-        if (e->gram && training && !e->split && b.gram && use_mask && b.relu_mask && (b.cd < 0 || fuse_ds)) {
-            const ConvL* cdp = b.cd >= 0 ? &e->convs[b.cd] : nullptr;
-            e->pending_flops = 2.0 * (double)c3.rows * c3.d.in_c * c3.d.in_c;
-            e->pending_bytes = conv_in_bytes(e, c3);
-            PROF(e, RPE_PROF_BN_FWD, stream, rpe_gram(e->dtype, c2.a, c3.rows, c3.d.in_c, b.gram, e->gram_ws, e->gram_ws_bytes, stream));
-            e->pending_bytes = 0;
-            PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_stats_from_gram(e->dtype, c3.wf, c3.d.out_c, c3.d.in_c, b.gram, rpe_gram_ones_row(c3.d.in_c), c3.rows,
-                                                                    e->params[c3.p_g], e->params[c3.p_b], e->running[2 * c3.bn_i], e->running[2 * c3.bn_i + 1],
-                                                                    e->nbt[c3.bn_i], 0.1f, 1e-5f, c3.scale, c3.shift, c3.mean, c3.invstd, stream));
-            e->pending_flops = conv_flops(c3);
-            e->pending_bytes = conv_in_bytes(e, c3) + conv_out_bytes(e, c3) * (2.0 + (e->gram_keep_y ? 1.0 : 0.0) + 1.0 / 16);   // x, residual -> out (+ y) + mask
-            PROF(e, RPE_PROF_CONV_FWD, stream, rpe_conv1x1_fwd_bn(&c3.d, e->dtype, c2.a, c3.wf, c3.a, e->gram_keep_y ? c3.y : nullptr, c3.scale, c3.shift,
-                                                                 cdp ? cdp->y : idn, cdp ? cdp->scale : nullptr, cdp ? cdp->shift : nullptr, b.relu_mask, stream));
-        } else
         if (b.cd >= 0 && fuse_ds) TRY(conv_bn(e, c3, c2.a, e->convs[b.cd].y, 1, stream, false, use_mask ? b.relu_mask : nullptr, &e->convs[b.cd]));
         else
         TRY(conv_bn(e, c3, c2.a, idn, 1, stream, false, use_mask ? b.relu_mask : nullptr));   // (relu_mask is null for fp32 engines)
         x = c3.a;
-    }
-    if (e->split) {   // the second half of the last block's output
-        hipEvent_t b_done = sync_event(e);
-        if (!b_done) return rpe_set_error(RPE_ERR_HIP, "resnet50_forward: hipEventCreate failed");
-        HIPTRY(hipEventRecord(b_done, e->half));
-        HIPTRY(hipStreamWaitEvent((hipStream_t)stream, b_done, 0));
     }
     ConvL& last = e->convs[e->blocks.back().c3];
     TRY(rpe_avgpool_fwd(e->dtype, last.a, e->pooled, e->B, last.Ho * last.Wo, 2048, stream));
@@ -868,28 +747,10 @@ static int wgrad_on(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, hi
     return 0;
 }
 
-// everything collected in side_work runs on the second stream behind one event on the caller's stream
-static int flush_side(rpe_resnet50* e, void* stream) {
-    if (e->side_work.empty()) return 0;
-    hipEvent_t ready = sync_event(e);
-    if (!ready) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
-    HIPTRY(hipEventRecord(ready, (hipStream_t)stream));
-    HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
-    for (auto& f : e->side_work)
-        if (int err = f(e->side)) { e->side_work.clear(); return err; }
-    e->side_work.clear();
-    return 0;
-}
-
 static int wgrad(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, void* stream) {
     if (e->overlap && e->side) {
-        if (e->defer_side) {   // (x and dy live in per-layer buffers that nothing rewrites within the step)
-            ConvL* cp = &c;
-            e->side_work.push_back([e, cp, x, dy](hipStream_t run) { return wgrad_on(e, *cp, x, dy, run); });
-            return 0;
-        }
         hipEvent_t ready = sync_event(e);
-        if (!ready) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
+        if (!ready) return event_error(e);
         HIPTRY(hipEventRecord(ready, (hipStream_t)stream));
         HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
         return wgrad_on(e, c, x, dy, e->side);
@@ -929,14 +790,11 @@ static int conv1x1_backward_folded(rpe_resnet50* e, ConvL& c, const void* dz, Co
     return 0;
     };
     if (e->overlap && e->side) {
-        if (e->defer_side) e->side_work.push_back(side_part);
-        else {
-            hipEvent_t ready = sync_event(e);
-            if (!ready) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
-            HIPTRY(hipEventRecord(ready, (hipStream_t)stream));
-            HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
-            TRY(side_part(e->side));
-        }
+        hipEvent_t ready = sync_event(e);
+        if (!ready) return event_error(e);
+        HIPTRY(hipEventRecord(ready, (hipStream_t)stream));
+        HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
+        TRY(side_part(e->side));
     } else {
         TRY(side_part((hipStream_t)stream));
     }
@@ -957,9 +815,8 @@ static int conv1x1_backward_folded(rpe_resnet50* e, ConvL& c, const void* dz, Co
 static int join_side(rpe_resnet50* e, hipStream_t s) {
     // everything the side stream produced so far (weight gradients) is complete before the caller's next launch on s
     if (e->overlap && e->side) {
-        TRY(flush_side(e, s));
         hipEvent_t done = sync_event(e);
-        if (!done) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
+        if (!done) return event_error(e);
         HIPTRY(hipEventRecord(done, e->side));
         HIPTRY(hipStreamWaitEvent(s, done, 0));
     }
@@ -973,6 +830,7 @@ extern "C" int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_fea
     for (int i = 0; i < np; ++i)
         if (!e->grads[i]) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward: gradient tensors were not bound");
     hipStream_t s = (hipStream_t)stream;
+    TRY(capture_guard(e, stream, "resnet50_backward"));
     TRY(ensure_side(e));
     e->sync_next = 0;
     if (e->gspan_lo) HIPTRY(hipMemsetAsync(e->gspan_lo, 0, e->gspan_bytes, s));
@@ -1017,11 +875,6 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
         const void* x_in = bi == 0 ? (const void*)e->pool : (const void*)e->convs[e->blocks[bi - 1].c3].a;
         void* gA = b.dz;                                             // dz3 (for the last block: the raw dA)
         void* gD = bi == 0 ? e->d_pool : e->blocks[bi - 1].dz;       // where the gradient of the block input goes
-        // Projection shortcut (conv + BN, no ReLU) of a stage-entry block: its whole backward -- BN reduce / finalize / apply, weight
-        // gradient, data gradient into G[0] -- needs only gA, so it CAN run on the side stream beside the conv3 -> conv2 -> conv1
-        // chain, joined in front of the block's last data gradient, which adds G[0] (own partial-sum / counter buffers).
-        // Experiment switch RPE_CD_SIDE=1: measured level with the one-stream form (22.0 vs 21.7 ms/step) -- the two streams
-        // share one HBM, moving bytes between them does not shorten the step.
         // a hooked layer output (the input of a stage-entry block) carries one more gradient term: it joins the shortcut gradient
         const void* hook_in = nullptr;
         if (b.cd >= 0 && bi > 0) {
@@ -1030,32 +883,6 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
             if (layer >= 2 && layer <= 4) hook_in = e->hook_grad[layer - 1];
         }
         static const bool ds_fold_ok = getenv("RPE_NO_DS_FOLD") == nullptr;
-        static const bool cd_side_ok = getenv("RPE_CD_SIDE") != nullptr;
-        const bool cd_on_side = b.cd >= 0 && cd_side_ok && e->overlap && e->side && bi != (int)e->blocks.size() - 1;
-        hipEvent_t cd_done = nullptr;
-        if (cd_on_side) {
-            ConvL& cd = e->convs[b.cd];
-            hipEvent_t ga_ready = sync_event(e);
-            cd_done = sync_event(e);
-            if (!ga_ready || !cd_done) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
-            HIPTRY(hipEventRecord(ga_ready, (hipStream_t)stream));
-            HIPTRY(hipStreamWaitEvent(e->side, ga_ready, 0));
-            e->pending_bytes = conv_out_bytes(e, cd) * 5.0;
-            PROF(e, RPE_PROF_BN_BWD, e->side, rpe_bn_backward(e->dtype, gA, nullptr, cd.y, cd.mean, cd.invstd, e->params[cd.p_g], e->grads[cd.p_g], e->grads[cd.p_b],
-                                                               cd.dy, nullptr, cd.rows, cd.d.out_c, e->bwd_part2, e->bwd_part_floats, cd.c1c2, e->dpart2, e->side));
-            float* dw = e->grads[cd.p_w];
-            e->pending_flops = conv_flops(cd);
-            e->pending_bytes = conv_in_bytes(e, cd) + conv_out_bytes(e, cd);
-            if (e->wg_slab) {
-                PROF(e, RPE_PROF_CONV_WGRAD, e->side, rpe_conv2d_wgrad_det(&cd.d, e->dtype, x_in, cd.dy, dw, e->wg_slab, e->wg_slab_bytes, e->side));
-            } else {
-                if (!e->gspan_lo) HIPTRY(hipMemsetAsync(dw, 0, (size_t)e->pnumel[cd.p_w] * 4, e->side));
-                PROF(e, RPE_PROF_CONV_WGRAD, e->side, rpe_conv2d_wgrad(&cd.d, e->dtype, x_in, cd.dy, dw, e->side));
-            }
-            e->pending_flops = conv_flops(cd);
-            e->pending_bytes = conv_in_bytes(e, cd) + conv_out_bytes(e, cd);
-            PROF(e, RPE_PROF_CONV_DGRAD, e->side, rpe_conv2d_dgrad(&cd.d, e->dtype, cd.dy, cd.wd, e->G[0], hook_in, e->side));
-        }
         if (e->fold && c3.d.in_c <= 256 && e->train_mode) {   // layers 1-3 (layer4's tensors are small: the unfolded form is faster there)
             TRY(conv1x1_backward_folded(e, c3, gA, c2, stream));                                  // dz2 (dy3 exists on the side stream only)
         } else {
@@ -1066,7 +893,6 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
         }
         TRY(bn_from_dz(e, c2, c2.dy, c2.dy, stream));
         TRY(wgrad(e, c2, c1.a, c2.dy, stream));
-        if (e->defer_mode == 2 && e->overlap && e->side) TRY(flush_side(e, stream));
         TRY(dgrad_fused(e, c2, c2.dy, c1.dy, nullptr, &c1, 2, stream));   // dz1
         TRY(bn_from_dz(e, c1, c1.dy, c1.dy, stream));
         TRY(wgrad(e, c1, x_in, c1.dy, stream));
@@ -1074,10 +900,7 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
         if (b.cd >= 0) {
             ConvL& cd = e->convs[b.cd];
             shortcut = e->G[0];
-            if (cd_on_side) {
-                HIPTRY(hipEventRecord(cd_done, e->side));
-                HIPTRY(hipStreamWaitEvent((hipStream_t)stream, cd_done, 0));   // the shortcut gradient is what the block's last data gradient adds
-            } else if (ds_fold_ok && e->fold && e->train_mode && e->fold_w && e->wfold_scratch && !hook_in && cd.d.kh == 1 && cd.d.stride == 1 &&
+            if (ds_fold_ok && e->fold && e->train_mode && e->fold_w && e->wfold_scratch && !hook_in && cd.d.kh == 1 && cd.d.stride == 1 &&
                        cd.d.pad == 0 && cd.d.in_c <= e->fold_w_max && (cd.d.out_c % 128) == 0 && (cd.d.in_c % 64) == 0) {
                 // stride-1 projection shortcut (layer1): its BatchNorm backward folds into the 1x1 conv like conv3's -- one reduction pass
                 // (dz = gA, no mask), then the K-concatenated data gradient and the folded weight gradient; no dy, no apply pass
@@ -1095,14 +918,11 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
                         return 0;
                     };
                     if (e->overlap && e->side) {
-                        if (e->defer_side) e->side_work.push_back(side_part);
-                        else {
-                            hipEvent_t ready = sync_event(e);
-                            if (!ready) return rpe_set_error(RPE_ERR_HIP, "resnet50_backward: hipEventCreate failed");
-                            HIPTRY(hipEventRecord(ready, (hipStream_t)stream));
-                            HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
-                            TRY(side_part(e->side));
-                        }
+                        hipEvent_t ready = sync_event(e);
+                        if (!ready) return event_error(e);
+                        HIPTRY(hipEventRecord(ready, (hipStream_t)stream));
+                        HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
+                        TRY(side_part(e->side));
                     } else {
                         TRY(side_part((hipStream_t)stream));
                     }
@@ -1126,7 +946,6 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
         } else {
             PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&c1.d, e->dtype, c1.dy, c1.wd, gD, shortcut, stream));
         }
-        if (e->overlap && e->side) TRY(flush_side(e, stream));   // this block's weight gradients: one event, then onto the second stream
     }
     e->bwd_next = bi;
     if (join) TRY(join_side(e, (hipStream_t)stream));

@@ -600,11 +600,12 @@ template <> __device__ inline void store4<f16>(f16* o, float a, float b, float c
 // Layers whose Co and Ci are multiples of 64 (every trunk conv) go 64x64 tile by tile through LDS, so both the source read
 // and the two destination writes (forward layout = source order; data-gradient layout = [Ci][RS][Co], a transpose) move
 // whole 128/256-byte rows; other layers fall back to element-wise scatter.
+constexpr int kPackMaxLayers = 255;
 template <typename T>
 __global__ __launch_bounds__(256) void pack_conv_weights_multi_kernel(const rpe_pack_desc* __restrict__ tab, int nlayers, long total) {
-    __shared__ long starts[128];
+    __shared__ long starts[kPackMaxLayers + 1];   // (ResNet-152 has 154 packed convs)
     __shared__ float tile[64][65];
-    for (int i = threadIdx.x; i <= nlayers && i < 128; i += blockDim.x) starts[i] = i < nlayers ? tab[i].start : total;
+    for (int i = threadIdx.x; i <= nlayers && i <= kPackMaxLayers; i += blockDim.x) starts[i] = i < nlayers ? tab[i].start : total;
     __syncthreads();
     const long chunk = 4096;   // one 64x64 tile; layer starts are multiples of it whenever Co, Ci are multiples of 64
     const int tr = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 4;
@@ -932,7 +933,7 @@ int rpe_pack_conv_weight(int dtype, const float* w_krsc, void* w_fwd, void* w_dg
 
 int rpe_pack_conv_weights_multi(int dtype, const rpe_pack_desc* table_dev, int nlayers, long total, void* stream) {
     note_kernel("pack_conv_weights_multi_kernel");
-    if (nlayers <= 0 || nlayers > 127 || total <= 0) return rpe_set_error(RPE_ERR_SHAPE, "pack_conv_weights_multi: bad table");
+    if (nlayers <= 0 || nlayers > kPackMaxLayers || total <= 0) return rpe_set_error(RPE_ERR_SHAPE, "pack_conv_weights_multi: bad table (1..255 layers)");
     const int grid = (int)((total + 4095) / 4096 < 8192 ? (total + 4095) / 4096 : 8192);
     if (dtype == RPE_F32) hipLaunchKernelGGL((pack_conv_weights_multi_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, table_dev, nlayers, total);
     else if (dtype == RPE_BF16) hipLaunchKernelGGL((pack_conv_weights_multi_kernel<bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, table_dev, nlayers, total);

@@ -79,17 +79,10 @@ template <typename T> struct NTArgs {
     const T* bn_a;       // BN(+residual)+ReLU output, [M][ldc] (mode 1)
     const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
     int tiles_m, tiles_n;
-    int nt_store;        // epilogue output stores non-temporal (streamed once, re-read only after >= its own size of other traffic)
     int role;            // 0 conv forward (training), 1 conv data gradient, 2 Linear, 3 conv forward (inference: bias/addend/ReLU):
                          // selects the epilogue variant compiled into the kernel and tags its symbol in profiles
     long a_elems;        // elements of the tensor behind A (conv modes: set by the caller; dense: M * lda, filled by the launcher)
     unsigned b_bytes;    // buffer-descriptor extent of Bw (filled by the launcher, < 2 GiB)
-    // role 5: training forward of a conv whose BatchNorm statistics are known BEFORE the launch (1x1 convs: from the Gram matrix of
-    // the input, rpe_bn_stats_from_gram): C = relu(acc * fwd_scale + fwd_shift + addend [* res_scale + res_shift]) with the packed
-    // ReLU mask (mask_out, 16-bit element types) -- the raw output is written only when y_out is set
-    const float *fwd_scale, *fwd_shift, *res_scale, *res_shift;
-    unsigned char* mask_out;
-    T* y_out;
     // Split-K form of the inference forward (few output tiles, long K: one rollout frame).  role 3 with `slab` set and
     // splits > 1 runs as role 4: grid.y = splits, workgroup (tile, z) walks K steps [z * split_steps, (z+1) * split_steps)
     // and stores its raw fp32 accumulators (fragment order) into slab[z][tile]; nt_split_epilogue_kernel then adds the

@@ -40,10 +40,6 @@ template <typename T> int launch_nt(NTArgs<T>& a, int mode, hipStream_t s) {
             (a.bn_mode && ((((uintptr_t)a.bn_y) & 15) || (a.bn_a && (((uintptr_t)a.bn_a) & 15)))))
             return rpe_set_error(RPE_ERR_ALIGN, "igemm_nt: conv outputs need N % 8 == 0 and 16-byte aligned rows");
     }
-    {   // experiment switch: RPE_NT_NTSTORE=1 streams every conv output past L2 (2: only outputs of 256 MB and more)
-        static const int nts = getenv("RPE_NT_NTSTORE") ? atoi(getenv("RPE_NT_NTSTORE")) : 0;
-        if (a.role != 2 && nts) a.nt_store = nts == 1 || (long)a.M * a.ldc * (long)sizeof(T) >= (256L << 20);
-    }
     if (mode == MODE_STEM) return launch_nt_mode<T, MODE_STEM>(a, s);
     if (mode == MODE_DENSE) return launch_nt_mode<T, MODE_DENSE>(a, s);
     return launch_nt_mode<T, MODE_CONV>(a, s);

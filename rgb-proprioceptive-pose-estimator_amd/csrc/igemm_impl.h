@@ -3,7 +3,8 @@
 //
 //   nt_kernel : C[M][N] = gather(A)[M][K] * W[N][K]^T  (+bias, +addend, relu, BN partial stats, fused BN backward)
 //               conv forward, conv data-gradient, Linear forward / data-gradient.
-//   tn_kernel : D[I][J] += sum_m P[m][I] * gather(Q)[m][J]   (fp32 atomics)
+//   tn_kernel : D[I][J] = sum_m P[m][I] * gather(Q)[m][J]   (per-workgroup fp32 slabs summed in a fixed order by tn_reduce_kernel;
+//               fp32 atomics only when the caller provides no slab workspace)
 //               conv weight-gradient, Linear weight-gradient.
 //
 // Layout: activations NHWC (channels contiguous), weights [N][K] with K = (r, s, c) contiguous.
@@ -18,9 +19,7 @@
 #pragma once
 #include "igemm.h"
 
-#ifndef RPE_EPI_DEPTH
-#define RPE_EPI_DEPTH 4   // epilogue operand prefetch distance of the fused data gradients, in steps (see nt_kernel, PIPE)
-#endif
+constexpr int kEpiDepth = 4;   // epilogue operand prefetch distance of the fused data gradients, in steps (see nt_kernel, PIPE); 8 measured level
 
 namespace rpe {
 
@@ -78,23 +77,21 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 //   <2, 128|64, 4, ., 3>: 128-row tile, 64-B K rows, 3-slot ring  (K < 1024, stem)
 //   <2, 128|64, 8, ., 2>: 128-row tile, 128-B K rows, 2-slot ring (K >= 1024: half the barriers per FLOP)
 //   <1, 64, 4, ., 3>    : 64x64 tile, 2 waves                     (few-row Linear layers)
-//   <4, 128|64, 8, ., 3>: 256-row tile, 8 waves                   (experiment, RPE_NT_BIG)
 // -----------------------------------------------------------------------------------------------
 // ROLE selects the epilogue compiled into the kernel (see the epilogue): 0 conv forward in training, 1 conv data gradient,
-// 2 Linear, 3 conv forward in inference.
+// 2 Linear, 3 conv forward in inference, 4 split-K partial tile.
 // BNM: the data gradient's fused BN-backward mode (NTArgs::bn_mode), a template parameter so that each launch carries one
 // epilogue variant only (role 1; 0 elsewhere).
 // (second launch-bound = minimum waves per SIMD: with the mode a constant hipcc hoisted the epilogue loads of mode 2 into 252
 // VGPRs -- one workgroup per CU, 25 % slower)
-// WAVES_N: waves along N (2: 64 x BN/2 per wave; 4: 64 x BN/4 -- twice the waves on the same tile and LDS footprint, for the
-// HBM-bound short-K launches whose workgroups spend most of their life in the load latency and the epilogue: more waves per CU
-// in flight, half the epilogue per wave).
-template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE, int BNM = 0, int WAVES_N = 2>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_N == 4 && BN < 256) ? 4 : 2) void nt_kernel(const NTArgs<T> p) {
+// Measured and rejected in rounds 1-2, code removed in round 3: 256-row / 8-wave tiles, 8 waves on the 128 x 128
+// tile, 128 x 256 / 8-wave tiles, non-temporal epilogue stores, 4- and 5-slot rings.
+template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE, int BNM = 0>
+__global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p) {
+    constexpr int WAVES_N = 2;   // waves along N: 64 x BN/2 per wave
     constexpr int CE = Elem<T>::kChunk, BK = KCH * CE;
     constexpr int NW = WAVES_N * WAVES_M, NTHR = 64 * NW;
     constexpr int BM = 64 * WAVES_M, WM = 64, WN = BN / WAVES_N, FM = WM / 16, FN = WN / 16;
-    static_assert(WAVES_N == 2 || WAVES_N == 4, "2 or 4 waves along N");
     static_assert(WN % 16 == 0 && WN >= 16, "a wave needs at least one 16-column fragment");
     constexpr int RPI = 64 / KCH;                       // rows covered by one 64-lane x 16-B DMA instruction
     constexpr int AR = BM / RPI / NW, BR = BN / RPI / NW;  // DMA instructions (= 16-B chunks per thread) per K-step
@@ -104,7 +101,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_N == 4 && BN < 256) 
     constexpr bool DMA = MODE != MODE_STEM;
     constexpr int NSTAGE = DMA ? NST : 2;              // DMA path: ring of NST slots, NST-1 tiles in flight
     static_assert(DMA || (WAVES_M == 2 && KCH == 4), "register staging is only wired for the 128-row / 64-B-row config");
-    static_assert(NST >= 2 && NST <= 5, "ring depth 2..5");
+    static_assert(NST >= 2 && NST <= 3, "ring depth 2..3");
     __shared__ u32x4 lds[(NSTAGE * STAGE > EPI16) ? NSTAGE * STAGE : EPI16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -341,14 +338,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_N == 4 && BN < 256) 
     const T* const e_addend = HAS_ADDEND ? p.addend : nullptr;
     const bool vec_add = VEC_ONLY ? (ncol_ok && e_addend != nullptr) : nfull && e_addend && (p.ld_add % CE == 0) && (((uintptr_t)e_addend) & 15) == 0;
     constexpr int bn_mode = HAS_BN ? BNM : 0;
-    const float* const e_bias = ((HAS_AFFINE && ROLE != 5) || ROLE == 1) ? p.bias : nullptr;   // (role 1: the constant term of a folded BN backward)
-    const int e_relu = (HAS_AFFINE && ROLE != 5) ? p.relu : 0;
+    const float* const e_bias = (HAS_AFFINE || ROLE == 1) ? p.bias : nullptr;   // (role 1: the constant term of a folded BN backward)
+    const int e_relu = HAS_AFFINE ? p.relu : 0;
     // Data-gradient launches with short K are bound by the epilogue's operand stream (residual gradient, y, a_out: up to
     // three reads and one write per output element against K/N-th of that for the GEMM operands).  One step at a time
     // keeps ~1-3 KB per wave in flight; here the operands of the next DEPTH steps are requested ahead (the first DEPTH
     // before the K loop even starts), 16 B per lane and operand, into registers that are recycled step by step.
-    constexpr bool PIPE = (ROLE == 1 || ROLE == 5) && (CE == 8);
-    constexpr int DEPTH = PIPE ? (NSTEP < RPE_EPI_DEPTH ? NSTEP : RPE_EPI_DEPTH) : 1;
+    constexpr bool PIPE = ROLE == 1 && CE == 8;
+    constexpr int DEPTH = PIPE ? (NSTEP < kEpiDepth ? NSTEP : kEpiDepth) : 1;
     u32x4 qd[DEPTH], qy[DEPTH], qa[DEPTH];
     auto step_row = [&](int t) -> long { return out_row(wave_m * WM + (t / NPASS) * 16 + (t % NPASS) * RPP + erow); };
     auto issue = [&](int t) {
@@ -415,7 +412,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_N == 4 && BN < 256) 
         // tile 0 must have landed: allow the (pf - 1) newer tiles to stay in flight
         {
             const int newer = (nk < pf ? nk : pf) - 1;
-            if (newer >= 4) wait_vmcnt<4 * NI>(); else if (newer == 3) wait_vmcnt<3 * NI>(); else if (newer == 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
+            if (newer >= 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
         int st = 0;
@@ -426,7 +423,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_N == 4 && BN < 256) 
             // tile kt+1 must be complete; tiles kt+2 .. may still be in flight
             int newer = nk - 2 - kt;               // tiles issued after kt+1
             if (newer > pf - 1) newer = pf - 1;
-            if (newer >= 4) wait_vmcnt<4 * NI>(); else if (newer == 3) wait_vmcnt<3 * NI>(); else if (newer == 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
+            if (newer >= 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             if (++st == NSTAGE) st = 0;
         };
@@ -472,18 +469,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_N == 4 && BN < 256) 
             if (bn_mode == 2) { csc[j] = p.bn_scale[n + j]; csh[j] = p.bn_shift[n + j]; }
         }
     }
-    float fsc[8], fsh[8], frs[8];   // role 5: BN scale / shift of this layer (the shift carries the residual's shift) and the residual's scale
-    if constexpr (ROLE == 5) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            fsc[j] = 0.f; fsh[j] = 0.f; frs[j] = 1.f;
-            if (n + j < p.N) {
-                fsc[j] = p.fwd_scale[n + j];
-                fsh[j] = p.fwd_shift[n + j] + (p.res_shift ? p.res_shift[n + j] : 0.f);
-                if (p.res_scale) frs[j] = p.res_scale[n + j];
-            }
-        }
-    }
     auto load8 = [&](const T* base, long off, bool vec, float* out) {
         if (VEC_ONLY || vec) {
             if (CE == 8) { chunk_to_f<T>(ld16(base + off), out); }
@@ -527,23 +512,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_N == 4 && BN < 256) 
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += cbias[j];
                 }
-                if constexpr (ROLE == 5) {
-                    if (p.y_out) *(u32x4*)(p.y_out + m * p.ldc + n) = f_to_chunk<T>(v);   // (CE == 8: 16-bit element types only)
-                    float ad[8];
-                    if (e_addend) {
-                        if (PIPE && vec_add) chunk_to_f<T>(qd[sl], ad);
-                        else load8(e_addend, m * p.ld_add + n, vec_add, ad);
-                    }
-                    unsigned bits = 0;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float t = fmaf(v[j], fsc[j], fsh[j]);
-                        if (e_addend) t = fmaf(ad[j], frs[j], t);
-                        bits |= (t > 0.f ? 1u : 0u) << j;
-                        v[j] = fmaxf(t, 0.f);
-                    }
-                    if (p.mask_out) p.mask_out[(m * p.ldc + n) >> 3] = (unsigned char)bits;
-                } else
                 if (e_addend) {
                     float ad[8];
                     if (PIPE && vec_add) chunk_to_f<T>(qd[sl], ad);
@@ -581,10 +549,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_N == 4 && BN < 256) 
                 }
                 T* cp = p.C + m * p.ldc + n;
                 if (VEC_ONLY || vec_c) {
-                    if (VEC_ONLY && p.nt_store) {
-                        __builtin_nontemporal_store(f_to_chunk<T>(v), (u32x4*)cp);
-                        if (CE == 4) __builtin_nontemporal_store(f_to_chunk<T>(v + 4), (u32x4*)(cp + 4));
-                    } else if (CE == 8) { *(u32x4*)cp = f_to_chunk<T>(v); }
+                    if (CE == 8) { *(u32x4*)cp = f_to_chunk<T>(v); }
                     else { *(u32x4*)cp = f_to_chunk<T>(v); *(u32x4*)(cp + 4) = f_to_chunk<T>(v + 4); }
                 } else {
 #pragma unroll
@@ -651,7 +616,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
     constexpr int PT = BMK * CPI, QT = BMK * CPJ;      // tile sizes in 16-byte units
     constexpr int STAGE = PT + QT;
     constexpr int NSTAGE = DMA ? NSLOT : 2;            // DMA: ring of NSLOT slots, NSLOT-1 tiles in flight while one is multiplied
-    static_assert(NSLOT >= 2 && NSLOT <= 4, "ring depth 2..4");
+    static_assert(NSLOT >= 2 && NSLOT <= 3, "ring depth 2..3");
     static_assert(BMK % RPI == 0 && BMK % RPJ == 0, "tile rows must split evenly over the passes");
     __shared__ u32x4 lds[NSTAGE * STAGE];
 
@@ -904,7 +869,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
         // has passed, with its ds_reads retired by the lgkmcnt(0) of wait_vmcnt (WAR, see there).
         constexpr int NI = NPI + NPJ, PF = NSTAGE - 1;
         auto wait_newer = [&](int newer) {
-            if (newer >= 3) wait_vmcnt<3 * NI>(); else if (newer == 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
+            if (newer >= 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
         };
 #pragma unroll
         for (int t = 0; t < PF; ++t)
@@ -1048,7 +1013,7 @@ template <typename T, int MODE> static int launch_nt_split(NTArgs<T>& a, hipStre
         return rpe_set_error(RPE_ERR_WORKSPACE, "igemm_nt: split-K launch without a plan or with a slab smaller than planned");
     a.splits = S; a.split_steps = steps;
     snprintf(g_last_kernel, sizeof(g_last_kernel), "nt_kernel<%s,1,64,4,%d,3,4,0> x%d + nt_split_epilogue_kernel", Elem<T>::kName, MODE, S);
-    hipLaunchKernelGGL((nt_kernel<T, 1, 64, 4, MODE, 3, 4, 0, 2>), dim3((unsigned)tiles, (unsigned)S), dim3(128), 0, s, a);
+    hipLaunchKernelGGL((nt_kernel<T, 1, 64, 4, MODE, 3, 4, 0>), dim3((unsigned)tiles, (unsigned)S), dim3(128), 0, s, a);
     RPE_CHECK_LAUNCH();
     hipLaunchKernelGGL((nt_split_epilogue_kernel<T>), dim3((unsigned)((tiles * 1024 + 255) / 256)), dim3(256), 0, s, (const float*)a.slab, S, a.tiles_m,
                        a.tiles_n, a.M, a.N, a.bias, a.addend, a.ld_add, a.relu, a.C, a.ldc);
@@ -1061,40 +1026,34 @@ template <typename T, int MODE> static int launch_nt_split(NTArgs<T>& a, hipStre
 // parallel -- one unit with every configuration took 5 minutes)
 // -----------------------------------------------------------------------------------------------
 
-template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE, int WAVES_N = 2> static int launch_nt_role(NTArgs<T>& a, hipStream_t s, long nwg) {
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "nt_kernel<%s,%d,%d,%d,%d,%d,%d,%d%s>", Elem<T>::kName, WAVES_M, BN, KCH, MODE, NST, ROLE,
-             ROLE == 1 ? a.bn_mode : 0, WAVES_N == 4 ? ",w4" : "");
-    const dim3 grid((unsigned)nwg), block(64 * WAVES_M * WAVES_N);
+template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE> static int launch_nt_role(NTArgs<T>& a, hipStream_t s, long nwg) {
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "nt_kernel<%s,%d,%d,%d,%d,%d,%d,%d>", Elem<T>::kName, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? a.bn_mode : 0);
+    const dim3 grid((unsigned)nwg), block(128 * WAVES_M);
     if (ROLE == 1) {
         switch (a.bn_mode) {
-            case 1: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 1 : 0, WAVES_N>), grid, block, 0, s, a); break;
-            case 2: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 2 : 0, WAVES_N>), grid, block, 0, s, a); break;
-            case 3: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 3 : 0, WAVES_N>), grid, block, 0, s, a); break;
-            case 4: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 4 : 0, WAVES_N>), grid, block, 0, s, a); break;
-            default: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, 0, WAVES_N>), grid, block, 0, s, a); break;
+            case 1: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 1 : 0>), grid, block, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 2 : 0>), grid, block, 0, s, a); break;
+            case 3: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 3 : 0>), grid, block, 0, s, a); break;
+            case 4: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 4 : 0>), grid, block, 0, s, a); break;
+            default: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, 0>), grid, block, 0, s, a); break;
         }
     } else {
-        hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, 0, WAVES_N>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, 0>), grid, block, 0, s, a);
     }
     RPE_CHECK_LAUNCH();
     return 0;
 }
 
-template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST = 3, int WAVES_N = 2> static int launch_nt_cfg(NTArgs<T>& a, hipStream_t s) {
+template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST = 3> static int launch_nt_cfg(NTArgs<T>& a, hipStream_t s) {
     constexpr int BM = 64 * WAVES_M;
     a.tiles_m = (MODE == MODE_CONV && a.g.parity) ? 4 * ceil_div(a.g.rows_q, BM) : ceil_div(a.M, BM);
     a.tiles_n = ceil_div(a.N, BN);
     const long nwg = (long)a.tiles_m * a.tiles_n;
     if (nwg <= 0 || nwg > 0x7fffffffL) return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: bad grid");
-    if constexpr (WAVES_N == 4) {   // (the 8-wave form is instantiated for the two training roles only)
-        if (a.role == 1) return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 1, 4>(a, s, nwg);
-        return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 0, 4>(a, s, nwg);
-    } else {
     if (a.role == 1) return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 1>(a, s, nwg);
     if (a.role == 2) return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 2>(a, s, nwg);
     if (a.role == 3) return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 3>(a, s, nwg);
     return launch_nt_role<T, WAVES_M, BN, KCH, MODE, NST, 0>(a, s, nwg);
-    }
 }
 
 // configuration choice for one staging mode (argument checks are in launch_nt, igemm.hip)
@@ -1106,32 +1065,14 @@ template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s) 
         return launch_nt_cfg<T, 2, 64, 4, MODE_STEM>(a, s);
     } else {
         if ((a.role == 3 || (a.role == 2 && MODE == MODE_DENSE)) && a.slab && a.splits > 1) return launch_nt_split<T, MODE>(a, s);
-        if (a.role == 5) {   // 1x1 training forward with the BatchNorm apply fused (16-bit element types; rpe_conv1x1_fwd_bn)
-            if constexpr (MODE == MODE_DENSE && sizeof(T) == 2) {
-                if ((long)ceil_div(a.M, 128) * ceil_div(a.N, 128) < 96) {
-                    a.tiles_m = ceil_div(a.M, 64); a.tiles_n = ceil_div(a.N, 64);
-                    return launch_nt_role<T, 1, 64, 4, MODE_DENSE, 3, 5>(a, s, (long)a.tiles_m * a.tiles_n);
-                }
-                a.tiles_m = ceil_div(a.M, 128); a.tiles_n = ceil_div(a.N, 128);
-                return launch_nt_role<T, 2, 128, 4, MODE_DENSE, 3, 5>(a, s, (long)a.tiles_m * a.tiles_n);
-            } else {
-                return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: the fused-BN forward is a dense launch of a 16-bit element type");
-            }
-        }
-        // 256-row / 8-wave tiles (1 workgroup per CU): measured on the ResNet shapes at bs256 they gain 3..10 % in isolation
-        // for K >= 1024 and lose 10..25 % for short K, and LOSE overall inside the train step (fused epilogues, 2 waves/SIMD
-        // in lockstep): 34.4 vs 32.9 ms/step.  Kept selectable for experiments (RPE_NT_BIG=1), off by default.
-        static const bool big_enabled = getenv("RPE_NT_BIG") != nullptr;
-        const bool big = big_enabled && a.M >= 4096 && a.K >= 1024;
+        // (256-row / 8-wave tiles, 1 workgroup per CU: measured on the ResNet shapes at bs256 they gain 3..10 % in isolation for K >= 1024,
+        // lose 10..25 % for short K, and LOSE inside the train step -- fused epilogues, 2 waves/SIMD in lockstep: 34.4 vs 32.9 ms/step.)
         // Long reductions (K >= 1024: the 3x3 convs from layer2 on and the deep 1x1s): 128-B K rows (BK 64) with a 2-slot
         // ring (64 KB LDS, 2 workgroups per CU) -- half the barriers per FLOP; measured +10..15 % there, -5..15 % on short K.
         // (4- and 5-slot rings of 64-B rows, same or 1.25x the LDS and 96 / 128 instead of 64 K elements in flight, measured
         // 8 % slower on the forward shapes and level on the data gradients: the per-step cost, not the prefetch depth, is
         // what the longer rows buy back.  Only the stride-2 parity-class data gradients, 1-4 taps deep, gained 15 %.)
-        static const bool bk64_all = getenv("RPE_NT_BK64") != nullptr, bk64_off = getenv("RPE_NT_NOBK64") != nullptr;
-        if (!big && !bk64_off && a.M >= 1024 && (bk64_all ? a.K >= 16 * CE : a.K >= 1024))
-            return wide ? launch_nt_cfg<T, 2, 128, 8, MODE, 2>(a, s) : launch_nt_cfg<T, 2, 64, 8, MODE, 2>(a, s);
-        if (big) return wide ? launch_nt_cfg<T, 4, 128, 8, MODE>(a, s) : launch_nt_cfg<T, 4, 64, 8, MODE>(a, s);
+        if (a.M >= 1024 && a.K >= 1024) return wide ? launch_nt_cfg<T, 2, 128, 8, MODE, 2>(a, s) : launch_nt_cfg<T, 2, 64, 8, MODE, 2>(a, s);
         if constexpr (MODE == MODE_DENSE) {
             // few-row Linear layers (the 256-row fusion MLP and ResNet fc: 4..16 tiles of 128x128 on 256 CUs, each walking K
             // alone at the fp32 MFMA rate -- 277 us for 256x1024x3655): 64x64 tiles / 2 waves put 4..8x as many workgroups
@@ -1139,22 +1080,9 @@ template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s) 
             if (!a.stats_part && (long)ceil_div(a.M, 128) * ceil_div(a.N, wide ? 128 : 64) < 96) return launch_nt_cfg<T, 1, 64, 4, MODE_DENSE>(a, s);
         }
         if constexpr (MODE == MODE_DENSE) {
-            // 128x256 tiles (8 waves of 64x64) for wide outputs: a 128-column tile writes 256-byte pieces of 512..4096-byte output
-            // rows, and the HBM write rate falls with the fraction of a row one workgroup covers (tools/probe_rows.py: 5.2 TB/s
-            // at N = 64, 4.3 at 128, 3.4 at 256, 3.0 at 512 with 128-column tiles)
-            static const int wide256 = getenv("RPE_NT_WIDE") ? atoi(getenv("RPE_NT_WIDE")) : 0;
-            if (wide256 && (a.role == 0 || (wide256 >= 2 && a.role == 1)) && a.M >= 4096 && a.N >= 256) return launch_nt_cfg<T, 2, 256, 4, MODE, 3, 4>(a, s);
-            // 8 waves on the 128x128 tile for the short-K 1x1 layers of the two training roles: an experiment switch (RPE_NT_W8=1).
-            // Measured at 256 images: forward launches +3 %, the fused-epilogue data gradients -7 % (128 VGPRs with spills at
-            // 4 waves per SIMD), the train step 22.6 vs 22.0 ms -- occupancy is not what bounds these launches.
-            static const int w8 = getenv("RPE_NT_W8") ? atoi(getenv("RPE_NT_W8")) : 0;
-            if (w8 && a.role <= 1 && a.M >= 4096 && wide) return launch_nt_cfg<T, 2, 128, 4, MODE, 3, 4>(a, s);
-        }
-        if constexpr (MODE == MODE_DENSE) {
             // K <= two 64-byte steps (layer1's 64-channel 1x1 convs): a 2-slot ring with both steps requested up front = 32 KB of LDS,
-            // four workgroups per CU instead of three -- more operand bytes in flight for launches that live on them (RPE_NT_K64=0: off)
-            static const bool k64 = !(getenv("RPE_NT_K64") && atoi(getenv("RPE_NT_K64")) == 0);
-            if (k64 && a.role <= 1 && a.K <= 8 * CE && a.M >= 4096 && wide) return launch_nt_cfg<T, 2, 128, 4, MODE, 2>(a, s);
+            // four workgroups per CU instead of three -- more operand bytes in flight for launches that live on them
+            if (a.role <= 1 && a.K <= 8 * CE && a.M >= 4096 && wide) return launch_nt_cfg<T, 2, 128, 4, MODE, 2>(a, s);
         }
         return wide ? launch_nt_cfg<T, 2, 128, 4, MODE>(a, s) : launch_nt_cfg<T, 2, 64, 4, MODE>(a, s);
     }
@@ -1167,7 +1095,7 @@ template <typename T, int BI, int BJ, int MODE> static void plan_tn_cfg(TNArgs<T
     a.tiles_i = ceil_div(a.I, BI);
     a.tiles_j = ceil_div(a.J, BJ);
     const long tiles = (long)a.tiles_i * a.tiles_j;
-    static const long target_wgs = getenv("RPE_TN_WGS") ? atol(getenv("RPE_TN_WGS")) : 512;
+    constexpr long target_wgs = 512;   // (256..768 measured within +-2 %)
     // (scaled so the atomic / slab bytes, not the workgroup count, stay constant across tile sizes)
     const long wgs = target_wgs * (128 * 128) / (BI * BJ) / wg_div;   // (wg_div 2: one 96-KB workgroup per CU)
     // round DOWN when that still fills >= 70 % of the target: the target is what is resident at once (64 KB of LDS per
@@ -1188,15 +1116,8 @@ template <typename T, int BI, int BJ, int MODE> static void plan_tn_cfg(TNArgs<T
 // ring with 64-row steps at 2 workgroups per CU wins wherever the operands are re-read through L2 (the per-CU LDS fill rate,
 // not HBM latency, bounds those launches: 128x128x64 steps fetch 32 KB per 2.1 MFLOP), a 3-slot ring (96 KB, one workgroup per
 // CU, two tiles in flight) wins on the long, HBM-streaming reductions of layer1 (M = 802816 rows: 0.33 -> 0.18 ms for the 3x3,
-// 0.23 -> 0.16 ms for the 64 <-> 256 1x1 with half the workgroups).  RPE_TN_RING = "ksub,nslot" forces one setting.
-static inline void tn_ring(long M, int& ksub, int& nslot, bool& forced) {
-    static int k = -1, n = 0;
-    if (k < 0) {
-        k = 0;
-        if (const char* e = getenv("RPE_TN_RING")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 1 || a == 2) && b >= 2 && b <= 4) { k = a; n = b; } }
-    }
-    forced = k > 0;
-    if (forced) { ksub = k; nslot = n; return; }
+// 0.23 -> 0.16 ms for the 64 <-> 256 1x1 with half the workgroups).  3- and 4-slot rings of 32-row steps lost 4..35 % everywhere.
+static inline void tn_ring(long M, int& ksub, int& nslot) {
     ksub = 2;
     nslot = M >= 400000 ? 3 : 2;
 }
@@ -1217,14 +1138,12 @@ template <typename T, int BI, int BJ, int MODE, int KS, int NS> static int launc
 
 // slab_query: only report the slab bytes this problem needs (rpe_*_wgrad_workspace_bytes), launch nothing
 template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<T>& a, hipStream_t s, long* slab_query) {
-    // register staging (the stem, or RPE_TN_REG=1 for experiments) walks 4 chunks of rows per step, the LDS-DMA ring 4 or 8
-    static const bool reg = getenv("RPE_TN_REG") != nullptr;
-    const bool dma = MODE != MODE_STEM && !reg;
+    // register staging (the stem) walks 4 chunks of rows per step, the LDS-DMA ring 8
+    const bool dma = MODE != MODE_STEM;
     int ksub = 1, nslot = 2;
-    bool forced = false;
-    if (dma) tn_ring(a.M, ksub, nslot, forced);
+    if (dma) tn_ring(a.M, ksub, nslot);
     const int BMK = (dma ? 4 * ksub : 4) * Elem<T>::kChunk;
-    plan_tn_cfg<T, BI, BJ, MODE>(a, BMK, (dma && !forced && nslot == 3) ? 2 : 1);
+    plan_tn_cfg<T, BI, BJ, MODE>(a, BMK, (dma && nslot == 3) ? 2 : 1);
     const long nwg = (long)a.tiles_i * a.tiles_j * a.splits;
     const long slab_bytes = nwg * (long)(BI * BJ) * 4;
     if (slab_query) { *slab_query = slab_bytes; return 0; }
@@ -1249,7 +1168,7 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
     }
     snprintf(g_last_kernel, sizeof(g_last_kernel), "tn_kernel<%s,%d,%d,%d,%d,%d,%d,%d>", Elem<T>::kName, BI, BJ, MODE, dma ? 1 : 0, dma ? ksub : 1,
              dma ? nslot : 2, a.slab ? 1 : 0);
-    if (!dma) {
+    if constexpr (MODE == MODE_STEM) {
         if (a.slab) {
             hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, false, 1, 2, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
             RPE_CHECK_LAUNCH();
@@ -1261,12 +1180,9 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
         }
         RPE_CHECK_LAUNCH();
         return 0;
-    }
-    if constexpr (MODE != MODE_STEM) {
-        if (ksub == 2 && nslot == 2) return launch_tn_ring<T, BI, BJ, MODE, 2, 2>(a, s, nwg);
-        if (ksub == 2 && nslot == 3) return launch_tn_ring<T, BI, BJ, MODE, 2, 3>(a, s, nwg);
-        if (ksub == 1 && nslot == 3) return launch_tn_ring<T, BI, BJ, MODE, 1, 3>(a, s, nwg);
-        return launch_tn_ring<T, BI, BJ, MODE, 1, 4>(a, s, nwg);
+    } else {
+        if (nslot == 3) return launch_tn_ring<T, BI, BJ, MODE, 2, 3>(a, s, nwg);
+        return launch_tn_ring<T, BI, BJ, MODE, 2, 2>(a, s, nwg);
     }
     return 0;
 }

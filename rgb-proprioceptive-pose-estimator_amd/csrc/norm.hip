@@ -134,39 +134,6 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
     if (rl == 0 && c < C) fin(c, s, q);
 }
 
-// Batch statistics of y = x W^T (a 1x1 conv) WITHOUT y: mean_c = w_c . colsum(x) / M,  E[y_c^2] = w_c^T (x^T x) w_c / M.  gram: fp32
-// [rows >= Ci + 1][Ci] with x^T x in rows [0, Ci) and colsum(x) in row `ones_row` (rpe_gram); W is the compute-dtype copy the conv
-// multiplies with.  One block per output channel; the quadratic form is centred (S - s1 s1^T / M) and summed in double, the
-// threads' partial sums meet in a fixed order.
-template <typename T>
-__global__ __launch_bounds__(256) void bn_gram_stats_kernel(const T* __restrict__ w, int Ci, const float* __restrict__ gram, int ones_row, const BnFwdFin fin) {
-    __shared__ float ws[1024];
-    __shared__ double red[2][256];
-    const int c = blockIdx.x;
-    for (int i = threadIdx.x; i < Ci; i += 256) ws[i] = Elem<T>::to_f(w[(long)c * Ci + i]);
-    __syncthreads();
-    const float* s1 = gram + (long)ones_row * Ci;
-    double q = 0.0, m = 0.0;
-    for (int i = threadIdx.x; i < Ci; i += 256) m += (double)ws[i] * (double)s1[i];
-    const double inv_count = 1.0 / fin.count;
-    for (int i = threadIdx.x >> 6; i < Ci; i += 4) {          // wave i-th row of S, lanes over its columns: coalesced
-        const float* row = gram + (long)i * Ci;
-        const double wi = ws[i], s1i = s1[i];
-        double r = 0.0;
-        for (int j = threadIdx.x & 63; j < Ci; j += 64) r += (double)ws[j] * ((double)row[j] - s1i * (double)s1[j] * inv_count);
-        q += wi * r;
-    }
-    red[0][threadIdx.x] = m;
-    red[1][threadIdx.x] = q;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double sm = 0.0, sq = 0.0;
-        for (int i = 0; i < 256; ++i) { sm += red[0][i]; sq += red[1][i]; }
-        // fin expects (sum y, sum y^2): sum y^2 = centred form + (sum y)^2 / M
-        fin(c, sm, sq + sm * sm * inv_count);
-    }
-}
-
 __global__ void bn_eval_affine_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                       float* scale, float* shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -189,8 +156,12 @@ template <bool NT> __device__ inline void st16(void* p, const u32x4& v) {
     else *(u32x4*)p = v;
 }
 
-// gridDim.x * 256 is a multiple of C/CE (launcher), so a thread's channel chunk is fixed and scale/shift live in registers;
-// UNR independent 16-byte loads per operand are issued before any of them is consumed.
+// Work distribution of the streaming kernels (measured: tools/micro/stream_order.hip, profiles/r03_stream_order.txt).  A block owns ONE
+// contiguous span of 256 * SUB * UNR chunks and every thread issues its UNR independent 16-byte loads per operand once: 5.4-6.0 TB/s
+// over three 411-MB tensors, against 4.2-4.8 TB/s for the round-2 form (a capped grid whose blocks stride over the whole tensor, i.e.
+// consecutive 4-KB pieces dealt round-robin to the 8 XCDs, several passes per thread).  Thread t handles chunks
+// base + s*256 + t + u*256*SUB (s < SUB = max(1, cpr/256), u < UNR): the channel chunk (s*256 + t) % cpr does not depend on u, so
+// the per-channel coefficients live in registers; the launcher checks that cpr = C/CE is a power of two.
 template <typename T, int UNR, bool NT, bool RESBN = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ out,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
@@ -198,9 +169,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
                                                       const float* __restrict__ res_scale, const float* __restrict__ res_shift) {
     constexpr int CE = Elem<T>::kChunk;
     const int cpr = C / CE;
-    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long stride = (long)gridDim.x * blockDim.x;
-    const int c0 = (int)(i0 % cpr) * CE;
+    const int sub = cpr > 256 ? cpr / 256 : 1;
+    const long ustride = 256L * sub, span = ustride * UNR;
+    for (long base = (long)blockIdx.x * span; base < nchunks; base += (long)gridDim.x * span)
+    for (int s = 0; s < sub; ++s) {
+    const long i = base + s * 256 + threadIdx.x;
+    const int c0 = (int)(i % cpr) * CE;
     // res_scale / res_shift: the residual is itself a raw conv output whose BatchNorm (the projection shortcut's, no ReLU) is
     // applied here on the fly -- its own apply pass and the normalised copy it wrote are gone; the shift folds into sh
     float sc[CE], sh[CE], rs[CE];
@@ -210,11 +184,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
         rs[e] = 1.f;
         if (RESBN) { rs[e] = res_scale[c0 + e]; sh[e] += res_shift[c0 + e]; }
     }
-    for (long i = i0; i < nchunks; i += stride * UNR) {
+    {
         u32x4 vy[UNR], vr[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const long j = i + u * stride;
+            const long j = i + u * ustride;
             if (j < nchunks) {
                 vy[u] = ld16<NT>(y + j * CE);
                 if (res) vr[u] = ld16<NT>(res + j * CE);
@@ -222,7 +196,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const long j = i + u * stride;
+            const long j = i + u * ustride;
             if (j >= nchunks) break;
             float v[CE], r[CE];
             chunk_to_f<T>(vy[u], v);
@@ -239,6 +213,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
             *(u32x4*)(out + j * CE) = f_to_chunk<T>(v);
             if (CE == 8 && mask) mask[j] = (unsigned char)bits;   // one byte per 8-channel chunk (16-bit element types only)
         }
+    }
     }
 }
 
@@ -323,10 +298,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_dz_kernel(const T* __restric
                                                              long nchunks, int C) {
     constexpr int CE = Elem<T>::kChunk;
     const int cpr = C / CE;
-    // gridDim.x * 256 is a multiple of cpr (launcher), so a thread's channel chunk is fixed: coefficients live in registers
-    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long stride = (long)gridDim.x * blockDim.x;
-    const int c0 = (int)(i0 % cpr) * CE;
+    // contiguous span per block, one pass per thread (see bn_apply_kernel)
+    const int sub = cpr > 256 ? cpr / 256 : 1;
+    const long ustride = 256L * sub, span = ustride * UNR;
+    for (long base = (long)blockIdx.x * span; base < nchunks; base += (long)gridDim.x * span)
+    for (int s = 0; s < sub; ++s) {
+    const long i = base + s * 256 + threadIdx.x;
+    const int c0 = (int)(i % cpr) * CE;
     float k0[CE], k1[CE], k2[CE];  // dy = k0*dz + k1 + k2*y
 #pragma unroll
     for (int e = 0; e < CE; ++e) {
@@ -335,16 +313,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_dz_kernel(const T* __restric
         k2[e] = -gi * invstd[c0 + e] * c2[c0 + e];
         k1[e] = -gi * c1[c0 + e] - k2[e] * mean[c0 + e];
     }
-    for (long i = i0; i < nchunks; i += stride * UNR) {
+    {
         u32x4 vd[UNR], vy[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const long j = i + u * stride;
+            const long j = i + u * ustride;
             if (j < nchunks) { vd[u] = ld16<NT>(dz + j * CE); vy[u] = ld16<NT>(y + j * CE); }
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const long j = i + u * stride;
+            const long j = i + u * ustride;
             if (j >= nchunks) break;
             float d[CE], yy[CE];
             chunk_to_f<T>(vd[u], d);
@@ -353,6 +331,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_dz_kernel(const T* __restric
             for (int e = 0; e < CE; ++e) d[e] = fmaf(k0[e], d[e], fmaf(k2[e], yy[e], k1[e]));
             *(u32x4*)(dy + j * CE) = f_to_chunk<T>(d);
         }
+    }
     }
 }
 
@@ -501,7 +480,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(const T* __restrict__ dpool, const unsigned char* __restrict__ pidx, const StemAux ax,
                                                              const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd, int B, int H, int W,
-                                                             int Ho, int Wo, float* __restrict__ part) {
+                                                             int Ho, int Wo, int rows_per_block, float* __restrict__ part) {
     constexpr int CE = Elem<T>::kChunk, CPR = 64 / CE, PPB = 256 / CPR;   // chunks per pixel, pixels per block pass
     __shared__ float sh[PPB][64][2];
     const int cc = threadIdx.x % CPR, pl = threadIdx.x / CPR, c0 = cc * CE;
@@ -512,8 +491,10 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(const T* __restric
 #pragma unroll
     for (int e = 0; e < CE; ++e) axw[e] = ax.dout ? ax.w[c0 + e] : 0.f;
     // one image row (b, h) at a time per block: the row decomposition is one scalar division per row, not two 64-bit
-    // divisions per element (which, not HBM, bounded the first version of this kernel: 0.5 ms per pass)
-    for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
+    // divisions per element (which, not HBM, bounded the first version of this kernel: 0.5 ms per pass).  A block owns
+    // `rows_per_block` CONSECUTIVE rows (a contiguous span of y: see bn_apply_kernel on why blocks do not stride over the tensor)
+    const int row_end = min(B * H, ((int)blockIdx.x + 1) * rows_per_block);
+    for (int row = blockIdx.x * rows_per_block; row < row_end; ++row) {
         const int b = row / H, h = row - b * H;
         for (int pw = 0; pw < 2; ++pw)   // all lanes on the same column parity: the set of pool windows is wave-uniform
             for (int w = 2 * pl + pw; w < W; w += 2 * PPB) {
@@ -542,7 +523,7 @@ __global__ __launch_bounds__(256) void stem_bwd_apply_kernel(const T* __restrict
                                                             const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ c1, const float* __restrict__ c2,
-                                                            T* __restrict__ dy, int B, int H, int W, int Ho, int Wo) {
+                                                            T* __restrict__ dy, int B, int H, int W, int Ho, int Wo, int rows_per_block) {
     constexpr int CE = Elem<T>::kChunk, CPR = 64 / CE, PPB = 256 / CPR;
     const int cc = threadIdx.x % CPR, pl = threadIdx.x / CPR, c0 = cc * CE;
     float sc[CE], sf[CE], k0[CE], k1[CE], k2[CE];
@@ -557,7 +538,8 @@ __global__ __launch_bounds__(256) void stem_bwd_apply_kernel(const T* __restrict
     float axw[CE];
 #pragma unroll
     for (int e = 0; e < CE; ++e) axw[e] = ax.dout ? ax.w[c0 + e] : 0.f;
-    for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
+    const int row_end = min(B * H, ((int)blockIdx.x + 1) * rows_per_block);
+    for (int row = blockIdx.x * rows_per_block; row < row_end; ++row) {
         const int b = row / H, h = row - b * H;
         for (int pw = 0; pw < 2; ++pw)
             for (int w = 2 * pl + pw; w < W; w += 2 * PPB) {
@@ -748,7 +730,9 @@ __global__ __launch_bounds__(256) void resize_v_crop_norm_kernel(const unsigned 
 // ---------------------------------------------------------------------------------------------
 static inline int ew_grid(long n, int per_block = 256) {
     long g = (n + per_block - 1) / per_block;
-    if (g > 8192) g = 8192;
+    // (round 2 capped this at 8192 blocks that stride over the tensor: 4.7 TB/s where one-pass blocks stream at 5.4-6.0,
+    // tools/micro/stream_order.hip)
+    if (g > (1L << 20)) g = 1L << 20;
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -760,7 +744,7 @@ static inline EwCfg ew_cfg() {
         // non-temporal operand loads: the streamed tensors are read once here (their next reader is a different kernel, >= their own
         // size of traffic later) and stop evicting the weights / partial sums the neighbouring GEMM launches keep in L2.  Measured
         // on one box, three alternations: 20.84 vs 21.17 ms/step (round 1, before the folds: level).  RPE_EW_NT=0 restores cached loads.
-        EwCfg v{4, 8192, true};
+        EwCfg v{4, 1L << 20, true};
         if (const char* e = getenv("RPE_EW_UNR")) v.unr = atoi(e);
         if (const char* e = getenv("RPE_EW_GRID")) v.cap = atol(e);
         if (const char* e = getenv("RPE_EW_NT")) v.nt = atoi(e) != 0;
@@ -768,16 +752,16 @@ static inline EwCfg ew_cfg() {
     }();
     return c;
 }
-// grid for `n` 16-byte chunks of rows with `cpr` chunks each: grid*256 a multiple of cpr, one thread covers >= unr chunks
+// grid for `n` 16-byte chunks of rows with `cpr` chunks each (a power of two): one block per contiguous span of
+// 256 * max(1, cpr/256) * unr chunks (bn_apply_kernel), capped at cfg.cap blocks (the kernels loop over further spans)
 static inline long ew_grid_rows(long n, int cpr, const EwCfg& cfg) {
-    long g = (n + 256L * cfg.unr - 1) / (256L * cfg.unr);
+    const long span = 256L * (cpr > 256 ? cpr / 256 : 1) * cfg.unr;
+    long g = (n + span - 1) / span;
     if (g > cfg.cap) g = cfg.cap;
     if (g < 1) g = 1;
-    long a = cpr, b = 256;
-    while (b) { const long t = a % b; a = b; b = t; }
-    const long mult = cpr / a;  // cpr / gcd(cpr, 256)
-    return (g + mult - 1) / mult * mult;
+    return g;
 }
+static inline bool ew_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // slices for the staged partial reduction: enough blocks to cover the chip, >= 8 tiles per slice
 static inline int reduce_slices(int tiles, int C) {
@@ -810,7 +794,7 @@ int bn_apply_launch(const void* y, const void* res, void* out, const float* scal
     const int cpr = C / CE;
     const EwCfg cfg = ew_cfg();
     const long g = ew_grid_rows(n, cpr, cfg);
-    if ((g * 256) % cpr) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply: C/chunk must divide grid*256 (power-of-two channel counts)");
+    if (!ew_pow2(cpr)) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply: C / (16-byte chunk) must be a power of two");
     if (mask && sizeof(T) != 2) return rpe_set_error(RPE_ERR_DTYPE, "bn_apply_mask: the packed ReLU mask is written for 16-bit element types only");
 #define RPE_BN_APPLY(U, N, R) hipLaunchKernelGGL((bn_apply_kernel<T, U, N, R>), dim3((unsigned)g), dim3(256), 0, s, (const T*)y, (const T*)res, (T*)out, scale, shift, n, C, relu, mask, res_scale, res_shift)
     if (res_scale) {   // the residual under its own BatchNorm (rpe_bn_apply_res_bn): one configuration
@@ -830,10 +814,9 @@ static int bn_apply_dz_launch(const void* dz, const void* y, const float* mean, 
     constexpr int CE = Elem<T>::kChunk;
     const int cpr = C / CE;
     const long n = M * C / CE;
-    // grid * 256 must be a multiple of chunks-per-row (cpr is a power of two <= 512 for every ResNet width)
     const EwCfg cfg = ew_cfg();
     const long g = ew_grid_rows(n, cpr, cfg);
-    if ((g * 256) % cpr) return rpe_set_error(RPE_ERR_SHAPE, "bn_bwd_from_dz: C/chunk must be a power of two");
+    if (!ew_pow2(cpr)) return rpe_set_error(RPE_ERR_SHAPE, "bn_bwd_from_dz: C / (16-byte chunk) must be a power of two");
 #define RPE_BN_DZ(U, N) hipLaunchKernelGGL((bn_bwd_apply_dz_kernel<T, U, N>), dim3((unsigned)g), dim3(256), 0, s, (const T*)dz, (const T*)y, mean, invstd, gamma, c1, c2, (T*)dy, n, C)
     if (cfg.nt) { if (cfg.unr == 1) RPE_BN_DZ(1, true); else if (cfg.unr == 2) RPE_BN_DZ(2, true); else RPE_BN_DZ(4, true); }
     else { if (cfg.unr == 1) RPE_BN_DZ(1, false); else if (cfg.unr == 2) RPE_BN_DZ(2, false); else RPE_BN_DZ(4, false); }
@@ -866,7 +849,7 @@ int bn_bwd_launch(const void* dA, const void* a_out, const void* y, const float*
     if (int e = reduce_finalize(part, (int)nb, C, dpart, BnBwdFin{(double)M, dgamma, dbeta, c1, c2}, s)) return e;
     if (!dy) return 0;   // statistics only (rpe_bn_backward_reduce): the apply pass is folded into the consumers
     // no ReLU in front and no dz wanted (projection-shortcut BNs): dz == dA, the streaming dz -> dy kernel does the third pass
-    if (!a_out && !dz_out && (256 % (C / CE) == 0 || (C / CE) % 256 == 0)) return bn_apply_dz_launch<T>(dA, y, mean, invstd, gamma, c1, c2, dy, M, C, s);
+    if (!a_out && !dz_out && ew_pow2(C / CE)) return bn_apply_dz_launch<T>(dA, y, mean, invstd, gamma, c1, c2, dy, M, C, s);
     const long n = M * C / CE;
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, s, (const T*)dA, (const T*)a_out, (const T*)y, mean, invstd, gamma,
                        (const float*)c1, (const float*)c2, (T*)dy, (T*)dz_out, n, C);
@@ -896,15 +879,17 @@ int stem_bwd_launch(const void* dpool, const unsigned char* pidx, const StemAux&
     if (nbl > 8192) nbl = 8192;
     if (nbl > (long)B * H) nbl = (long)B * H;
     if (nbl < 1) return rpe_set_error(RPE_ERR_WORKSPACE, "stem_bwd: partial-sum workspace too small");
-    const int nb = (int)nbl;
+    const int rpb = (int)(((long)B * H + nbl - 1) / nbl);          // consecutive image rows per block
+    const int nb = (int)(((long)B * H + rpb - 1) / rpb);
     hipLaunchKernelGGL((stem_bwd_reduce_kernel<T>), dim3(nb), dim3(256), 0, s, (const T*)dpool, pidx, ax, (const T*)y, scale, shift, mean, invstd, B, H, W,
-                       Ho, Wo, part);
+                       Ho, Wo, rpb, part);
     RPE_CHECK_LAUNCH();
     float* c1 = c1c2;
     float* c2 = c1c2 + 64;
     if (int e = reduce_finalize(part, nb, 64, dpart, BnBwdFin{(double)B * H * W, dgamma, dbeta, c1, c2}, s)) return e;
-    hipLaunchKernelGGL((stem_bwd_apply_kernel<T>), dim3(B * H < 16384 ? B * H : 16384), dim3(256), 0, s, (const T*)dpool, pidx, ax, (const T*)y, scale, shift, mean, invstd,
-                       gamma, (const float*)c1, (const float*)c2, (T*)dy, B, H, W, Ho, Wo);
+    const int rpa = (B * H + (1 << 20) - 1) >> 20;   // one image row (14 KB of y at 112 pixels) per block, up to 2^20 blocks
+    hipLaunchKernelGGL((stem_bwd_apply_kernel<T>), dim3((B * H + rpa - 1) / rpa), dim3(256), 0, s, (const T*)dpool, pidx, ax, (const T*)y, scale, shift, mean, invstd,
+                       gamma, (const float*)c1, (const float*)c2, (T*)dy, B, H, W, Ho, Wo, rpa);
     RPE_CHECK_LAUNCH();
     return 0;
 }
@@ -928,21 +913,6 @@ int rpe_bn_finalize(const float* part, int tiles, int C, long count, const float
     if (tiles <= 0 || C <= 0 || count <= 0) return rpe_set_error(RPE_ERR_SHAPE, "bn_finalize: empty problem");
     return reduce_finalize(part, tiles, C, dpart, BnFwdFin{(double)count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, scale,
                                                            shift, save_mean, save_invstd}, (hipStream_t)stream);
-}
-
-int rpe_bn_stats_from_gram(int dtype, const void* w, int Co, int Ci, const float* gram, int ones_row, long count, const float* gamma, const float* beta,
-                           float* running_mean, float* running_var, long long* num_batches, float momentum, float eps, float* scale, float* shift,
-                           float* save_mean, float* save_invstd, void* stream) {
-    note_kernel("bn_gram_stats_kernel");
-    if (!w || !gram || Co <= 0 || Ci <= 0 || Ci > 1024 || count <= 0 || ones_row < Ci) return rpe_set_error(RPE_ERR_SHAPE, "bn_stats_from_gram: bad arguments (in_c <= 1024)");
-    const BnFwdFin fin{(double)count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, scale, shift, save_mean, save_invstd};
-    hipStream_t s = (hipStream_t)stream;
-    if (dtype == RPE_F32) hipLaunchKernelGGL((bn_gram_stats_kernel<float>), dim3(Co), dim3(256), 0, s, (const float*)w, Ci, gram, ones_row, fin);
-    else if (dtype == RPE_BF16) hipLaunchKernelGGL((bn_gram_stats_kernel<bf16>), dim3(Co), dim3(256), 0, s, (const bf16*)w, Ci, gram, ones_row, fin);
-    else if (dtype == RPE_F16) hipLaunchKernelGGL((bn_gram_stats_kernel<f16>), dim3(Co), dim3(256), 0, s, (const f16*)w, Ci, gram, ones_row, fin);
-    else return rpe_set_error(RPE_ERR_DTYPE, "bn_stats_from_gram: unsupported dtype");
-    RPE_CHECK_LAUNCH();
-    return 0;
 }
 
 int rpe_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,

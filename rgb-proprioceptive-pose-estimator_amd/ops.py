@@ -301,40 +301,6 @@ def bn_apply_res_bn(y, scale, shift, res_y, res_scale, res_shift, relu=True, wan
     return (out, mask) if want_mask else out
 
 
-def gram(x):
-    """x [..., C] (NHWC activations) -> (x^T x [C, C], colsum(x) [C]) fp32, one launch + fixed-order slab sum"""
-    c = x.shape[-1]
-    m = x.numel() // c
-    code = dtype_code(x)
-    ones_row = lib.rpe_gram_ones_row(c)
-    out = torch.empty((ones_row + 1, c), dtype=torch.float32, device=x.device)
-    ws = scratch(lib.rpe_gram_workspace_bytes(code, m, c), x.device)
-    lib.rpe_gram(code, _p(_chk(x, "x")), m, c, _p(out), _p(ws), ws.numel(), _stream())
-    return out[:c], out[ones_row], out
-
-
-def bn_stats_from_gram(w, gram_buf, count, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
-    """BatchNorm statistics of y = x w^T from the Gram buffer of x (ops.gram): (scale, shift, mean, invstd)"""
-    co, ci = w.shape
-    dev = w.device
-    scale, shift, mean, invstd = (torch.empty(co, dtype=torch.float32, device=dev) for _ in range(4))
-    lib.rpe_bn_stats_from_gram(dtype_code(w), _p(_chk(w, "w")), co, ci, _p(gram_buf), lib.rpe_gram_ones_row(ci), int(count), _p(gamma), _p(beta),
-                               _p(running_mean), _p(running_var), None, momentum, eps, _p(scale), _p(shift), _p(mean), _p(invstd), _stream())
-    return scale, shift, mean, invstd
-
-
-def conv1x1_fwd_bn(x, w, scale, shift, residual=None, res_scale=None, res_shift=None, want_y=False):
-    """relu((x w^T) * scale + shift + residual [* res_scale + res_shift]) with the packed ReLU mask, one launch (16-bit types)"""
-    co, ci = w.shape
-    d = conv_desc(x.shape, co, 1, 1, 0)
-    out = torch.empty(tuple(x.shape[:-1]) + (co,), dtype=x.dtype, device=x.device)
-    y = torch.empty_like(out) if want_y else None
-    mask = torch.empty(out.numel() // 8, dtype=torch.uint8, device=x.device)
-    lib.rpe_conv1x1_fwd_bn(ctypes.byref(d), dtype_code(x), _p(_chk(x, "x")), _p(_chk(w, "w")), _p(out), _p(y), _p(scale), _p(shift), _p(residual),
-                           _p(res_scale), _p(res_shift), _p(mask), _stream())
-    return out, mask, y
-
-
 def bn_backward(dA, a_out, y, mean, invstd, gamma, want_dz=False):
     c = y.shape[-1]
     dev = y.device

@@ -88,6 +88,15 @@ def train_step(model, batch, criterion, optimizer, train_obj_pose, phase="train"
     return loss.detach(), pos_err, ori_err
 
 
+def _graph_keepalive(model):
+    """What a captured graph has baked addresses of, beyond its own tensors: the trunk plans (native engine + workspace) that exist
+    at capture time and the per-device weight-gradient scratch.  A later eager call may evict a plan from the trunk's LRU table or
+    replace the scratch by a larger buffer; holding these references keeps the captured addresses alive for as long as the graph
+    object lives (the eager path simply continues on its new buffers)."""
+    from .. import ops
+    return (list(model.trunk._plans.values()), list(ops._SCRATCH.values()))
+
+
 class GraphedTrainStep:
     """One train step (forward -> loss -> on-device val metrics -> backward -> Adam) captured ONCE into a hipGraph and replayed.
 
@@ -121,12 +130,18 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph):
             self.out = train_step(model, self.static, criterion, optimizer, train_obj_pose, "train", None)
         self.warmup_steps = warmup   # optimizer steps taken while building (the capture itself does not execute anything)
+        self._keep = _graph_keepalive(model)
 
     def __call__(self, batch):
         for dst, src in zip(self.static, batch):
             if dst is not None and dst is not src:   # (fill `self.static` in place to skip the copy)
                 dst.copy_(src, non_blocking=True)
         self.graph.replay()
+        # The replay re-ran the captured weight-packing launch, the optimizer and the BN running-statistics updates behind the
+        # host's back: every plan's cached weight copies (the BN-folded inference copies above all) are stale now, exactly as
+        # after an eager step.  Bumping the trunk's weight version makes the next eval forward -- on this plan or any other --
+        # re-fold before it runs.
+        self.model.trunk.weights_changed()
         return self.out
 
 
@@ -149,6 +164,7 @@ class GraphedRolloutFrame:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.out = model(self.img, self.depth, self.x0bar)
+        self._keep = _graph_keepalive(model)
 
     def __call__(self, img, depth, x0bar):
         self.img.copy_(img, non_blocking=True)

@@ -689,52 +689,6 @@ def test_bn_apply_with_shortcut_bn_on_the_fly(dtype, rows, c):
         assert torch.equal(bits, out.cpu().float() > 0)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("cfg", [(8, 28, 64, 256), (4, 14, 128, 512), (6, 14, 256, 1024), (2, 6, 64, 256)])
-@pytest.mark.parametrize("shortcut", ["identity", "projection", "none"])
-def test_conv1x1_forward_with_bn_from_gram(dtype, cfg, shortcut):
-    """conv3 -> bn3 -> (+identity) -> ReLU without writing or re-reading the conv output: BatchNorm statistics from the Gram matrix of
-    the INPUT (rpe_gram + rpe_bn_stats_from_gram) against the statistics of the conv output itself; the fused forward
-    (rpe_conv1x1_fwd_bn) against conv -> batch_norm -> add -> relu; mask = the positive outputs."""
-    b, h, ci, co = cfg
-    g = torch.Generator().manual_seed(sum(cfg))
-    x = q(F.relu(torch.randn(b, h, h, ci, generator=g) * 1.5 + 0.4), dtype)          # post-ReLU activations: positive means
-    w = q(torch.randn(co, ci, generator=g) / ci ** 0.5, dtype)
-    gamma, beta = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.3
-    rows = b * h * h
-    y64 = x.reshape(rows, ci).double() @ w.double().t()
-    mean_ref, var_ref = y64.mean(0), y64.var(0, unbiased=False)
-    xd, wd = x.to(dtype).to(DEV), w.to(dtype).to(DEV)
-    S, s1, buf = ops.gram(xd)
-    assert rel_err(S, (x.reshape(rows, ci).double().t() @ x.reshape(rows, ci).double()).float()) < 2e-5
-    assert rel_err(s1, x.reshape(rows, ci).double().sum(0).float()) < 2e-5
-    assert torch.equal(buf, ops.gram(xd)[2])                                          # fixed-order sums
-    rm, rv = torch.zeros(co, device=DEV), torch.ones(co, device=DEV)
-    scale, shift, mean, invstd = ops.bn_stats_from_gram(wd, buf, rows, gamma.to(DEV), beta.to(DEV), rm, rv)
-    assert rel_err(mean, mean_ref.float()) < 1e-4
-    assert ((invstd.cpu().double() * torch.sqrt(var_ref + 1e-5) - 1).abs().max()) < 2e-4
-    assert rel_err(rm, 0.1 * mean_ref.float()) < 1e-4
-    assert rel_err(rv, (0.9 + 0.1 * var_ref * rows / (rows - 1)).float()) < 2e-4
-    res = rs = rb = None
-    ref = (y64 - mean_ref) / torch.sqrt(var_ref + 1e-5) * gamma.double() + beta.double()
-    if shortcut != "none":
-        res = q(torch.randn(rows, co, generator=g), dtype)
-        if shortcut == "projection":
-            rs, rb = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.3
-            ref = ref + res.double() * rs.double() + rb.double()
-        else:
-            ref = ref + res.double()
-    ref = F.relu(ref).float().reshape(b, h, h, co)
-    dev = lambda t: None if t is None else t.to(DEV)
-    out, mask, y = ops.conv1x1_fwd_bn(xd, wd, scale, shift, None if res is None else res.to(dtype).to(DEV).reshape(b, h, h, co), dev(rs), dev(rb), want_y=True)
-    assert rel_err(out, ref) < tol(dtype)
-    assert rel_err(y, y64.float().reshape(b, h, h, co)) < tol(dtype)
-    bits = ((mask.cpu()[:, None] >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(rows, co).bool()
-    assert torch.equal(bits, out.cpu().float().reshape(rows, co) > 0)
-    out2, mask2, none = ops.conv1x1_fwd_bn(xd, wd, scale, shift, None if res is None else res.to(dtype).to(DEV).reshape(b, h, h, co), dev(rs), dev(rb))
-    assert none is None and torch.equal(out2, out) and torch.equal(mask2, mask)
-
-
 def test_operands_above_2_gib():
     """Round 1 capped a tensor at 2 GiB (32-bit byte offsets against one buffer descriptor: ~1300 images per process in bf16).  The
     descriptors now start at each tile's / split's first row or image: convs whose activation tensors exceed 2 GiB must equal the same

@@ -27,7 +27,14 @@ from _helpers_cases import C1, SAMPLE_MAX, SAMPLE_STRIDE, SEQ_CFG, SEQ_SAMPLE_MA
 DEV = "cuda"
 # relative-to-max tolerance of the 7-d pose outputs / the loss per compute dtype.  fp32 is the north-star bar; the 16-bit
 # paths round every activation to 8 (bf16) or 11 (fp16) significant bits.
-OUT_TOL = {torch.float32: 1e-4, torch.bfloat16: 6.5e-2, torch.float16: 1.5e-2}
+# Bars ~2x what is measured at the configs[0] size (bf16 8.2e-3, fp16 1.8e-3; fp32 1.8e-6 against the north-star 1e-4).
+OUT_TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2, torch.float16: 4e-3}
+# the toy golden cases run train-mode BatchNorm over 2-4 images: the statistics of so few samples amplify the storage rounding further
+# (measured worst cases over the five families: bf16 3.4e-2, fp16 1.4e-2 -- the two-stage `n` model)
+TOY_TOL = {torch.float32: 1e-4, torch.bfloat16: 6.5e-2, torch.float16: 2.5e-2}
+# config-sized sequence models (32 images): the LSTM stacks -- in `td` two of them in series -- carry the trunk's storage rounding
+# further than the MLP of configs[0] does (measured: td bf16 2.1e-2 on the second output)
+SEQ_TOL = {torch.float32: 1e-4, torch.bfloat16: 4.5e-2, torch.float16: 1e-2}
 # GRADIENT bars.  At random initialisation this 50-layer train-mode-BN network amplifies rounding noise in the backward by
 # ~1e5 (every BN backward subtracts the common-mode part of the gradient, the rounding noise stays): two fp32 implementations
 # differ by 1-3e-2 per trunk tensor, and gradients computed with 16-bit activation storage are mostly noise in the early
@@ -186,7 +193,8 @@ def test_all_models_16bit_gradient_quality(kind, dtype, golden_dir):
         loss = crit(out, b1["obj"])
         outs = (out,)
     loss.backward()
-    tol = OUT_TOL[dtype]
+    tol = TOY_TOL[dtype]
+    print("%s[%s] toy: pose rel err %s" % (kind, dtype, ["%.3e" % rel(o, gold["out%d_s1" % i]) for i, o in enumerate(outs)]))
     for i, o in enumerate(outs):
         assert rel(o, gold["out%d_s1" % i]) < tol, "out%d" % i
     np.testing.assert_allclose(loss.item(), gold["loss_s1"], rtol=tol)
@@ -279,7 +287,7 @@ def test_config_sized_sequence_models_match_reference(kind, dtype, golden_dir):
     model.cuda()
     crit = M.PoseDistanceLoss(distance_metric="combined", scale_factor=1.0, alpha=0.5, mode="pose")
     val = M.PoseDistanceLoss(mode="val")
-    tol = OUT_TOL[dtype]
+    tol = SEQ_TOL[dtype]
     model.eval()
     model.reset_initial_state(lead[-1])
     b9 = to_dev(po.synth_batch(lead, dseed + 9, with_depth=use_depth))
@@ -287,6 +295,7 @@ def test_config_sized_sequence_models_match_reference(kind, dtype, golden_dir):
         out = model(b9["img"], b9["depth"], b9["x0bar"])
     for i, o in enumerate(out if isinstance(out, tuple) else (out,)):
         e = rel(o, gold["pre_eval_out%d" % i])
+        print("%s_cfg[%s]: eval out%d rel err %.3e" % (kind, dtype, i, e))
         assert e < max(tol, 2e-4), "eval out%d %.3g" % (i, e)
     model.train()
     model.reset_initial_state(lead[-1])
@@ -332,3 +341,39 @@ def test_config_sized_sequence_models_match_reference(kind, dtype, golden_dir):
             assert err < head_bar, "%s: cosine %.5f, relative error %.4f" % (name, cos, err)
         if dtype == torch.float32:
             np.testing.assert_allclose(float(g.double().norm()), dig[1], rtol=F32_GRAD_BAR[1], err_msg=name)
+
+
+def test_bs256_benchmarked_shape_bf16_outputs_gradients_and_repeatability():
+    """The benchmarked shape itself (BASELINE configs[1]: 256 images of 224x224 per GPU, bf16, NaiveObjectStateEstimator with latent
+    512 / hidden [1024, 256, 64]): train-mode outputs against the CPU oracle on identical weights and inputs, every gradient finite,
+    and two passes over the same batch bitwise equal (outputs and the whole flat gradient)."""
+    cfg = dict(latent_dim=512, hidden=[1024, 256, 64], use_depth=False, no_proprioception=False)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    sd = po.make_state("no", cfg, 33)
+    batch = po.synth_batch((256,), 303)
+    with torch.no_grad():
+        ref = po.model_forward("no", cfg, {k: v.clone() for k, v in sd.items()}, batch["img"], None, batch["x0bar"], train=True)
+    model = quiet_build("no", cfg, torch.bfloat16)
+    load_values(model, "no", sd)
+    model.cuda().train()
+    crit = M.PoseDistanceLoss(distance_metric="combined", scale_factor=1.0, alpha=0.5, mode="pose")
+    b = to_dev(batch)
+    passes = []
+    for _ in range(2):
+        for p in model.parameters():
+            p.grad = None
+        out = model(b["img"], None, b["x0bar"])
+        loss = crit(out, b["obj"])
+        loss.backward()
+        torch.cuda.synchronize()
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        passes.append((out.detach().clone(), loss.detach().clone(), grads))
+    e = rel(passes[0][0], ref)
+    print("bs256[bf16]: pose rel err vs oracle %.3e, loss %.4f" % (e, passes[0][1].item()))
+    assert e < OUT_TOL[torch.bfloat16]
+    assert len(passes[0][2]) > 160
+    for n, g in passes[0][2].items():
+        assert torch.isfinite(g).all(), n
+    assert torch.equal(passes[0][0], passes[1][0])
+    for n, g in passes[0][2].items():
+        assert torch.equal(g, passes[1][2][n]), "gradient of %s differs between two passes over the same batch" % n
