@@ -389,6 +389,12 @@ const char* rpe_last_kernel_name(void);
 int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_features, long ld_d_features, void* stream);
 int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int join, void* stream);
 int rpe_resnet50_backward_end(rpe_resnet50_t* e, int use_d_early, void* stream);
+/* Backward of a FROZEN trunk -- import_resnet freezes every ResNet parameter when feature_extract and use_pretrained are both set
+ * (util/model_utils.py:110-113,136-137; the setting of every published job: scripts/train_no.sbatch:83, train_tdo.sbatch:83,
+ * train_tdo_v2.sbatch:84) and then installs a fresh, trainable fc (util/model_utils.py:140-141): only that fc's weight and bias take
+ * a gradient, nothing flows into the body (no data gradient, no BN backward, no conv weight gradients: ~2/3 of the step's work).
+ * The forward stays the training forward (BatchNorm on batch statistics, running statistics updated), as torch runs it. */
+int rpe_resnet50_backward_frozen(rpe_resnet50_t* e, const float* d_features, long ld_d_features, void* stream);
 /* Instead of a dense early-feature gradient tensor (rpe_resnet50_early_grad), hand the aux head's gradient to the next backward
  * in its compact form (see rpe_stem_bwd); the pointers must stay valid until that backward's end stage has been enqueued.
  * aux_dout == NULL clears it. */

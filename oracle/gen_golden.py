@@ -451,6 +451,48 @@ def run_nan_loss():
     print("no_nanloss loss", rec["loss_s1"], "max |grad|", max(d[2] for d in gd))
 
 
+# The configuration every published job of the reference runs (scripts/train_no.sbatch:83, train_tdo.sbatch:83, train_tdo_v2.sbatch:84
+# pass --use_pretrained, and feature_extract=True is the constructors' default): util/model_utils.py:110-113,136-137 then FREEZES the
+# whole ResNet body (requires_grad False) and only the replaced fc, the aux head and the fusion layers train -- with BatchNorm still in
+# train mode (batch statistics, running statistics updated).  The stub's resnet50(pretrained=True) returns its seeded init instead of
+# fetching.  Recorded: which parameters have a gradient, outputs / loss, those gradients, BN running statistics after the step.
+def run_frozen():
+    cfg, lead, wseed, dseed = CASES["no"]
+    torch.manual_seed(0)
+    model = NaiveObjectStateEstimator("cube", list(cfg["hidden"]), 50, cfg["latent_dim"], True, (9,), False, True, False)
+    sd = po.make_state("no", cfg, wseed)
+    load_values(model, "no", sd)
+    model.train()
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-3)
+    b = po.synth_batch(lead, dseed + 1)
+    out = model(b["img"], torch.empty(*b["img"].shape), b["x0bar"])
+    loss = PoseDistanceLoss(**LOSS_CFG)(out, b["obj"])
+    opt.zero_grad()
+    loss.backward()
+    rec = {"out0_s1": out.detach().numpy(), "loss_s1": np.array(loss.item())}
+    rec["trainable"] = np.array([n for n, p in model.named_parameters() if p.requires_grad])
+    rec["frozen"] = np.array([n for n, p in model.named_parameters() if not p.requires_grad])
+    gn, gd = [], []
+    for name, p in model.named_parameters():
+        if p.grad is None:   # frozen, or the depth head (trainable but unused without use_depth)
+            continue
+        assert p.requires_grad, name
+        gn.append(name)
+        gd.append(digest(p.grad))
+        g = p.grad.detach().flatten()
+        rec[("grad::" if g.numel() <= 4096 else "gsample::") + name] = (g if g.numel() <= 4096 else g[::SAMPLE_STRIDE][:SAMPLE_MAX]).numpy().copy()
+    rec["grad_keys_s1"], rec["grad_digest_s1"] = np.array(gn), np.stack(gd)
+    opt.step()
+    fin = model.state_dict()
+    for k, v in fin.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            if v.numel() <= 256:
+                rec["final::" + k] = v.numpy().copy()
+    rec["final_frozen_digest"] = np.stack([digest(fin[k]) for k in [str(n) for n in rec["frozen"]]])
+    np.savez_compressed(os.path.join(OUT, "model_no_frozen.npz"), **rec)
+    print("no_frozen loss", rec["loss_s1"], "trainable", len(rec["trainable"]), "frozen", len(rec["frozen"]))
+
+
 def run_loss():
     g = torch.Generator().manual_seed(7)
     rec = {}
@@ -481,7 +523,7 @@ def run_loss():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["loss"] + list(CASES) + ["c1", "r101", "td_s4", "hooks", "nohook", "td_cfg", "tdo_cfg", "tdo_v2_cfg", "nanloss"]
+    which = sys.argv[1:] or ["loss"] + list(CASES) + ["c1", "r101", "td_s4", "hooks", "nohook", "td_cfg", "tdo_cfg", "tdo_v2_cfg", "nanloss", "frozen"]
     for w in which:
         if w == "loss":
             run_loss()
@@ -495,6 +537,8 @@ if __name__ == "__main__":
             run_hooks("hooks", HOOKS)
         elif w == "nohook":
             run_hooks("nohook", NOHOOK)
+        elif w == "frozen":
+            run_frozen()
         elif w == "nanloss":
             run_nan_loss()
         elif w.endswith("_cfg"):

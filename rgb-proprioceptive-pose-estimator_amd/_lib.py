@@ -129,6 +129,7 @@ _SPEC = {
     "rpe_resnet50_backward_begin": (I, [P, P, L, P]),
     "rpe_resnet50_backward_blocks": (I, [P, I, I, P]),
     "rpe_resnet50_backward_end": (I, [P, I, P]),
+    "rpe_resnet50_backward_frozen": (I, [P, P, L, P]),
     "rpe_resnet50_set_aux_grad": (I, [P, P, L, P, P, P]),
     "rpe_resnet50_profile_kernels": (L, [P, P, L]),
     "rpe_last_kernel_name": (c_char_p, []),

@@ -142,6 +142,16 @@ inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 // the engine's per-symbol profile keys on (defined in igemm.hip)
 extern thread_local char g_last_kernel[96];
 inline void note_kernel(const char* name) { snprintf(g_last_kernel, sizeof(g_last_kernel), "%s", name); }
+// Per-KERNEL spans inside one entry point (the engine's per-symbol profile: rpe_resnet50_profile / bench.py's `roofline`): an entry
+// point that launches several kernels calls prof_split(stream, name of the NEXT kernel) between them.  With a hook installed (thread
+// local; the engine's PROF macro does it while profiling) the span of the kernels launched so far is closed under the name noted so
+// far and a new one starts; without a hook it only notes the name.  Spans then carry the symbols rocprofv3 lists, one each.
+struct ProfHook { void (*split)(void* ctx, hipStream_t s); void* ctx; };
+extern thread_local ProfHook g_prof_hook;
+inline void prof_split(hipStream_t s, const char* next_kernel) {
+    if (g_prof_hook.split) g_prof_hook.split(g_prof_hook.ctx, s);
+    note_kernel(next_kernel);
+}
 
 }  // namespace rpe
 

@@ -408,13 +408,11 @@ static int conv1x1_wgrad_folded_t(const rpe_conv_desc* d, const void* dz, const 
     a.P = (const T*)dz; a.P2 = (const T*)a_in; a.Q = (const T*)a_in; a.D = dp;
     a.slab = (float*)(sc + pl.slab_off); a.slab_bytes = scratch_bytes - pl.slab_off;
     if (int e = launch_tn<T>(a, MODE_DENSE, s)) return e;
+    prof_split(s, "wgrad_fold_combine_kernel");
     const size_t lds = (size_t)(16 * Ci + (Ci < 128 ? Ci : 128) * 64) * 4;
     hipLaunchKernelGGL(wgrad_fold_combine_kernel, dim3(Co / 16, (Ci + 63) / 64), dim3(256), lds, s, dw, dp, w_master, gamma, invstd, mean, c1c2, c1c2 + Co, Co, Ci,
                        pl.ones_row);
     RPE_CHECK_LAUNCH();
-    char name[96];
-    snprintf(name, sizeof(name), "%.60s + wgrad_fold_combine_kernel", g_last_kernel);
-    note_kernel(name);
     return 0;
 }
 

@@ -129,6 +129,8 @@ struct rpe_resnet50 {
     std::vector<Span> spans;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_next = 0;
+    hipEvent_t cur_a = nullptr;   // start event of the span being recorded (PROF / prof_split)
+    int cur_cat = 0;
     // weight-gradient GEMMs run on a second stream, overlapping the data-gradient / BN chain (they only feed Adam)
     hipStream_t side = nullptr;
     bool overlap = true;
@@ -157,15 +159,27 @@ static hipEvent_t next_event(rpe_resnet50* e) {
     return e->ev_pool[e->ev_next++];
 }
 
-// runs `call` and, when profiling, brackets it with events on the launch stream
+// runs `call` and, when profiling, brackets it with events on the launch stream.  An entry point that launches several kernels
+// splits its span per kernel (prof_split, common.h): the hook closes the running span under the symbol noted so far -- the first
+// span carries the call's algorithmic FLOPs / bytes -- and opens the next at the same event.
+static void prof_close(rpe_resnet50* e, hipStream_t s, bool reopen) {
+    hipEvent_t b = next_event(e);
+    if (!e->cur_a || !b) { e->cur_a = nullptr; return; }
+    (void)hipEventRecord(b, s);
+    e->spans.push_back({e->cur_cat, e->cur_a, b, kernel_id(e), e->pending_flops, e->pending_bytes});
+    e->pending_flops = 0; e->pending_bytes = 0;
+    e->cur_a = reopen ? b : nullptr;
+}
+static void prof_hook_split(void* ctx, hipStream_t s) { prof_close((rpe_resnet50*)ctx, s, true); }
 #define PROF(e, cat, stream, call)                                                   \
     do {                                                                             \
-        hipEvent_t pa__ = nullptr, pb__ = nullptr;                                   \
-        if ((e)->profiling) { pa__ = next_event(e); pb__ = next_event(e);            \
-            if (pa__) (void)hipEventRecord(pa__, (hipStream_t)(stream)); }                 \
-        if (int err__ = (call)) return err__;                                        \
-        if ((e)->profiling && pa__ && pb__) { (void)hipEventRecord(pb__, (hipStream_t)(stream)); \
-            (e)->spans.push_back({(cat), pa__, pb__, kernel_id(e), (e)->pending_flops, (e)->pending_bytes}); (e)->pending_flops = 0; (e)->pending_bytes = 0; } \
+        if ((e)->profiling) { (e)->cur_a = next_event(e); (e)->cur_cat = (cat);      \
+            if ((e)->cur_a) (void)hipEventRecord((e)->cur_a, (hipStream_t)(stream)); \
+            rpe::g_prof_hook = {prof_hook_split, (e)}; }                             \
+        const int err__ = (call);                                                    \
+        rpe::g_prof_hook = {nullptr, nullptr};                                       \
+        if (err__) return err__;                                                     \
+        if ((e)->profiling) prof_close((e), (hipStream_t)(stream), false);           \
     } while (0)
 
 static int add_conv(rpe_resnet50* e, const std::string& name, const std::string& bn, int in_h, int in_w, int in_c, int out_c, int k,
@@ -1001,6 +1015,27 @@ extern "C" int rpe_resnet50_set_hook_grad(rpe_resnet50_t* e, int layer, const vo
 extern "C" int rpe_resnet50_set_stem_raw(rpe_resnet50_t* e, int on) {
     if (!e) return rpe_set_error(RPE_ERR_STATE, "resnet50_set_stem_raw: null engine");
     if (e->stem_raw != (on != 0)) { e->stem_raw = on != 0; if (e->pack_state == 2) e->pack_state = 0; }   // the inference copy of conv1's weight changes
+    return 0;
+}
+
+// see include/rpe_hip.h: the replaced fc's weight / bias gradient, nothing else
+extern "C" int rpe_resnet50_backward_frozen(rpe_resnet50_t* e, const float* d_features, long ld_d_features, void* stream) {
+    if (!e || !e->bound) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward_frozen: engine not bound");
+    if (!e->fwd_done) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward_frozen: no training-mode forward to differentiate");
+    const int np = (int)e->pnames.size();
+    if (!d_features || !e->grads[np - 2] || !e->grads[np - 1]) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward_frozen: fc gradient tensors were not bound");
+    hipStream_t s = (hipStream_t)stream;
+    float* dWfc = e->grads[np - 2];
+    if (e->main_slab) {
+        TRY(rpe_linear_wgrad_det(RPE_F32, d_features, (int)ld_d_features, e->pooled, 2048, dWfc, 2048, e->B, e->latent, 2048, 0, e->main_slab, e->main_slab_bytes, stream));
+    } else {
+        HIPTRY(hipMemsetAsync(dWfc, 0, (size_t)e->latent * 2048 * 4, s));
+        TRY(rpe_linear_wgrad(RPE_F32, d_features, (int)ld_d_features, e->pooled, 2048, dWfc, 2048, e->B, e->latent, 2048, stream));
+    }
+    TRY(rpe_colsum(d_features, e->B, e->latent, (int)ld_d_features, e->grads[np - 1], 0, stream));
+    e->aux_dout = nullptr;                                    // (an aux head's gradient towards bn1 has nowhere to go)
+    for (int i = 0; i < 4; ++i) e->hook_grad[i] = nullptr;
+    e->bwd_next = -2;
     return 0;
 }
 

@@ -9,6 +9,7 @@
 namespace rpe {
 
 thread_local char g_last_kernel[96] = "";
+thread_local ProfHook g_prof_hook = {nullptr, nullptr};
 
 template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s);
 

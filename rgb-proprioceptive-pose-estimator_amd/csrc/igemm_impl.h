@@ -1012,9 +1012,10 @@ template <typename T, int MODE> static int launch_nt_split(NTArgs<T>& a, hipStre
     if (S < 2 || !a.slab || a.slab_bytes < nt_split_slab_bytes(a.M, a.N, S) || (MODE == MODE_CONV && a.g.parity))
         return rpe_set_error(RPE_ERR_WORKSPACE, "igemm_nt: split-K launch without a plan or with a slab smaller than planned");
     a.splits = S; a.split_steps = steps;
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "nt_kernel<%s,1,64,4,%d,3,4,0> x%d + nt_split_epilogue_kernel", Elem<T>::kName, MODE, S);
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "nt_kernel<%s,1,64,4,%d,3,4,0>", Elem<T>::kName, MODE);
     hipLaunchKernelGGL((nt_kernel<T, 1, 64, 4, MODE, 3, 4, 0>), dim3((unsigned)tiles, (unsigned)S), dim3(128), 0, s, a);
     RPE_CHECK_LAUNCH();
+    prof_split(s, "nt_split_epilogue_kernel");
     hipLaunchKernelGGL((nt_split_epilogue_kernel<T>), dim3((unsigned)((tiles * 1024 + 255) / 256)), dim3(256), 0, s, (const float*)a.slab, S, a.tiles_m,
                        a.tiles_n, a.M, a.N, a.bias, a.addend, a.ld_add, a.relu, a.C, a.ldc);
     RPE_CHECK_LAUNCH();
@@ -1126,6 +1127,7 @@ template <typename T, int BI, int BJ, int MODE, int KS, int NS> static int launc
     if (a.slab) {
         hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, true, KS, NS, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
         RPE_CHECK_LAUNCH();
+        prof_split(s, "tn_reduce_kernel");
         const long nt = (long)a.tiles_i * a.tiles_j, groups = nt * (BI * BJ / 4);
         hipLaunchKernelGGL((tn_reduce_kernel<BI, BJ>), dim3((unsigned)(groups / 64)), dim3(512), 0, s, a.slab, a.D, a.I, a.J, a.ldd, a.tiles_j,
                            (int)nt, a.splits, a.accumulate);
@@ -1172,6 +1174,7 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
         if (a.slab) {
             hipLaunchKernelGGL((tn_kernel<T, BI, BJ, MODE, false, 1, 2, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
             RPE_CHECK_LAUNCH();
+            prof_split(s, "tn_reduce_kernel");
             const long nt = (long)a.tiles_i * a.tiles_j, groups = nt * (BI * BJ / 4);
             hipLaunchKernelGGL((tn_reduce_kernel<BI, BJ>), dim3((unsigned)(groups / 64)), dim3(512), 0, s, a.slab, a.D, a.I, a.J, a.ldd,
                                a.tiles_j, (int)nt, a.splits, a.accumulate);

@@ -841,15 +841,18 @@ int bn_bwd_launch(const void* dA, const void* a_out, const void* y, const float*
     long rpb = (M + nb - 1) / nb;
     nb = (M + rpb - 1) / rpb;
     if (nb * 2 * C > part_floats) return rpe_set_error(RPE_ERR_WORKSPACE, "bn_bwd: partial-sum workspace too small");
+    note_kernel("bn_bwd_reduce_kernel");
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3((unsigned)nb, slabs), dim3(256), 0, s, (const T*)dA, (const T*)a_out, (const T*)y, mean,
                        invstd, M, C, SW, (int)rpb, part);
     RPE_CHECK_LAUNCH();
     float* c1 = c1c2;
     float* c2 = c1c2 + C;
+    prof_split(s, "reduce_finalize_kernel<BnBwdFin>");
     if (int e = reduce_finalize(part, (int)nb, C, dpart, BnBwdFin{(double)M, dgamma, dbeta, c1, c2}, s)) return e;
     if (!dy) return 0;   // statistics only (rpe_bn_backward_reduce): the apply pass is folded into the consumers
     // no ReLU in front and no dz wanted (projection-shortcut BNs): dz == dA, the streaming dz -> dy kernel does the third pass
-    if (!a_out && !dz_out && ew_pow2(C / CE)) return bn_apply_dz_launch<T>(dA, y, mean, invstd, gamma, c1, c2, dy, M, C, s);
+    if (!a_out && !dz_out && ew_pow2(C / CE)) { prof_split(s, "bn_bwd_apply_dz_kernel"); return bn_apply_dz_launch<T>(dA, y, mean, invstd, gamma, c1, c2, dy, M, C, s); }
+    prof_split(s, "bn_bwd_apply_kernel");
     const long n = M * C / CE;
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, s, (const T*)dA, (const T*)a_out, (const T*)y, mean, invstd, gamma,
                        (const float*)c1, (const float*)c2, (T*)dy, (T*)dz_out, n, C);
@@ -865,7 +868,9 @@ int bn_bwd_from_dz_launch(const void* dz, const void* y, const float* mean, cons
     const int cpr = C / CE;
     float* c1 = c1c2;
     float* c2 = c1c2 + C;
+    note_kernel("reduce_finalize_kernel<BnBwdFin>");
     if (int e = reduce_finalize(stats_part, tiles, C, dpart, BnBwdFin{(double)M, dgamma, dbeta, c1, c2}, s)) return e;
+    prof_split(s, "bn_bwd_apply_dz_kernel");
     return bn_apply_dz_launch<T>(dz, y, mean, invstd, gamma, c1, c2, dy, M, C, s);
 }
 
@@ -881,12 +886,15 @@ int stem_bwd_launch(const void* dpool, const unsigned char* pidx, const StemAux&
     if (nbl < 1) return rpe_set_error(RPE_ERR_WORKSPACE, "stem_bwd: partial-sum workspace too small");
     const int rpb = (int)(((long)B * H + nbl - 1) / nbl);          // consecutive image rows per block
     const int nb = (int)(((long)B * H + rpb - 1) / rpb);
+    note_kernel("stem_bwd_reduce_kernel");
     hipLaunchKernelGGL((stem_bwd_reduce_kernel<T>), dim3(nb), dim3(256), 0, s, (const T*)dpool, pidx, ax, (const T*)y, scale, shift, mean, invstd, B, H, W,
                        Ho, Wo, rpb, part);
     RPE_CHECK_LAUNCH();
     float* c1 = c1c2;
     float* c2 = c1c2 + 64;
+    prof_split(s, "reduce_finalize_kernel<BnBwdFin>");
     if (int e = reduce_finalize(part, nb, 64, dpart, BnBwdFin{(double)B * H * W, dgamma, dbeta, c1, c2}, s)) return e;
+    prof_split(s, "stem_bwd_apply_kernel");
     const int rpa = (B * H + (1 << 20) - 1) >> 20;   // one image row (14 KB of y at 112 pixels) per block, up to 2^20 blocks
     hipLaunchKernelGGL((stem_bwd_apply_kernel<T>), dim3((B * H + rpa - 1) / rpa), dim3(256), 0, s, (const T*)dpool, pidx, ax, (const T*)y, scale, shift, mean, invstd,
                        gamma, (const float*)c1, (const float*)c2, (T*)dy, B, H, W, Ho, Wo, rpa);
@@ -956,7 +964,6 @@ int rpe_bn_apply_res_bn(int dtype, const void* y, const void* res_y, const float
 int rpe_bn_backward(int dtype, const void* dA, const void* a_out, const void* y, const float* mean, const float* invstd,
                     const float* gamma, float* dgamma, float* dbeta, void* dy, void* dz_out, long rows, int C, float* part,
                     long part_floats, float* c1c2, double* dpart, void* stream) {
-    note_kernel("bn_bwd_reduce_kernel + reduce_finalize_kernel<BnBwdFin> + bn_bwd_apply_kernel");
     if (dtype == RPE_F32)
         return bn_bwd_launch<float>(dA, a_out, y, mean, invstd, gamma, dgamma, dbeta, dy, dz_out, rows, C, part, part_floats, c1c2, dpart, (hipStream_t)stream);
     if (dtype == RPE_BF16)
@@ -970,7 +977,6 @@ int rpe_bn_backward(int dtype, const void* dA, const void* a_out, const void* y,
  * its consumers (rpe_bn_bwd_fold_conv1x1 / rpe_conv1x1_wgrad_folded) and whose sums no fused epilogue has produced */
 int rpe_bn_backward_reduce(int dtype, const void* dA, const void* a_out, const void* y, const float* mean, const float* invstd, const float* gamma,
                            float* dgamma, float* dbeta, long rows, int C, float* part, long part_floats, float* c1c2, double* dpart, void* stream) {
-    note_kernel("bn_bwd_reduce_kernel + reduce_finalize_kernel<BnBwdFin>");
     if (dtype == RPE_F32) return bn_bwd_launch<float>(dA, a_out, y, mean, invstd, gamma, dgamma, dbeta, nullptr, nullptr, rows, C, part, part_floats, c1c2, dpart, (hipStream_t)stream);
     if (dtype == RPE_BF16) return bn_bwd_launch<bf16>(dA, a_out, y, mean, invstd, gamma, dgamma, dbeta, nullptr, nullptr, rows, C, part, part_floats, c1c2, dpart, (hipStream_t)stream);
     if (dtype == RPE_F16) return bn_bwd_launch<f16>(dA, a_out, y, mean, invstd, gamma, dgamma, dbeta, nullptr, nullptr, rows, C, part, part_floats, c1c2, dpart, (hipStream_t)stream);
@@ -980,7 +986,6 @@ int rpe_bn_backward_reduce(int dtype, const void* dA, const void* a_out, const v
 int rpe_bn_backward_from_dz(int dtype, const void* dz, const void* y, const float* mean, const float* invstd, const float* gamma,
                             const float* stats_part, int tiles, float* dgamma, float* dbeta, void* dy, long rows, int C, float* c1c2,
                             double* dpart, void* stream) {
-    note_kernel("reduce_finalize_kernel<BnBwdFin> + bn_bwd_apply_dz_kernel");
     if (dtype == RPE_F32)
         return bn_bwd_from_dz_launch<float>(dz, y, mean, invstd, gamma, stats_part, tiles, dgamma, dbeta, dy, rows, C, c1c2, dpart, (hipStream_t)stream);
     if (dtype == RPE_BF16)
@@ -1115,7 +1120,6 @@ int rpe_stem_bwd(int dtype, const void* dpool, const unsigned char* pool_idx, co
                  const float* invstd, const float* gamma, const float* aux_dout, long aux_ld, const float* aux_depth_feat,
                  const unsigned char* aux_idx, const float* aux_w, float* dgamma, float* dbeta, void* dy, int B, int H, int W, float* part,
                  long part_floats, float* c1c2, double* dpart, void* stream) {
-    note_kernel("stem_bwd_reduce_kernel + reduce_finalize_kernel + stem_bwd_apply_kernel");
     if (B <= 0 || H <= 0 || W <= 0 || ((H | W) & 1)) return rpe_set_error(RPE_ERR_SHAPE, "stem_bwd: H and W must be even");
     if (aux_dout && (!aux_idx || !aux_w)) return rpe_set_error(RPE_ERR_SHAPE, "stem_bwd: aux gradient needs its winner indices and weight");
     const StemAux ax{aux_dout, aux_ld, aux_depth_feat, aux_idx, aux_w};

@@ -120,6 +120,12 @@ class ResNet50Trunk(nn.Module):
         plan.rebind_if_needed()
         return plan
 
+    def body_frozen(self):
+        """True when no parameter of the ResNet body takes a gradient (import_resnet froze it: feature_extract and use_pretrained):
+        the backward then computes the replaced fc's gradient only."""
+        fc = {id(self.fc.weight), id(self.fc.bias)}
+        return not any(p.requires_grad for p in self.parameters() if id(p) not in fc)
+
     def weights_changed(self):
         """Call after an optimizer step or load_state_dict: every plan's cached weight copies (compute-dtype copies for
         training, BN-folded copies for inference) are stale.  Training forwards call it themselves."""
@@ -294,6 +300,13 @@ class _Plan:
         """stage_done(name): optional callback fired when the gradients of a stage ("fc", "layer4" .. "layer1", "stem") are
         complete in stream order -- the data-parallel path starts their all-reduce there, under the rest of the backward."""
         s = ops._stream()
+        if self.trunk.body_frozen():
+            # feature_extract and use_pretrained (util/model_utils.py:110-113,137 of the reference): nothing flows into the body
+            lib.rpe_resnet50_backward_frozen(self.handle, ops._p(d_features), d_features.stride(0), s)
+            if stage_done is not None:
+                for name in ("fc", "layer4", "layer3", "layer2", "layer1", "stem"):
+                    stage_done(name)
+            return
         if stage_done is None:
             lib.rpe_resnet50_backward(self.handle, ops._p(d_features), d_features.stride(0), int(use_d_early), s)
             return

@@ -182,6 +182,14 @@ class PoseModelBase(nn.Module):
         if self._arena is None or not self._arena.is_current():
             self._arena = ParamArena(self)
         self._arena.loss_scaler = self.loss_scaler   # FusedAdam unscales / skips through it (amp.py)
+        if self.loss_scaler is not None:   # a scaler state restored by FusedAdam.load_state_dict before this model had an arena
+            pend = None
+            for p in self.parameters():
+                if getattr(p, "_rpe_pending_amp", None) is not None:
+                    pend = p._rpe_pending_amp
+                    p._rpe_pending_amp = None
+            if pend is not None:
+                self.loss_scaler.load_state_dict(pend)
         if self.aux_nets is not None and (self._aux_ops is None or any(op.conv_w.device != device for op in self._aux_ops)):
             self._aux_ops = []
             for i, layer in enumerate(self._hooks):

@@ -105,6 +105,21 @@ class FusedAdam(torch.optim.Optimizer):
         self._v = None if sd["v"] is None else sd["v"].clone()
         self._arena = None   # re-attached (and the moments moved to its device) at the next step
         self._dev_state = sd["dev_state"].clone() if sd.get("dev_state") is not None else None
-        self._amp_restore = sd.get("amp")   # handed to the model's scaler when the arena is attached
+        # fp16: the loss scaler must hold the checkpointed scale BEFORE the first backward after the resume multiplies the output
+        # gradients by it (round 2 handed it over inside the first step(), i.e. after that backward had used a fresh 2^12: the first
+        # step's gradients were off by the ratio of the two scales and went into Adam's moments).  The scaler object belongs to the
+        # model: load it now if the arena exists, else leave it on the parameters for the model's _materialize to install.
+        amp_sd = sd.get("amp")
+        self._amp_restore = None
+        if amp_sd is not None:
+            params = [p for g in self.param_groups for p in g["params"]]
+            arena = arena_of(params)
+            scaler = getattr(arena, "loss_scaler", None) if arena is not None else None
+            if scaler is not None:
+                scaler.load_state_dict(amp_sd)
+            else:
+                self._amp_restore = amp_sd
+                for p in params:
+                    p._rpe_pending_amp = amp_sd
         for g, sg in zip(self.param_groups, sd.get("param_groups", [])):
             g.update({k: v for k, v in sg.items() if k != "params"})

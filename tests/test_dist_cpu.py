@@ -1,5 +1,10 @@
 """Multi-process (gloo, world_size 2) checks of the data-parallel path on CPU: episode sharding, the bucketed SUM
-all-reduce over a flat gradient buffer, and the 'SUM, not AVG' property of a summed loss."""
+all-reduce over a flat gradient buffer, and the 'SUM, not AVG' property of a summed loss.
+
+What runs here is dist.py (GradSync, shard_bounds, broadcast_parameters) around a STAND-IN regressor with the path's loss structure:
+the pose models themselves have no CPU path (the HIP extension is the product and refuses CPU tensors), so the model-level
+data-parallel checks live in tests/test_gpu_dist.py (two gloo ranks sharing one GPU: staged == one-shot reduction; RCCL with one
+rank) and, for the staged joins' cost on one GPU, `bench.py --force-dist`."""
 import os
 import socket
 

@@ -395,3 +395,57 @@ def test_nan_loss_value_keeps_gradients_finite_like_the_reference(dtype, golden_
         for k in gold.files:   # head parameters one Adam step later (trunk tensors: gradient signs near zero are rounding noise)
             if k.startswith("final::fc") or k.startswith("final::aux_nets"):
                 np.testing.assert_allclose(msd[k[7:]].cpu().numpy(), gold[k], rtol=0, atol=2.5e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("dtype,bar", [(torch.float32, 1e-4), (torch.bfloat16, 5e-2)], ids=["f32", "bf16"])
+def test_frozen_trunk_matches_reference_and_skips_the_body_backward(dtype, bar, golden_dir):
+    """feature_extract=True, use_pretrained=True -- the constructors' defaults and the setting of every published job
+    (scripts/train_no.sbatch:83, train_tdo.sbatch:83, train_tdo_v2.sbatch:84): util/model_utils.py:110-113,137 freezes the ResNet
+    body, BatchNorm stays in train mode.  Against the reference's own run (model_no_frozen.npz): the same parameters are frozen,
+    outputs / loss agree, the frozen ones have grad None, the trainable ones the reference's gradients, BN running statistics
+    move; and the engine runs the fc-only backward (no data-gradient / weight-gradient launch for the body)."""
+    import warnings
+    from rgb_proprioceptive_pose_estimator_amd import ops
+    gold = np.load(os.path.join(golden_dir, "model_no_frozen.npz"))
+    cfg, lead, wseed, dseed = CASES["no"]
+    sd = po.make_state("no", cfg, wseed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")            # (no local ImageNet checkpoint: the seeded values are loaded below)
+        model = M.NaiveObjectStateEstimator("cube", list(cfg["hidden"]), 50, cfg["latent_dim"], True, (9,), False, True, False, compute_dtype=dtype)
+    load_values(model, "no", sd)
+    assert [n for n, p in model.named_parameters() if not p.requires_grad] == [str(k) for k in gold["frozen"]]
+    assert [n for n, p in model.named_parameters() if p.requires_grad] == [str(k) for k in gold["trainable"]]
+    model.cuda().train()
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    crit = M.PoseDistanceLoss(distance_metric="combined", scale_factor=1.0, alpha=0.5, mode="pose")
+    b = to_dev(po.synth_batch(lead, dseed + 1))
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    out = model(b["img"], None, b["x0bar"])
+    loss = crit(out, b["obj"])
+    opt.zero_grad()
+    loss.backward()
+    assert model.trunk.body_frozen()
+    assert rel(out, gold["out0_s1"]) < bar
+    np.testing.assert_allclose(loss.item(), gold["loss_s1"], rtol=bar)
+    named = dict(model.named_parameters())
+    for k in gold["frozen"]:
+        assert named[str(k)].grad is None, k
+    for name, dig in zip(gold["grad_keys_s1"], gold["grad_digest_s1"]):
+        name = str(name)
+        g = named[name].grad
+        assert g is not None and torch.isfinite(g).all(), name
+        want = torch.from_numpy(gold["grad::" + name] if "grad::" + name in gold.files else gold["gsample::" + name])
+        got = g.detach().float().cpu().flatten()
+        got = got if "grad::" + name in gold.files else got[::997][:4096]
+        tol = 2e-3 if dtype == torch.float32 else 0.25
+        assert ((got - want).norm() / want.norm().clamp_min(1e-12)).item() < tol, name
+    opt.step()
+    torch.cuda.synchronize()
+    after = model.state_dict()
+    for k in gold["frozen"]:                         # frozen parameters do not move
+        assert torch.equal(after[str(k)], before[str(k)]), k
+    assert not torch.equal(after["feature_net.module.fc.weight"], before["feature_net.module.fc.weight"])
+    if dtype == torch.float32:
+        for k in gold.files:                         # BatchNorm ran in train mode: running statistics as the reference's
+            if k.startswith("final::"):
+                assert rel(after[k[7:]], gold[k]) < 1e-4, k

@@ -319,7 +319,10 @@ def test_config_sized_sequence_models_match_reference(kind, dtype, golden_dir):
     named = dict(model.named_parameters())
     scale = 1.0 if model.loss_scaler is None else model.loss_scaler.get_scale()
     gk = [str(k) for k in gold["grad_keys_s1"]]
-    assert sorted(gk) == sorted(n for n, p in named.items() if p.grad is not None)
+    have = {n for n, p in named.items() if p.grad is not None}
+    assert set(gk) <= have
+    for n in have - set(gk):   # the reference leaves .grad None where nothing flows (the unused depth head); the arena publishes zeros
+        assert float(named[n].grad.abs().max()) == 0.0, n
     # head layers see 16-bit trunk features on the 16-bit paths: their gradients carry that noise (~ the output tolerance x a few)
     head_bar = {torch.float32: 2e-3, torch.bfloat16: 0.25, torch.float16: 0.06}[dtype]
     for name, dig in zip(gk, gold["grad_digest_s1"]):
