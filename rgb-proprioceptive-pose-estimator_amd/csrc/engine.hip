@@ -761,15 +761,21 @@ static int wgrad_on(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, hi
     return 0;
 }
 
+// work for the second stream whose inputs are final at this point of the caller's stream: issued there behind an event (without a
+// second stream it runs in place).  Measured and rejected in round 3 (profiles/r03_ab_wgrad_hold.txt): HOLDING the weight gradients of
+// the deep, matrix-core-bound blocks back until the data-gradient chain reaches the HBM-bound layers 1-2 (one event for all of them)
+// -- 20.4-21.5 ms/step for five hold / flush points against 20.05: a weight gradient issued right behind its dy is the best placement.
+template <typename F> static int to_side(rpe_resnet50* e, void* stream, F work) {
+    if (!(e->overlap && e->side)) return work((hipStream_t)stream);
+    hipEvent_t ready = sync_event(e);
+    if (!ready) return event_error(e);
+    HIPTRY(hipEventRecord(ready, (hipStream_t)stream));
+    HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
+    return work(e->side);
+}
 static int wgrad(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, void* stream) {
-    if (e->overlap && e->side) {
-        hipEvent_t ready = sync_event(e);
-        if (!ready) return event_error(e);
-        HIPTRY(hipEventRecord(ready, (hipStream_t)stream));
-        HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
-        return wgrad_on(e, c, x, dy, e->side);
-    }
-    return wgrad_on(e, c, x, dy, (hipStream_t)stream);
+    ConvL* cp = &c;
+    return to_side(e, stream, [e, cp, x, dy](hipStream_t run) { return wgrad_on(e, *cp, x, dy, run); });
 }
 // Folded form of (BN backward of c.bn -> weight gradient + data gradient of the 1x1 conv c), entered with dz = gradient wrt the BN
 // output and this BN's partial sums in stats_part (left by the data gradient that produced dz):
@@ -803,15 +809,7 @@ static int conv1x1_backward_folded(rpe_resnet50* e, ConvL& c, const void* dz, Co
     }
     return 0;
     };
-    if (e->overlap && e->side) {
-        hipEvent_t ready = sync_event(e);
-        if (!ready) return event_error(e);
-        HIPTRY(hipEventRecord(ready, (hipStream_t)stream));
-        HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
-        TRY(side_part(e->side));
-    } else {
-        TRY(side_part((hipStream_t)stream));
-    }
+    TRY(to_side(e, stream, side_part));
     e->pending_bytes = 0;
     PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_bwd_fold_conv1x1(e->dtype, c.d.out_c, c.d.in_c, fwd_weight(e, c), c.wd, e->params[c.p_g], c.invstd, c.mean, c.c1c2,
                                                               e->w_kcat, e->fold_bias, e->fold_scratch, e->fold_scratch_bytes, stream));
@@ -931,15 +929,7 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
                                                                                   e->grads[c.p_w], e->wfold_scratch, e->wfold_scratch_bytes, run));
                         return 0;
                     };
-                    if (e->overlap && e->side) {
-                        hipEvent_t ready = sync_event(e);
-                        if (!ready) return event_error(e);
-                        HIPTRY(hipEventRecord(ready, (hipStream_t)stream));
-                        HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
-                        TRY(side_part(e->side));
-                    } else {
-                        TRY(side_part((hipStream_t)stream));
-                    }
+                    TRY(to_side(e, stream, side_part));
                 }
                 e->pending_bytes = 0;
                 PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_bwd_fold_conv1x1(e->dtype, cd.d.out_c, cd.d.in_c, fwd_weight(e, cd), cd.wd, e->params[cd.p_g], cd.invstd, cd.mean,
