@@ -107,6 +107,21 @@ int rpe_bn_bwd_fold_conv1x1(int dtype, int out_c, int in_c, const void* w_fwd, c
                             const float* mean, const float* c1c2, void* w_kcat, float* bias, void* scratch, long scratch_bytes, void* stream);
 int rpe_conv1x1_dgrad_kcat(const rpe_conv_desc* d, int dtype, const void* dz, const void* a_in, const void* w_kcat, const float* bias, void* dx,
                            const rpe_bn_bwd_epilogue* bn, void* stream);
+/* The same fold for the conv in FRONT of a narrow BatchNorm -- a Bottleneck's conv1 (x [M][in_c] -> y [M][out_c], z = bn1(y)):
+ *   dx = [dz | y] [A o W ; C' o W] + 1 b^T   (y is the second K-concatenated operand itself: K = 2 out_c, no Gram matrix),
+ *   dW[k][n] = A_k ((dz^T x)[k][n] - c1_k s1[n]) + C'_k ((y^T x)[k][n] - mean_k s1[n]),  s1 = colsum(x)   (one row-concatenated launch),
+ * so neither gradient reads a materialised dy and bn1's streaming dz, y -> dy pass is gone (replaces the BatchNorm2d backward + conv1
+ * backward of a torchvision Bottleneck as torch autograd runs them: util/model_utils.py:136, models/naive.py:316).
+ * rpe_bn_bwd_fold_y_conv1x1: w_kcat [in_c][2 out_c] (compute dtype), bias [in_c] from the data-gradient copy of the weight [in_c][out_c]
+ * and the BN coefficients (rpe_bn_backward_coeffs); rpe_conv1x1_dgrad_kcat_y: the data gradient (+ bias, + addend, + the fused BN-backward
+ * epilogue of the layer behind, as rpe_conv2d_dgrad_bn); rpe_conv1x1_wgrad_folded_y: the weight gradient into dw [out_c][in_c] fp32. */
+int rpe_bn_bwd_fold_y_conv1x1(int dtype, int out_c, int in_c, const void* w_dgrad, const float* gamma, const float* invstd, const float* mean,
+                              const float* c1c2, void* w_kcat, float* bias, void* stream);
+int rpe_conv1x1_dgrad_kcat_y(const rpe_conv_desc* d, int dtype, const void* dz, const void* y, const void* w_kcat, const float* bias, void* dx,
+                             const void* addend, const rpe_bn_bwd_epilogue* bn, void* stream);
+long rpe_conv1x1_wgrad_folded_y_scratch_bytes(const rpe_conv_desc* d, int dtype);
+int rpe_conv1x1_wgrad_folded_y(const rpe_conv_desc* d, int dtype, const void* dz, const void* y, const void* x, const float* gamma, const float* invstd,
+                               const float* mean, const float* c1c2, float* dw, void* scratch, long scratch_bytes, void* stream);
 /* The weight-gradient side of the same fold: dw[out_c][in_c] (fp32, OVERWRITTEN) = A o (dz^T a_in) + B' colsum(a_in)^T + C' o (W S),
  * S = a_in^T a_in -- reads dz and a_in only, no dy.  w_master: the fp32 weight [out_c][in_c].  Deterministic (slab sums). */
 long rpe_conv1x1_wgrad_folded_scratch_bytes(const rpe_conv_desc* d, int dtype);

@@ -56,6 +56,10 @@ _SPEC = {
     "rpe_bn_bwd_fold_scratch_bytes": (L, [I, I, I]),
     "rpe_bn_bwd_fold_conv1x1": (I, [I, I, I, P, P, P, P, P, P, P, P, P, L, P]),
     "rpe_conv1x1_dgrad_kcat": (I, [PD, I, P, P, P, P, P, POINTER(BnBwdEpilogue), P]),
+    "rpe_bn_bwd_fold_y_conv1x1": (I, [I, I, I, P, P, P, P, P, P, P, P]),
+    "rpe_conv1x1_dgrad_kcat_y": (I, [PD, I, P, P, P, P, P, P, POINTER(BnBwdEpilogue), P]),
+    "rpe_conv1x1_wgrad_folded_y_scratch_bytes": (L, [PD, I]),
+    "rpe_conv1x1_wgrad_folded_y": (I, [PD, I, P, P, P, P, P, P, P, P, P, L, P]),
     "rpe_conv1x1_wgrad_folded_scratch_bytes": (L, [PD, I]),
     "rpe_conv1x1_wgrad_folded": (I, [PD, I, P, P, P, P, P, P, P, P, P, L, P]),
     "rpe_bn_backward_coeffs": (I, [P, I, I, L, P, P, P, P, P]),

@@ -437,6 +437,129 @@ static int conv1x1_dgrad_kcat_t(const rpe_conv_desc* d, const void* dz, const vo
     return launch_nt<T>(a, MODE_DENSE, s);
 }
 
+// ---- the same fold for the conv in FRONT of a narrow BatchNorm (a bottleneck's conv1: x [M][Ci = 4p] -> y [M][Co = p]) ------------
+//   dy = A o dz + B' + C' o y  (per channel k of y)   =>   dx = dy W = [dz | y] [A o W ; C' o W] + 1 b^T,  b = W^T B'
+// y itself is the narrow tensor here, so it is the second K-concatenated operand directly (K: p -> 2p, no Gram matrix): the streaming
+// dz, y -> dy pass (3p per block on the data-gradient chain) disappears.  wd = [Ci][Co], the data-gradient copy of the weight.
+// one wave per row n of wd: wk[n][k] = A_k wd[n][k], wk[n][Co + k] = C'_k wd[n][k], bias[n] = sum_k B'_k wd[n][k]
+template <typename T>
+__global__ __launch_bounds__(256) void bn_fold_y_kernel(const T* __restrict__ wd, const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                       const float* __restrict__ mean, const float* __restrict__ c1, const float* __restrict__ c2,
+                                                       T* __restrict__ wk, float* __restrict__ bias, int Co, int Ci) {
+    constexpr int CE = Elem<T>::kChunk;
+    extern __shared__ float coef[];   // A | C' | B'  (Co each)
+    for (int k = threadIdx.x; k < Co; k += 256) {
+        const float a = gamma[k] * invstd[k];
+        const float cp = -a * invstd[k] * c2[k];
+        coef[k] = a; coef[Co + k] = cp; coef[2 * Co + k] = -a * c1[k] - cp * mean[k];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Ci) return;
+    float acc = 0.f;
+    for (int k = lane * CE; k < Co; k += 64 * CE) {
+        float w[CE], o1[CE], o2[CE];
+        chunk_to_f<T>(*(const u32x4*)(wd + (long)row * Co + k), w);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { o1[e] = coef[k + e] * w[e]; o2[e] = coef[Co + k + e] * w[e]; acc = fmaf(coef[2 * Co + k + e], w[e], acc); }
+        *(u32x4*)(wk + (long)row * (2 * Co) + k) = f_to_chunk<T>(o1);
+        *(u32x4*)(wk + (long)row * (2 * Co) + Co + k) = f_to_chunk<T>(o2);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) bias[row] = acc;
+}
+template <typename T>
+static int bn_fold_y_t(int Co, int Ci, const void* wd, const float* gamma, const float* invstd, const float* mean, const float* c1c2, void* w_kcat,
+                       float* bias, hipStream_t s) {
+    hipLaunchKernelGGL((bn_fold_y_kernel<T>), dim3((Ci + 3) / 4), dim3(256), (size_t)Co * 12, s, (const T*)wd, gamma, invstd, mean, c1c2, c1c2 + Co, (T*)w_kcat, bias,
+                       Co, Ci);
+    RPE_CHECK_LAUNCH();
+    note_kernel("bn_fold_y_kernel");
+    return 0;
+}
+
+// data gradient from A = [dz (M x Co) | y (M x Co)] and w_kcat [Ci][2 Co] (bn_fold_y_t), + bias, + the shortcut gradient, with the
+// fused BN-backward epilogue of the layer behind (the previous block's bn3: ReLU mask bits, partial sums)
+template <typename T>
+static int conv1x1_dgrad_kcat_y_t(const rpe_conv_desc* d, const void* dz, const void* y, const void* w_kcat, const float* bias, void* dx, const void* addend,
+                                  const rpe_bn_bwd_epilogue* bn, hipStream_t s) {
+    NTArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.A = (const T*)dz; a.A2 = (const T*)y; a.Bw = (const T*)w_kcat; a.C = (T*)dx;
+    a.M = d->batch * d->in_h * d->in_w; a.N = d->in_c; a.K = 2 * d->out_c; a.K1 = d->out_c;
+    a.lda = d->out_c; a.lda2 = d->out_c; a.ldb = a.K; a.ldc = d->in_c;
+    a.bias = bias;
+    a.addend = (const T*)addend; a.ld_add = d->in_c;
+    a.role = 1;
+    if (bn) {
+        if (!bn->y || !bn->mean || !bn->invstd || !bn->stats_part) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_dgrad_kcat_y: y, mean, invstd, stats_part are required");
+        a.bn_mode = bn->a_mask ? 4 : bn->a_out ? 1 : (bn->scale && bn->shift ? 2 : 3);
+        a.bn_y = (const T*)bn->y; a.bn_a = (const T*)bn->a_out; a.bn_mask = bn->a_mask;
+        a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bn_scale = bn->scale; a.bn_shift = bn->shift;
+        a.stats_part = bn->stats_part;
+    }
+    return launch_nt<T>(a, MODE_DENSE, s);
+}
+
+// weight gradient of the same conv from dz, y and x (no dy):  dW[k][n] = A_k (Dz[k][n] - c1_k s1[n]) + C'_k (Dy[k][n] - mean_k s1[n])
+// with Dz = dz^T x, Dy = y^T x, s1 = colsum(x): ONE row-concatenated TN launch (P = dz | P2 = y | all-ones tile) + an element-wise combine.
+// dp rows: [0, Co) Dz | [I1, I1 + Co) Dy | row `ones_row` s1, I1 = roundup(Co, 128).
+__global__ __launch_bounds__(256) void wgrad_fold_y_combine_kernel(float* __restrict__ dw, const float* __restrict__ dp, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ invstd, const float* __restrict__ mean,
+                                                                  const float* __restrict__ c1, const float* __restrict__ c2, int Co, int Ci, int I1, int ones_row) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;      // one float4 of dw [Co][Ci]
+    const long total = (long)Co * Ci / 4;
+    if (idx >= total) return;
+    const int k = (int)(idx / (Ci / 4)), n = (int)(idx - (long)k * (Ci / 4)) * 4;
+    const float a = gamma[k] * invstd[k];
+    const float cp = -a * invstd[k] * c2[k];
+    const f32x4 dzv = *(const f32x4*)(dp + (long)k * Ci + n), dyv = *(const f32x4*)(dp + (long)(I1 + k) * Ci + n), s1 = *(const f32x4*)(dp + (long)ones_row * Ci + n);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = a * (dzv[j] - c1[k] * s1[j]) + cp * (dyv[j] - mean[k] * s1[j]);
+    *(f32x4*)(dw + (long)k * Ci + n) = o;
+}
+struct WFoldYPlan { long slab_off, total; int I1, ones_row; };
+template <typename T> static void wfold_y_args(TNArgs<T>& a, long M, int Co, int Ci, const WFoldYPlan& pl) {
+    memset(&a, 0, sizeof(a));
+    a.M = (int)M; a.I = pl.ones_row + 1; a.J = Ci; a.ldp = Co; a.ldq = Ci; a.ldd = Ci;
+    a.ldp2 = Co; a.I1 = pl.I1; a.I2 = Co; a.ones_i0 = pl.ones_row; a.p_cols = Co;
+}
+template <typename T> static int wfold_y_plan(long M, int Co, int Ci, WFoldYPlan& pl) {
+    pl.I1 = (Co + 127) / 128 * 128;
+    pl.ones_row = 2 * pl.I1;
+    TNArgs<T> a;
+    wfold_y_args<T>(a, M, Co, Ci, pl);
+    a.P2 = (const T*)16;   // (placeholder: the query plans the concatenated problem, nothing is dereferenced)
+    long slab = 0;
+    if (int e = launch_tn<T>(a, MODE_DENSE, nullptr, &slab)) return e;
+    pl.slab_off = ((long)(pl.ones_row + 1) * Ci * 4 + 255) / 256 * 256;
+    pl.total = pl.slab_off + slab;
+    return 0;
+}
+template <typename T>
+static int conv1x1_wgrad_folded_y_t(const rpe_conv_desc* d, const void* dz, const void* y, const void* x, const float* gamma, const float* invstd,
+                                    const float* mean, const float* c1c2, float* dw, void* scratch, long scratch_bytes, long* query, hipStream_t s) {
+    const long M = (long)d->batch * d->in_h * d->in_w;
+    const int Co = d->out_c, Ci = d->in_c;
+    if ((Co % 64) || (Ci % 64)) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_wgrad_folded_y: out_c and in_c must be multiples of 64");
+    WFoldYPlan pl;
+    if (int e = wfold_y_plan<T>(M, Co, Ci, pl)) return e;
+    if (query) { *query = pl.total; return 0; }
+    if (!scratch || scratch_bytes < pl.total) return rpe_set_error(RPE_ERR_WORKSPACE, "conv1x1_wgrad_folded_y: scratch smaller than rpe_conv1x1_wgrad_folded_y_scratch_bytes()");
+    float* dp = (float*)scratch;
+    TNArgs<T> a;
+    wfold_y_args<T>(a, M, Co, Ci, pl);
+    a.P = (const T*)dz; a.P2 = (const T*)y; a.Q = (const T*)x; a.D = dp;
+    a.slab = (float*)((char*)scratch + pl.slab_off); a.slab_bytes = scratch_bytes - pl.slab_off;
+    if (int e = launch_tn<T>(a, MODE_DENSE, s)) return e;
+    prof_split(s, "wgrad_fold_y_combine_kernel");
+    hipLaunchKernelGGL(wgrad_fold_y_combine_kernel, dim3((unsigned)(((long)Co * Ci / 4 + 255) / 256)), dim3(256), 0, s, dw, dp, gamma, invstd, mean, c1c2, c1c2 + Co, Co, Ci,
+                       pl.I1, pl.ones_row);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
 static void stem_gather(Gather& g, int H, int W) {
     const int Ho = out_dim(H, 7, 2, 3), Wo = out_dim(W, 7, 2, 3);
     g.H = H; g.W = W; g.C = 4; g.Ho = Ho; g.Wo = Wo; g.R = 8; g.S = 8;
@@ -674,6 +797,40 @@ int rpe_conv1x1_wgrad_folded(const rpe_conv_desc* d, int dtype, const void* dz, 
     return wfold_dispatch(d, dtype, dz, a_in, w_master, gamma, invstd, mean, c1c2, dw, scratch, scratch_bytes, nullptr, (hipStream_t)stream);
 }
 
+
+int rpe_bn_bwd_fold_y_conv1x1(int dtype, int out_c, int in_c, const void* w_dgrad, const float* gamma, const float* invstd, const float* mean,
+                              const float* c1c2, void* w_kcat, float* bias, void* stream) {
+    if (out_c <= 0 || in_c <= 0 || (out_c % 64) || out_c > 4096 || !w_dgrad || !gamma || !invstd || !mean || !c1c2 || !w_kcat || !bias)
+        return rpe_set_error(RPE_ERR_SHAPE, "bn_bwd_fold_y_conv1x1: bad arguments (out_c % 64 == 0)");
+    DISPATCH(dtype, bn_fold_y_t, out_c, in_c, w_dgrad, gamma, invstd, mean, c1c2, w_kcat, bias, (hipStream_t)stream);
+}
+
+int rpe_conv1x1_dgrad_kcat_y(const rpe_conv_desc* d, int dtype, const void* dz, const void* y, const void* w_kcat, const float* bias, void* dx,
+                             const void* addend, const rpe_bn_bwd_epilogue* bn, void* stream) {
+    if (int e = check_desc(d)) return e;
+    if (d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_dgrad_kcat_y: 1x1 / stride 1 / no padding only");
+    if (!dz || !y || !w_kcat || !bias || !dx || (d->out_c % 64)) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_dgrad_kcat_y: bad arguments (out_c % 64 == 0)");
+    DISPATCH(dtype, conv1x1_dgrad_kcat_y_t, d, dz, y, w_kcat, bias, dx, addend, bn, (hipStream_t)stream);
+}
+
+static int wfold_y_dispatch(const rpe_conv_desc* d, int dtype, const void* dz, const void* y, const void* x, const float* gamma, const float* invstd,
+                            const float* mean, const float* c1c2, float* dw, void* scratch, long scratch_bytes, long* query, hipStream_t s) {
+    DISPATCH(dtype, conv1x1_wgrad_folded_y_t, d, dz, y, x, gamma, invstd, mean, c1c2, dw, scratch, scratch_bytes, query, s);
+}
+
+long rpe_conv1x1_wgrad_folded_y_scratch_bytes(const rpe_conv_desc* d, int dtype) {
+    long bytes = 0;
+    if (check_desc(d) || wfold_y_dispatch(d, dtype, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &bytes, nullptr)) return -1;
+    return bytes;
+}
+
+int rpe_conv1x1_wgrad_folded_y(const rpe_conv_desc* d, int dtype, const void* dz, const void* y, const void* x, const float* gamma, const float* invstd,
+                               const float* mean, const float* c1c2, float* dw, void* scratch, long scratch_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    if (d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_wgrad_folded_y: 1x1 / stride 1 / no padding only");
+    if (!dz || !y || !x || !gamma || !invstd || !mean || !c1c2 || !dw) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_wgrad_folded_y: null argument");
+    return wfold_y_dispatch(d, dtype, dz, y, x, gamma, invstd, mean, c1c2, dw, scratch, scratch_bytes, nullptr, (hipStream_t)stream);
+}
 
 int rpe_conv1x1_dgrad_kcat(const rpe_conv_desc* d, int dtype, const void* dz, const void* a_in, const void* w_kcat, const float* bias, void* dx,
                            const rpe_bn_bwd_epilogue* bn, void* stream) {

@@ -95,6 +95,8 @@ struct rpe_resnet50 {
     long fold_scratch_bytes = 0;
     void* wfold_scratch = nullptr;   // side-stream scratch of the folded weight gradient (S, colsum, W S, slabs)
     long wfold_scratch_bytes = 0;
+    bool fold1 = true;       // bn1's backward folded into conv1's data / weight gradient (y-form: rpe_bn_bwd_fold_y_conv1x1)
+    int fold1_max = 128;     // widest bn1 (planes) folded: layers 1-2, whose conv1 gradients are HBM-bound (RPE_BN1_FOLD_MAX)
     bool fold_w = true;
     int fold_w_max = 256;   // widest conv3 input the folded weight gradient takes (RPE_WGRAD_FOLD_MAX; measured 128: 21.92, 256: 21.77, 512: 21.80 ms/step)
     void* main_slab = nullptr;   // the same for the two weight gradients that run on the caller's stream (stem conv, fc)
@@ -306,7 +308,12 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
             if (sb > e->fold_scratch_bytes) e->fold_scratch_bytes = sb;
             const long w = (long)d.in_c * (d.out_c + d.in_c) * (long)es;
             if (w > wk) wk = w;
+            const rpe_conv_desc& d1 = e->convs[b.c1].d;      // y-form fold of conv1: w_kcat [in_c][2 out_c]
+            const long w1 = (long)d1.in_c * 2 * d1.out_c * (long)es;
+            if (w1 > wk) wk = w1;
         }
+        e->fold1 = getenv("RPE_NO_BN1_FOLD") == nullptr;
+        if (getenv("RPE_BN1_FOLD_MAX")) e->fold1_max = atoi(getenv("RPE_BN1_FOLD_MAX"));
         e->fold_w = getenv("RPE_NO_WGRAD_FOLD") == nullptr && getenv("RPE_TN_REG") == nullptr;   // (the row-concatenated operand is an LDS-DMA path feature)
         if (e->fold_w) {
             if (getenv("RPE_WGRAD_FOLD_MAX")) e->fold_w_max = atoi(getenv("RPE_WGRAD_FOLD_MAX"));
@@ -315,10 +322,16 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
                 const long sb = rpe_conv1x1_wgrad_folded_scratch_bytes(&e->convs[b.c3].d, dtype);
                 if (sb > e->wfold_scratch_bytes) e->wfold_scratch_bytes = sb;
             }
+            if (e->fold1)
+                for (auto& b : e->blocks) {
+                    if (e->convs[b.c1].d.out_c > e->fold1_max) continue;
+                    const long sb = rpe_conv1x1_wgrad_folded_y_scratch_bytes(&e->convs[b.c1].d, dtype);
+                    if (sb > e->wfold_scratch_bytes) e->wfold_scratch_bytes = sb;
+                }
             if (e->wfold_scratch_bytes > 0) want(e, &e->wfold_scratch, e->wfold_scratch_bytes);
         }
         want(e, &e->w_kcat, wk);
-        want(e, (void**)&e->fold_bias, 512L * 4);
+        want(e, (void**)&e->fold_bias, 2048L * 4);
         want(e, &e->fold_scratch, e->fold_scratch_bytes);
     }
     if (!getenv("RPE_WGRAD_ATOMIC")) {
@@ -906,8 +919,28 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
         TRY(bn_from_dz(e, c2, c2.dy, c2.dy, stream));
         TRY(wgrad(e, c2, c1.a, c2.dy, stream));
         TRY(dgrad_fused(e, c2, c2.dy, c1.dy, nullptr, &c1, 2, stream));   // dz1
-        TRY(bn_from_dz(e, c1, c1.dy, c1.dy, stream));
-        TRY(wgrad(e, c1, x_in, c1.dy, stream));
+        // bn1 + conv1.  Folded (layers 1-2): coefficients only on this stream; the weight gradient (side stream) and the data gradient
+        // (below, behind the projection shortcut's backward, which shares the fold scratch) both work from dz1 and y1 -- no dy1, no
+        // streaming dz, y -> dy pass.  Otherwise: that pass, then both gradients from dy1.
+        const bool fold_c1 = e->fold && e->fold1 && e->fold_w && e->wfold_scratch && e->train_mode && c1.d.out_c <= e->fold1_max && (c1.d.out_c % 64) == 0 &&
+                             (c1.d.in_c % 64) == 0;
+        if (fold_c1) {
+            e->pending_bytes = 0;
+            PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_backward_coeffs(e->stats_part, e->fused_tiles, c1.d.out_c, c1.rows, e->grads[c1.p_g], e->grads[c1.p_b], c1.c1c2,
+                                                                    e->dpart, stream));
+            ConvL* cp = &c1;
+            TRY(to_side(e, stream, [e, cp, x_in](hipStream_t run) -> int {
+                ConvL& c = *cp;
+                e->pending_flops = conv_flops(c) * 2.0;
+                e->pending_bytes = 2.0 * conv_out_bytes(e, c) + conv_in_bytes(e, c);   // dz, y, x
+                PROF(e, RPE_PROF_CONV_WGRAD, run, rpe_conv1x1_wgrad_folded_y(&c.d, e->dtype, c.dy, c.y, x_in, e->params[c.p_g], c.invstd, c.mean, c.c1c2, e->grads[c.p_w],
+                                                                            e->wfold_scratch, e->wfold_scratch_bytes, run));
+                return 0;
+            }));
+        } else {
+            TRY(bn_from_dz(e, c1, c1.dy, c1.dy, stream));
+            TRY(wgrad(e, c1, x_in, c1.dy, stream));
+        }
         const void* shortcut = gA;
         if (b.cd >= 0) {
             ConvL& cd = e->convs[b.cd];
@@ -943,8 +976,29 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
                 PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&cd.d, e->dtype, cd.dy, cd.wd, e->G[0], hook_in, stream));
             }
         }
+        static const bool use_mask = getenv("RPE_NO_RELU_MASK") == nullptr;
+        if (fold_c1) {
+            e->pending_bytes = 0;
+            PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_bwd_fold_y_conv1x1(e->dtype, c1.d.out_c, c1.d.in_c, c1.wd, e->params[c1.p_g], c1.invstd, c1.mean, c1.c1c2, e->w_kcat,
+                                                                        e->fold_bias, stream));
+            rpe_bn_bwd_epilogue ep;
+            const rpe_bn_bwd_epilogue* epp = nullptr;
+            double extra = 0.0;
+            if (bi > 0) {   // dz3 of the previous block: its ReLU mask, bn3's partial sums
+                ConvL& p3 = e->convs[e->blocks[bi - 1].c3];
+                unsigned char* mk = use_mask ? e->blocks[bi - 1].relu_mask : nullptr;
+                ep.y = p3.y; ep.a_mask = mk; ep.a_out = mk ? nullptr : p3.a;
+                ep.mean = p3.mean; ep.invstd = p3.invstd; ep.scale = nullptr; ep.shift = nullptr;
+                ep.stats_part = e->stats_part;
+                epp = &ep;
+                extra = 1.0 + (mk ? 1.0 / 16 : 1.0);
+            }
+            e->pending_flops = conv_flops(c1) * 2.0;
+            e->pending_bytes = 2.0 * conv_out_bytes(e, c1) + conv_in_bytes(e, c1) * (2.0 + extra);   // dz1, y1; out, shortcut (, y3, mask)
+            e->fused_tiles = (int)rpe_conv2d_dgrad_stats_tiles(&c1.d);
+            PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv1x1_dgrad_kcat_y(&c1.d, e->dtype, c1.dy, c1.y, e->w_kcat, e->fold_bias, gD, shortcut, epp, stream));
+        } else
         if (bi > 0) {
-            static const bool use_mask = getenv("RPE_NO_RELU_MASK") == nullptr;
             TRY(dgrad_fused(e, c1, c1.dy, gD, shortcut, &e->convs[e->blocks[bi - 1].c3], 1, stream,
                             use_mask ? e->blocks[bi - 1].relu_mask : nullptr));  // dz3 of the previous block
         } else {

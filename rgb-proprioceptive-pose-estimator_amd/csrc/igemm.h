@@ -120,7 +120,7 @@ template <typename T> struct TNArgs {
     // all-ones P: its rows are the column sums of Q.  One launch then yields dz^T x, x^T x and colsum(x) (folded weight gradient).
     const T* P2;
     int ldp2, I1, I2, ones_i0;
-    int p_cols;     // without P2: the columns P really has (rows i >= p_cols of D stay zero up to the all-ones tile); 0 = I
+    int p_cols;     // the columns P really has (rows i >= p_cols of D stay zero up to I1 / the all-ones tile); 0 = I1 with P2, else I
     float* slab;    // optional workspace of >= slab_bytes (16-byte aligned): per-workgroup fp32 tiles, summed by tn_reduce_kernel in a
     long slab_bytes;  // fixed order (deterministic, no float atomics); null -> atomic accumulation into D
     int accumulate;   // slab mode: D += sum instead of D = sum

@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
     // which tensor this tile's P columns come from (uniform per workgroup): P, P2 (rows >= I1), or none (the all-ones tile)
     const bool ones_tile = DMA && MODE == MODE_DENSE && p.ones_i0 > 0 && i0 == p.ones_i0;
     const bool second_p = DMA && MODE == MODE_DENSE && p.P2 != nullptr && i0 >= p.I1 && !ones_tile;
-    const int p_col0 = second_p ? i0 - p.I1 : i0, p_cols = ones_tile ? 0 : (second_p ? p.I2 : (p.P2 ? p.I1 : (p.p_cols > 0 ? p.p_cols : p.I))), p_ld = second_p ? p.ldp2 : p.ldp;
+    const int p_col0 = second_p ? i0 - p.I1 : i0, p_cols = ones_tile ? 0 : (second_p ? p.I2 : (p.p_cols > 0 ? p.p_cols : (p.P2 ? p.I1 : p.I))), p_ld = second_p ? p.ldp2 : p.ldp;
     // the descriptors start at this split's first row (dense) / first image (conv operand): 32-bit offsets span one split, tensors may
     // be of any size; num_records = the bytes from there to the end of the tensor, clamped below 2^31 (see nt_kernel)
     auto clamp31 = [](long bytes) -> int { return (int)(bytes < 0 ? 0 : (bytes > 0x7fffffffL ? 0x7fffffffL : bytes)); };

@@ -176,6 +176,47 @@ def bn_bwd_fold_conv1x1(w_fwd, w_dgrad, gamma, invstd, mean, c1c2):
     return wk, bias
 
 
+def bn_bwd_fold_y_conv1x1(w_dgrad, gamma, invstd, mean, c1c2):
+    """w_dgrad [Ci, Co] (compute dtype) -> (w_kcat [Ci, 2 Co], bias [Ci] fp32): the backward of the BatchNorm BEHIND a 1x1 conv whose
+    output is narrow (a Bottleneck's conv1), folded into its data gradient with y itself as the second K-concatenated operand."""
+    ci, co = w_dgrad.shape
+    dev = w_dgrad.device
+    wk = torch.empty((ci, 2 * co), dtype=w_dgrad.dtype, device=dev)
+    bias = torch.empty(ci, dtype=torch.float32, device=dev)
+    lib.rpe_bn_bwd_fold_y_conv1x1(dtype_code(w_dgrad), co, ci, _p(_chk(w_dgrad, "w_dgrad")), _p(gamma), _p(invstd), _p(mean), _p(c1c2), _p(wk), _p(bias), _stream())
+    return wk, bias
+
+
+def conv1x1_dgrad_kcat_y(dz, y, w_kcat, bias, ci, addend=None, bn=None):
+    """dz, y [B,H,W,Co] -> dx [B,H,W,Ci] = [dz | y] w_kcat^T + bias (+ addend).  bn: optional dict(y, mean, invstd, a_out / a_mask, scale,
+    shift) of the layer BEHIND dx (fused ReLU mask + BN-backward partial sums); then returns (dz_in, stats)."""
+    _chk(dz, "dz"), _chk(y, "y")
+    b, h, w, co = dz.shape
+    d = conv_desc((b, h, w, ci), co, 1, 1, 0)
+    dx = torch.empty((b, h, w, ci), dtype=dz.dtype, device=dz.device)
+    if bn is None:
+        lib.rpe_conv1x1_dgrad_kcat_y(ctypes.byref(d), dtype_code(dz), _p(dz), _p(y), _p(w_kcat), _p(bias), _p(dx), _p(addend), None, _stream())
+        return dx
+    st = torch.empty((lib.rpe_conv2d_dgrad_stats_tiles(ctypes.byref(d)), 2, ci), dtype=torch.float32, device=dz.device)
+    ep = BnBwdEpilogue(*(None if t is None else t.data_ptr() for t in (bn["y"], bn.get("a_out"), bn["mean"], bn["invstd"], bn.get("scale"), bn.get("shift"), st,
+                                                                      bn.get("a_mask"))))
+    lib.rpe_conv1x1_dgrad_kcat_y(ctypes.byref(d), dtype_code(dz), _p(dz), _p(y), _p(w_kcat), _p(bias), _p(dx), _p(addend), ctypes.byref(ep), _stream())
+    return dx, st
+
+
+def conv1x1_wgrad_folded_y(dz, y, x, gamma, invstd, mean, c1c2):
+    """dW [Co, Ci] fp32 of a 1x1 conv with the backward of the BatchNorm behind it folded in: reads dz, y (both [.., Co]) and x ([.., Ci])."""
+    _chk(dz, "dz"), _chk(y, "y"), _chk(x, "x")
+    b, h, w, co = dz.shape
+    ci = x.shape[3]
+    d = conv_desc((b, h, w, ci), co, 1, 1, 0)
+    dw = torch.empty((co, ci), dtype=torch.float32, device=dz.device)
+    ws = scratch(lib.rpe_conv1x1_wgrad_folded_y_scratch_bytes(ctypes.byref(d), dtype_code(dz)), dz.device)
+    lib.rpe_conv1x1_wgrad_folded_y(ctypes.byref(d), dtype_code(dz), _p(dz), _p(y), _p(x), _p(gamma), _p(invstd), _p(mean), _p(c1c2), _p(dw), _p(ws), ws.numel(),
+                                   _stream())
+    return dw
+
+
 def conv1x1_wgrad_folded(dz, a_in, w_master, gamma, invstd, mean, c1c2):
     """dW [Co, Ci] fp32 of a 1x1 conv with its output BN's backward folded in: reads dz and the conv input only."""
     _chk(dz, "dz"), _chk(a_in, "a_in")

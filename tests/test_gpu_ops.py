@@ -324,6 +324,70 @@ def test_bn_backward_folded_into_conv1x1_dgrad(dtype, cfg, epilogue):
     assert rel_err(dg2, dg2_ref) < t and rel_err(db2, db2_ref) < t
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 14, 256, 64), (3, 10, 512, 128), (5, 24, 256, 64), (2, 12, 64, 64), (2, 7, 1024, 256)])
+@pytest.mark.parametrize("epilogue", [False, True])
+def test_bn_backward_folded_into_the_conv_in_front_y_form(dtype, cfg, epilogue):
+    """A Bottleneck's conv1 (x [Ci = 4p] -> y [Co = p]) with bn1's backward folded in (rpe_bn_bwd_fold_y_conv1x1 + rpe_conv1x1_dgrad_kcat_y +
+    rpe_conv1x1_wgrad_folded_y): dx = [dz | y] [A o W ; C' o W] + b (+ shortcut gradient) and dW from dz, y, x alone == torch's BatchNorm
+    backward followed by the conv's data and weight gradients; optionally with the fused epilogue of the layer behind (the previous
+    block's bn3: a_out mask / packed mask, partial sums)."""
+    b, h, ci, co = cfg
+    g = torch.Generator().manual_seed(sum(cfg) + 1)
+    rows = b * h * h
+    x = q(torch.randn(b, ci, h, h, generator=g) * 0.8 + 0.3, dtype)
+    w = q(torch.randn(co, ci, 1, 1, generator=g) / ci ** 0.5, dtype)
+    y = q(F.conv2d(x, w), dtype)
+    y_leaf = y.clone().requires_grad_(True)
+    gamma, beta = 0.5 + torch.rand(co, generator=g), torch.rand(co, generator=g) - 0.5
+    z = F.batch_norm(y_leaf, None, None, gamma, beta, True, 0.1, 1e-5)
+    dz = q(torch.randn(z.shape, generator=g) + 0.2, dtype)
+    (dy_ref,) = torch.autograd.grad(z, y_leaf, dz)
+    add = q(torch.randn(b, ci, h, h, generator=g), dtype)
+    dx_ref = F.conv_transpose2d(dy_ref, w) + add
+    dw_ref = torch.einsum("bkhw,bnhw->kn", dy_ref, x)
+    yn, dzn, xn = nhwc(y), nhwc(dz), nhwc(x)
+    mean = yn.reshape(rows, co).mean(0)
+    invstd = 1.0 / torch.sqrt(yn.reshape(rows, co).var(0, unbiased=False) + 1e-5)
+    xhat = (yn - mean) * invstd
+    st = torch.stack([dzn.reshape(rows, co).sum(0), (dzn * xhat).reshape(rows, co).sum(0)])[None].contiguous()
+    _, _, c1c2 = ops.bn_backward_coeffs(st.to(DEV), rows)
+    wd = w.reshape(co, ci).t().contiguous().to(dtype).to(DEV)
+    wk, bias = ops.bn_bwd_fold_y_conv1x1(wd, gamma.to(DEV), invstd.to(DEV), mean.to(DEV), c1c2)
+    dz_d, y_d, x_d, add_d = dzn.to(dtype).to(DEV), yn.to(dtype).to(DEV), xn.to(dtype).to(DEV), nhwc(add).to(dtype).to(DEV)
+    t = {torch.float32: 1e-4, torch.bfloat16: 3e-2, torch.float16: 5e-3}[dtype]
+    if not epilogue:
+        dx = ops.conv1x1_dgrad_kcat_y(dz_d, y_d, wk, bias, ci, addend=add_d)
+        assert rel_err(nchw(dx), dx_ref) < t
+        dx0 = ops.conv1x1_dgrad_kcat_y(dz_d, y_d, wk, bias, ci)               # without the shortcut gradient
+        assert rel_err(nchw(dx0), dx_ref - add) < t
+        dw = ops.conv1x1_wgrad_folded_y(dz_d, y_d, x_d, gamma.to(DEV), invstd.to(DEV), mean.to(DEV), c1c2)
+        assert rel_err(dw, dw_ref) < (1e-3 if dtype == torch.float32 else t)
+        assert torch.equal(dw, ops.conv1x1_wgrad_folded_y(dz_d, y_d, x_d, gamma.to(DEV), invstd.to(DEV), mean.to(DEV), c1c2))   # fixed-order sums
+        return
+    # the layer behind: x = relu(bn3(y3) + identity) of the previous block; dx above is the gradient wrt x
+    y3 = q(torch.randn(b, ci, h, h, generator=g) * 1.2, dtype).requires_grad_(True)
+    g3 = (0.5 + torch.rand(ci, generator=g)).requires_grad_(True)
+    b3 = (torch.rand(ci, generator=g) - 0.5).requires_grad_(True)
+    idn = q(torch.randn(b, ci, h, h, generator=g), dtype)
+    out_prev = F.relu(F.batch_norm(y3, None, None, g3, b3, True, 0.1, 1e-5) + idn)
+    dy3_ref, dg3_ref, db3_ref = torch.autograd.grad(out_prev, (y3, g3, b3), dx_ref)
+    y3n = nhwc(y3.detach())
+    m3 = y3n.reshape(rows, ci).mean(0)
+    r3 = 1.0 / torch.sqrt(y3n.reshape(rows, ci).var(0, unbiased=False) + 1e-5)
+    sc3, sh3 = g3.detach() * r3, b3.detach() - m3 * g3.detach() * r3
+    y3d = y3n.to(dtype).to(DEV)
+    bn = dict(y=y3d, mean=m3.to(DEV), invstd=r3.to(DEV))
+    if dtype == torch.float32:
+        bn["a_out"] = ops.bn_apply(y3d, sc3.to(DEV), sh3.to(DEV), nhwc(idn).to(dtype).to(DEV), relu=True)
+    else:
+        _, bn["a_mask"] = ops.bn_apply_mask(y3d, sc3.to(DEV), sh3.to(DEV), nhwc(idn).to(dtype).to(DEV))
+    dz3, st3 = ops.conv1x1_dgrad_kcat_y(dz_d, y_d, wk, bias, ci, addend=add_d, bn=bn)
+    dy3, dg3, db3 = ops.bn_backward_from_dz(dz3, y3d, m3.to(DEV), r3.to(DEV), g3.detach().to(DEV), st3)
+    assert rel_err(nchw(dy3), dy3_ref) < t
+    assert rel_err(dg3, dg3_ref) < t and rel_err(db3, db3_ref) < t
+
+
 def test_pack_conv_weight():
     w = torch.randn(64, 3, 3, 128)
     wf, wd = ops.pack_conv_weight(w.to(DEV), torch.bfloat16)
