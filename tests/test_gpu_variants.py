@@ -21,6 +21,8 @@ ENGINE_VARIANTS = [
     {"RPE_NO_FWD_OVERLAP": "1", "RPE_STEM_UNFUSED": "1", "RPE_NO_BN_FOLD": "1"},
     # conv3 weight gradient from dy; fp32 atomics instead of slabs
     {"RPE_NO_WGRAD_FOLD": "1", "RPE_WGRAD_ATOMIC": "1"},
+    # bn1's backward folded into conv1's gradients (y-form; measured slower in the step, off by default), every layer
+    {"RPE_BN1_FOLD": "1", "RPE_BN1_FOLD_MAX": "512"},
     # the projection shortcut's BN as a pass of its own; folded weight gradient for layers 1-2 only; inference convs unsplit
     # (the golden case's eval / rollout outputs run at 2-4 images: the default takes the split-K kernels there)
     {"RPE_NO_SPLITK": "1", "RPE_NO_DS_FUSE": "1", "RPE_WGRAD_FOLD_MAX": "128", "RPE_NO_LINEAR_SPLITK": "1", "RPE_NO_DS_FOLD": "1"},
