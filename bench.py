@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 CATS = ["conv_fwd", "conv_dgrad", "conv_wgrad", "bn_fwd", "bn_bwd", "other"]
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+PRECONDITION_S = 1.5   # seconds of untimed train steps before the W warm-up steps (reported in the line as `precondition_s`)
 
 
 def log(*a):
@@ -205,6 +206,13 @@ def main():
             run_step()
     else:
         run_step = lambda: train_step(model, batch, criterion, opt, train_obj_pose, "train", sync)
+        # Device pre-conditioning, BEFORE the W warm-up steps and outside every timed region: the first process on a freshly leased box
+        # has measured 5-8 % slow for its first second or two (profiles/r03_ab_wgrad_hold.txt: first run 22.08 ms/step, the same build
+        # 20.05 a minute later; clocks / first-touch of the 19 GB workspace) -- with --warmup 5 that second would land in the timed steps.
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < PRECONDITION_S:
+            run_step()
+            torch.cuda.synchronize()
         for _ in range(args.warmup):
             run_step()
 
@@ -304,6 +312,7 @@ def main():
             "metric": "images/sec (train step, 224x224 bs256 per GPU)", "value": round(imgs / dt, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "precondition_s": 0.0 if use_graph else PRECONDITION_S,
             "config": {"workload": workloads[args.model] + (" [use_depth=True]" if dh else ""), "model": args.model,
                        "images_per_gpu": args.batch, "global_batch": args.batch * world, "resolution": 224, "latent_dim": 512,
                        "parallelism": "dp%d" % world + (" (RCCL world 1: staged joins + bucketed all-reduce on one GPU)" if args.force_dist else ""),

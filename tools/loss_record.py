@@ -1,0 +1,61 @@
+"""Convergence record: loss per train step of the bench workload on ONE seeded batch repeated (the model must overfit it), HIP path in
+bf16 / fp16 / fp32 from identical initial weights, and the CPU oracle for the first steps from the same state.  NaN loss VALUES (an
+all-zero post-ReLU quaternion: models/losses.py:68-69 of the reference, pinned by tests/golden/model_no_nanloss.npz) are recorded as null.
+
+    python tools/loss_record.py [images 32] [steps 200] [oracle_steps 20] > profiles/r03_loss_trace.json
+"""
+import contextlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from oracle import pose_oracle as po
+from rgb_proprioceptive_pose_estimator_amd import models as M
+from rgb_proprioceptive_pose_estimator_amd.optim import FusedAdam
+from rgb_proprioceptive_pose_estimator_amd.util.learn_utils import train_step
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+ORACLE = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+CFG = dict(latent_dim=512, hidden=[1024, 256, 64], use_depth=False, no_proprioception=False)
+LOSS = dict(metric="combined", scale=1.0, alpha=0.5, mode="pose")
+sd0 = po.make_state("no", CFG, 0)
+batch = po.synth_batch((B,), 1234)
+
+
+def clean(x):
+    return None if x != x else round(x, 5)
+
+
+out = {"workload": "NaiveObjectStateEstimator latent 512 hidden [1024,256,64], %d images of 224x224, the SAME seeded batch every step, Adam lr 1e-3, "
+                   "PoseDistanceLoss(combined, alpha 0.5)" % B, "steps": STEPS}
+for name, dtype in (("f32", torch.float32), ("bf16", torch.bfloat16), ("f16", torch.float16)):
+    with contextlib.redirect_stdout(sys.stderr):
+        m = M.NaiveObjectStateEstimator("cube", [1024, 256, 64], 50, 512, False, (9,), False, False, False, compute_dtype=dtype)
+    m.load_state_dict({k: v.clone() for k, v in sd0.items()})
+    m.cuda().train()
+    crit = {"obj_loss": M.PoseDistanceLoss(distance_metric="combined", scale_factor=1.0, alpha=0.5, mode="pose"), "val_loss": M.PoseDistanceLoss(mode="val")}
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    b = tuple(None if t is None else t.cuda() for t in (batch["img"], None, batch["x0bar"], batch["x0"], None, batch["obj"]))
+    ls, pos = [], []
+    for i in range(STEPS):
+        loss, pe, oe = train_step(m, b, crit, opt, True, "train", None)
+        ls.append(clean(float(loss.item())))
+        pos.append(round(float(pe.item()) / B, 5))
+    out[name] = {"loss": ls, "mean_pos_err_m": pos, "nan_loss_steps": sum(1 for x in ls if x is None),
+                 "params_finite": bool(torch.isfinite(m._arena.flat).all().item())}
+    print("[loss_record] %s: first %.4f last %s min %s" % (name, ls[0], ls[-1], min(x for x in ls if x is not None)), file=sys.stderr)
+    del m, opt
+    torch.cuda.empty_cache()
+if ORACLE:
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    sd, opt, ls = {k: v.clone() for k, v in sd0.items()}, {}, []
+    for i in range(ORACLE):
+        r = po.train_step("no", CFG, sd, batch, LOSS, opt, val_metrics=False)
+        ls.append(clean(float(r["loss"])))
+    out["oracle_f32_cpu"] = {"loss": ls}
+print(json.dumps(out))

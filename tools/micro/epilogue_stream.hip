@@ -21,6 +21,8 @@ __global__ __launch_bounds__(256) void k(unsigned short* __restrict__ out, const
     constexpr int N = 256, K = 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ u32x4 sA[128 * 8];
+    extern __shared__ char pad_lds[];   // only its SIZE matters: it sets how many workgroups fit a CU
+    if (M < 0) pad_lds[threadIdx.x] = 1;
     if (MODE <= 1) {
         const int lb = xcd_remap(blockIdx.x, gridDim.x);
         const int tile_n = lb & 1, tile_m = lb >> 1;
@@ -75,18 +77,18 @@ __global__ __launch_bounds__(256) void k(unsigned short* __restrict__ out, const
     }
 }
 
-template <int MODE> static int run(const char* name, unsigned short* out, const unsigned short* add, const unsigned short* y, const unsigned short* A, long M, int grid3) {
+template <int MODE> static int run(const char* name, unsigned short* out, const unsigned short* add, const unsigned short* y, const unsigned short* A, long M, int grid3, int pad = 0) {
     const int npanels = (int)(M / 64);
     const int grid = MODE <= 1 ? (int)(M / 128) * 2 : (MODE == 2 ? npanels : grid3);
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    hipLaunchKernelGGL((k<MODE>), dim3(grid), dim3(256), 0, 0, out, add, y, A, M, npanels);
+    hipLaunchKernelGGL((k<MODE>), dim3(grid), dim3(256), pad, 0, out, add, y, A, M, npanels);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a, 0));
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k<MODE>), dim3(grid), dim3(256), 0, 0, out, add, y, A, M, npanels);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k<MODE>), dim3(grid), dim3(256), pad, 0, out, add, y, A, M, npanels);
     CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
     float ms = 0; CK(hipEventElapsedTime(&ms, a, b)); ms /= 10;
     const double bytes = (double)M * 64 * 2 + 3.0 * M * 256 * 2;
-    printf("%-64s grid %6d: %.3f ms  %.2f TB/s\n", name, grid, ms, bytes / ms / 1e9);
+    printf("%-64s grid %6d lds %3d KB: %.3f ms  %.2f TB/s\n", name, grid, 16 + pad / 1024, ms, bytes / ms / 1e9);
     return 0;
 }
 
@@ -99,6 +101,8 @@ int main() {
         if (run<0>("128x128 tiles, all loads up front", out, add, y, A, M, 0)) return 1;
         if (run<1>("128x128 tiles, A tile -> wait -> epilogue steps 4 ahead", out, add, y, A, M, 0)) return 1;
         if (run<2>("64x256 row panels, operands 4 steps ahead", out, add, y, A, M, 0)) return 1;
+        for (int pad : {0, 16 << 10, 32 << 10, 48 << 10, 64 << 10})
+            if (run<1>("128x128 tiles, phases, occupancy limited by LDS", out, add, y, A, M, 0, pad)) return 1;
         if (run<3>("64x256 row panels, persistent (768 wgs)", out, add, y, A, M, 768)) return 1;
         if (run<3>("64x256 row panels, persistent (1536 wgs)", out, add, y, A, M, 1536)) return 1;
         if (run<3>("64x256 row panels, persistent (2048 wgs)", out, add, y, A, M, 2048)) return 1;
