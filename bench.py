@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 CATS = ["conv_fwd", "conv_dgrad", "conv_wgrad", "bn_fwd", "bn_bwd", "other"]
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-PRECONDITION_S = 1.5   # seconds of untimed train steps before the W warm-up steps (reported in the line as `precondition_s`)
+PRECONDITION_MIN_S, PRECONDITION_MAX_S = 1.5, 12.0   # untimed train steps before the W warm-up steps (reported in the line as `precondition_s`)
 
 
 def log(*a):
@@ -197,6 +197,7 @@ def main():
     if world > 1 or args.force_dist:
         broadcast_parameters(model._arena.flat, list(model.buffers()))
         sync = GradSync(model._arena.grad, reduce_single=args.force_dist).attach(model)   # slices are all-reduced under the backward
+    precondition_s = 0.0
     if use_graph:
         # the whole step as ONE captured hipGraph (forward, loss, val metrics, backward on both streams, Adam); replayed per step
         graphed = GraphedTrainStep(model, criterion, opt, train_obj_pose, batch, warmup=min(3, max(1, args.warmup)))
@@ -207,12 +208,22 @@ def main():
     else:
         run_step = lambda: train_step(model, batch, criterion, opt, train_obj_pose, "train", sync)
         # Device pre-conditioning, BEFORE the W warm-up steps and outside every timed region: the first process on a freshly leased box
-        # has measured 5-8 % slow for its first second or two (profiles/r03_ab_wgrad_hold.txt: first run 22.08 ms/step, the same build
-        # 20.05 a minute later; clocks / first-touch of the 19 GB workspace) -- with --warmup 5 that second would land in the timed steps.
-        t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < PRECONDITION_S:
-            run_step()
+        # has measured 5-10 % slow for its first seconds (profiles/r03_ab_wgrad_hold.txt: first run 22.08 ms/step, the same build 20.05 a
+        # minute later; r03_ab_stream_ew.txt: 22.47 vs 20.32) -- with --warmup 5 those seconds would land in the timed steps.  Windows of 10
+        # untimed steps are run until two consecutive windows agree within 1 % (at least PRECONDITION_MIN_S, at most PRECONDITION_MAX_S).
+        t_pre, prev = time.perf_counter(), None
+        while True:
+            t_w = time.perf_counter()
+            for _ in range(10):
+                run_step()
             torch.cuda.synchronize()
+            now = time.perf_counter()
+            w = now - t_w
+            settled = prev is not None and abs(w - prev) <= 0.01 * prev
+            prev = w
+            if (settled and now - t_pre >= PRECONDITION_MIN_S) or now - t_pre >= PRECONDITION_MAX_S:
+                break
+        precondition_s = time.perf_counter() - t_pre
         for _ in range(args.warmup):
             run_step()
 
@@ -312,7 +323,7 @@ def main():
             "metric": "images/sec (train step, 224x224 bs256 per GPU)", "value": round(imgs / dt, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "precondition_s": 0.0 if use_graph else PRECONDITION_S,
+            "precondition_s": round(precondition_s, 2),
             "config": {"workload": workloads[args.model] + (" [use_depth=True]" if dh else ""), "model": args.model,
                        "images_per_gpu": args.batch, "global_batch": args.batch * world, "resolution": 224, "latent_dim": 512,
                        "parallelism": "dp%d" % world + (" (RCCL world 1: staged joins + bucketed all-reduce on one GPU)" if args.force_dist else ""),

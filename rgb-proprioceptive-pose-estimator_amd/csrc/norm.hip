@@ -748,6 +748,8 @@ static inline EwCfg ew_cfg() {
         if (const char* e = getenv("RPE_EW_UNR")) v.unr = atoi(e);
         if (const char* e = getenv("RPE_EW_GRID")) v.cap = atol(e);
         if (const char* e = getenv("RPE_EW_NT")) v.nt = atoi(e) != 0;
+        // (measured and rejected in round 3, profiles/r03_ab_stream_ew.txt: capping the blocks per CU with unused LDS, which gains 8 % in
+        // tools/micro/epilogue_stream.hip, and 8 chunks per thread -- level or slower inside the step)
         return v;
     }();
     return c;
