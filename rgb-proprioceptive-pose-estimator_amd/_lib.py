@@ -13,7 +13,8 @@ import torch  # noqa: F401
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librpe_hip.so")
+# (RPE_LIB_PATH: another build of the SAME ABI, for A/B timing of two library builds on one box -- tools/ab_lib.sh)
+LIB_PATH = os.environ.get("RPE_LIB_PATH") or os.path.join(_HERE, "librpe_hip.so")
 
 RPE_F32, RPE_BF16, RPE_F16 = 0, 1, 2
 ABI_VERSION = 1

@@ -636,9 +636,8 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
     // lane-linear image one DMA instruction writes).  The slot holds logical chunk slot ^ swz(row).
     const int p_slot = tid % CPI, p_r = tid / CPI;
     const int q_slot = tid % CPJ, q_r = tid / CPJ;
-    // conv: the BJ-wide column tile lies inside one tap (BJ divides C)
-    int tap_r = 0, tap_s = 0, tap_c = 0;
-    if (MODE == MODE_CONV) { const int rs = j0 / g.C; tap_c = j0 - rs * g.C; tap_r = rs / g.S; tap_s = rs - tap_r * g.S; }
+    // conv: a column tile may span several taps (C = 64 with 128-column tiles: two taps, so dy is walked 5 instead of 9 times for a
+    // 3x3 conv); every 16-byte chunk lies inside one tap (C % 8 == 0), its tap is fixed per thread and pass (tap_of below)
 
     auto p_src = [&](int mb, int i) -> const T* {
         const int row = p_r + i * RPI;
@@ -657,9 +656,10 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
         const unsigned rem = mm - b * g.div_hw.d;
         const unsigned oh = fd_div(rem, g.div_w);
         const unsigned ow = rem - oh * g.div_w.d;
-        const int ih = (int)oh * g.sn + g.base_h + tap_r, iw = (int)ow * g.sn + g.base_w + tap_s;
+        const int cj = j0 + cc * CE, rs = cj / g.C, tc = cj - rs * g.C, tr = rs / g.S, ts = rs - tr * g.S;   // this chunk's tap
+        const int ih = (int)oh * g.sn + g.base_h + tr, iw = (int)ow * g.sn + g.base_w + ts;
         return (ok && ih >= 0 && iw >= 0 && ih < g.H && iw < g.W)
-                   ? p.Q + (long)b * g.img_stride + ((long)ih * g.W + iw) * g.C + tap_c + cc * CE : nullptr;
+                   ? p.Q + (long)b * g.img_stride + ((long)ih * g.W + iw) * g.C + tc : nullptr;
     };
     // DMA path addressing (as in nt_kernel): raw buffer descriptors, a 32-bit byte offset per lane and chunk.  Rows advance
     // by BMK per step: dense operands add a uniform byte stride to their offsets; the conv operand re-derives (image, oh, ow)
@@ -689,6 +689,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
     // (BMK = nb images + qh output rows + rw pixels); offsets are built with 24-bit multiplies (full rate; the launcher
     // checks that the image stride and pixel counts fit)
     unsigned q_b[NPJ], q_oh[NPJ], q_ow[NPJ];
+    int q_tr[NPJ], q_ts[NPJ], q_tc[NPJ];   // tap (r, s) and channel offset inside the tap of this thread's chunk in pass i
     unsigned adv_b = 0, adv_h = 0, adv_w = 0;
     if (DMA && MODE == MODE_CONV) {
         const unsigned hw = g.div_hw.d, wo = g.div_w.d;
@@ -709,6 +710,11 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
             const int row = q_r + i * RPJ;
             q_cc[i] = q_slot ^ tn_swz<T, CPJ>(row);
             q_okc[i] = (j0 + q_cc[i] * CE) < p.J;
+            q_tr[i] = q_ts[i] = q_tc[i] = 0;
+            if (MODE == MODE_CONV) {
+                const int cj = j0 + q_cc[i] * CE, rs = cj / g.C;
+                q_tc[i] = cj - rs * g.C; q_tr[i] = rs / g.S; q_ts[i] = rs - q_tr[i] * g.S;
+            }
             q_voff[i] = OOB;
             q_b[i] = q_oh[i] = q_ow[i] = 0;
             if (MODE == MODE_DENSE && q_okc[i]) q_voff[i] = (unsigned)(((long)row * p.ldq + j0 + q_cc[i] * CE) * ES);
@@ -737,10 +743,10 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
                 if (q_voff[i] < OOB) q_voff[i] += q_step;
             } else {
                 // rows past M have q_b >= batch: their offset lies beyond num_records, no separate test
-                const int ih = (int)__umul24(q_oh[i], (unsigned)g.sn) + g.base_h + tap_r, iw = (int)__umul24(q_ow[i], (unsigned)g.sn) + g.base_w + tap_s;
+                const int ih = (int)__umul24(q_oh[i], (unsigned)g.sn) + g.base_h + q_tr[i], iw = (int)__umul24(q_ow[i], (unsigned)g.sn) + g.base_w + q_ts[i];
                 const bool ok = q_okc[i] && ih >= 0 && iw >= 0 && ih < g.H && iw < g.W;
                 const unsigned pix = __umul24((unsigned)ih, (unsigned)g.W) + (unsigned)iw;
-                vo = ok ? (__umul24(q_b[i], (unsigned)g.img_stride) + __umul24(pix, (unsigned)g.C) + (unsigned)(tap_c + q_cc[i] * CE)) * ES : OOB;
+                vo = ok ? (__umul24(q_b[i], (unsigned)g.img_stride) + __umul24(pix, (unsigned)g.C) + (unsigned)q_tc[i]) * ES : OOB;
                 q_ow[i] += adv_w;
                 const bool cw = q_ow[i] >= g.div_w.d;
                 q_ow[i] -= cw ? g.div_w.d : 0u;
@@ -1145,6 +1151,8 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
     int ksub = 1, nslot = 2;
     if (dma) tn_ring(a.M, ksub, nslot);
     const int BMK = (dma ? 4 * ksub : 4) * Elem<T>::kChunk;
+    // (the register-staged stem kernel is bound by the latency of its load -> LDS -> barrier steps, not by bytes: 2x / 4x the
+    // workgroups measured level, as did reading dy once instead of four times)
     plan_tn_cfg<T, BI, BJ, MODE>(a, BMK, (dma && nslot == 3) ? 2 : 1);
     const long nwg = (long)a.tiles_i * a.tiles_j * a.splits;
     const long slab_bytes = nwg * (long)(BI * BJ) * 4;
@@ -1199,7 +1207,9 @@ template <typename T> int launch_tn(TNArgs<T>& a, int mode, hipStream_t s, long*
         if (mode == MODE_DENSE && (a.ldq % CE)) return rpe_set_error(RPE_ERR_ALIGN, "igemm_tn: dense ldq must be a chunk multiple");
         if (a.slab && (((uintptr_t)a.slab) & 15)) return rpe_set_error(RPE_ERR_ALIGN, "igemm_tn: the slab workspace must be 16-byte aligned");
     }
-    if (mode == MODE_STEM) return launch_tn_cfg<T, 64, 64, MODE_STEM>(a, s, slab_query);
+    // stem (7x7, J = 224 of 256 packed columns): ONE 64 x 256 tile, so the 411-MB dy operand is read once (round 2 walked it once
+    // per 64-column tile: four times, 0.35 ms at the end of the step with nothing beside it)
+    if (mode == MODE_STEM) return launch_tn_cfg<T, 64, 256, MODE_STEM>(a, s, slab_query);
     const bool wide_i = a.I > 64;
     if (mode == MODE_DENSE) {
         const bool wide_j = a.J > 64;
@@ -1211,7 +1221,7 @@ template <typename T> int launch_tn(TNArgs<T>& a, int mode, hipStream_t s, long*
     if (a.g.C % 64) return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: conv channels must be a multiple of 64");
     if (a.g.img_stride >= (1L << 24) || (long)a.g.H * a.g.W >= (1L << 24))
         return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: an image of 2^24 elements or more (offsets are built with 24-bit multiplies)");
-    const bool wide_j = (a.g.C % 128) == 0;
+    const bool wide_j = (a.g.C % 128) == 0 || ((a.g.C % 64) == 0 && a.J >= 128);   // (64-channel layers: a 128-column tile spans two taps)
     if (wide_i && wide_j) return launch_tn_cfg<T, 128, 128, MODE_CONV>(a, s, slab_query);
     if (wide_j) return launch_tn_cfg<T, 64, 128, MODE_CONV>(a, s, slab_query);
     if (wide_i) return launch_tn_cfg<T, 128, 64, MODE_CONV>(a, s, slab_query);
