@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RPE_ABI_VERSION 1
+#define RPE_ABI_VERSION 2   /* 2: BN partial-sum row counts depend on the element type (halo form of the 3x3 convs) */
 
 enum { RPE_F32 = 0, RPE_BF16 = 1, RPE_F16 = 2 };   /* RPE_F16: IEEE half activations / weight copies (BASELINE config C5), fp32 accumulate */
 enum {
@@ -58,8 +58,11 @@ typedef struct {
 } rpe_conv_desc;
 
 int rpe_conv_out_hw(const rpe_conv_desc* d, int* ho, int* wo);
-/* number of 128-row tiles = rows of the BN partial-sum buffer [tiles][2][out_c] */
+/* number of 128-row tiles = rows of the BN partial-sum buffer [tiles][2][out_c] of the 1x1 / stem / strided launches */
 long rpe_conv_stats_tiles(long rows);
+/* rows of stats_part [tiles][2][out_c] rpe_conv2d_fwd writes for this conv and element type: 128-row tiles, except the 3x3 / stride 1 /
+ * pad 1 convs of the 16-bit types, whose tiles are whole output rows (the halo form) */
+long rpe_conv2d_fwd_stats_tiles(const rpe_conv_desc* d, int dtype);
 
 /* y[B][Ho][Wo][out_c] = conv(x, w);  w_krsc = [out_c][kh][kw][in_c].
  * stats_part (nullable): per-128-row-tile column sums and sums of squares of the fp32
@@ -91,8 +94,8 @@ typedef struct {
     float* stats_part;
     const unsigned char* a_mask; /* or: the packed ReLU mask rpe_bn_apply_mask wrote, [rows][in_c/8] bytes (bit j = channel 8k+j > 0) */
 } rpe_bn_bwd_epilogue;
-/* rows of bn->stats_part the fused data gradient writes (stride-2 layers enumerate rows per parity class) */
-long rpe_conv2d_dgrad_stats_tiles(const rpe_conv_desc* d);
+/* rows of bn->stats_part the fused data gradient writes (stride-2 layers enumerate rows per parity class; 3x3 / stride 1 in 16-bit types: halo tiles) */
+long rpe_conv2d_dgrad_stats_tiles(const rpe_conv_desc* d, int dtype);
 int rpe_conv2d_dgrad_bn(const rpe_conv_desc* d, int dtype, const void* dy, const void* w_crsk, void* dz, const void* addend,
                         const rpe_bn_bwd_epilogue* bn, void* stream);
 /* BatchNorm backward folded into the data gradient of the 1x1 / stride-1 conv in front of it (y = a_in W^T, z = BN(y)):

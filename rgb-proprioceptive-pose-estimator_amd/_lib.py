@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RPE_LIB_PATH") or os.path.join(_HERE, "librpe_hip.so")
 
 RPE_F32, RPE_BF16, RPE_F16 = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class RpeError(RuntimeError):
@@ -50,7 +50,8 @@ _SPEC = {
     "rpe_conv2d_fwd_affine_workspace_bytes": (L, [PD, I]),
     "rpe_conv2d_fwd_affine_ws": (I, [PD, I, P, P, P, P, P, I, P, L, P]),
     "rpe_conv2d_dgrad": (I, [PD, I, P, P, P, P, P]),
-    "rpe_conv2d_dgrad_stats_tiles": (L, [PD]),
+    "rpe_conv2d_dgrad_stats_tiles": (L, [PD, I]),
+    "rpe_conv2d_fwd_stats_tiles": (L, [PD, I]),
     "rpe_conv2d_dgrad_bn": (I, [PD, I, P, P, P, P, POINTER(BnBwdEpilogue), P]),
     "rpe_bn_backward_reduce": (I, [I, P, P, P, P, P, P, P, P, L, I, P, L, P, P, P]),
     "rpe_bn_backward_from_dz": (I, [I, P, P, P, P, P, P, I, P, P, P, L, I, P, P, P]),

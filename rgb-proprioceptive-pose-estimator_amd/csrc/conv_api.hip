@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "igemm.h"
 
@@ -39,6 +40,18 @@ static inline int out_dim(int in, int k, int s, int p) { return (in + 2 * p - k)
 // stride-2 data gradients with even input dims run in parity-class order (see igemm.h Gather::parity)
 static inline bool dgrad_parity(const rpe_conv_desc* d) { return d->stride == 2 && !(d->in_h & 1) && !(d->in_w & 1); }
 static inline bool is_dense(const rpe_conv_desc* d) { return d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0; }
+// The halo form of nt_kernel (igemm.h MODE_HALO): 3x3 / stride 1 / pad 1 with 16-bit elements and `chan` gathered channels (in_c forward,
+// out_c for the data gradient) a multiple of 64.  RPE_NO_HALO=1 keeps the per-tap gathered form (A/B switch).
+static inline int halo_rt(const rpe_conv_desc* d, int dtype, int chan) {
+    static const bool off = getenv("RPE_NO_HALO") && atoi(getenv("RPE_NO_HALO"));
+    if (off || dtype == RPE_F32 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || (chan % 64)) return 0;
+    return halo_rows_per_tile(d->in_h, d->in_w);
+}
+template <typename T> static inline int dtype_of() { return sizeof(T) == 4 ? RPE_F32 : std::is_same<T, bf16>::value ? RPE_BF16 : RPE_F16; }
+static inline void halo_gather(Gather& g, const rpe_conv_desc* d, int rt) {
+    g.halo_rt = rt; g.halo_px = rt * d->in_w; g.halo_rows = d->batch * d->in_h;
+    g.div_h = make_fastdiv(d->in_h); g.div_pw = make_fastdiv(d->in_w + 2); g.div_hp = make_fastdiv(d->in_h + 2);
+}
 
 template <typename T>
 static int conv_fwd_t(const rpe_conv_desc* d, const void* x, const void* w, void* y, float* stats, const float* bias, const void* addend, int relu,
@@ -69,6 +82,7 @@ static int conv_fwd_t(const rpe_conv_desc* d, const void* x, const void* w, void
     g.div_hw = make_fastdiv(Ho * Wo); g.div_w = make_fastdiv(Wo);
     g.img_stride = (long)d->in_h * d->in_w * d->in_c;
     a.a_elems = (long)d->batch * g.img_stride;
+    if (const int rt = (a.slab && a.splits > 1) ? 0 : halo_rt(d, dtype_of<T>(), d->in_c)) { halo_gather(g, d, rt); return launch_nt<T>(a, MODE_HALO, s); }
     return launch_nt<T>(a, MODE_CONV, s);
 }
 
@@ -105,6 +119,7 @@ static int conv_dgrad_t(const rpe_conv_desc* d, const void* dy, const void* w_cr
         g.rows_q = d->batch * g.Ho * g.Wo;
         g.div_hw = make_fastdiv(g.Ho * g.Wo); g.div_w = make_fastdiv(g.Wo);
     }
+    if (const int rt = halo_rt(d, dtype_of<T>(), d->out_c)) { halo_gather(g, d, rt); return launch_nt<T>(a, MODE_HALO, s); }
     return launch_nt<T>(a, MODE_CONV, s);
 }
 
@@ -713,8 +728,15 @@ int rpe_conv_out_hw(const rpe_conv_desc* d, int* ho, int* wo) {
 
 long rpe_conv_stats_tiles(long rows) { return (rows + 127) / 128; }
 
-long rpe_conv2d_dgrad_stats_tiles(const rpe_conv_desc* d) {
+long rpe_conv2d_fwd_stats_tiles(const rpe_conv_desc* d, int dtype) {
+    if (!d || d->stride <= 0) return 0;
+    if (const int rt = halo_rt(d, dtype, d->in_c)) return ((long)d->batch * d->in_h + rt - 1) / rt;
+    return ((long)d->batch * out_dim(d->in_h, d->kh, d->stride, d->pad) * out_dim(d->in_w, d->kw, d->stride, d->pad) + 127) / 128;
+}
+
+long rpe_conv2d_dgrad_stats_tiles(const rpe_conv_desc* d, int dtype) {
     if (!d) return 0;
+    if (const int rt = halo_rt(d, dtype, d->out_c)) return ((long)d->batch * d->in_h + rt - 1) / rt;
     const long rows = (long)d->batch * d->in_h * d->in_w;
     if (!is_dense(d) && dgrad_parity(d)) return 4 * ((rows / 4 + 127) / 128);
     return (rows + 127) / 128;

@@ -276,9 +276,9 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
         want(e, (void**)&c.mean, c.d.out_c * 4L);
         want(e, (void**)&c.invstd, c.d.out_c * 4L);
         want(e, (void**)&c.c1c2, 2L * c.d.out_c * 4);
-        const long sf = (rpe_conv_stats_tiles(c.rows) + 2) * 2 * c.d.out_c;
+        const long sf = (rpe_conv2d_fwd_stats_tiles(&c.d, dtype) + 2) * 2 * c.d.out_c;
         if (sf > e->stats_floats) e->stats_floats = sf;
-        const long sf2 = (rpe_conv2d_dgrad_stats_tiles(&c.d) + 4) * 2 * c.d.in_c;  // fused dgrad partials (parity classes round up)
+        const long sf2 = (rpe_conv2d_dgrad_stats_tiles(&c.d, dtype) + 4) * 2 * c.d.in_c;  // fused dgrad partials (parity classes round up)
         if (sf2 > e->stats_floats) e->stats_floats = sf2;
     }
     const ConvL& st = e->convs[0];
@@ -617,7 +617,7 @@ static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residua
     float* rm = e->running[2 * c.bn_i];
     float* rv = e->running[2 * c.bn_i + 1];
     e->pending_bytes = 0;
-    PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_finalize(stats, (int)rpe_conv_stats_tiles(c.rows), c.d.out_c, c.rows, e->params[c.p_g], e->params[c.p_b], rm, rv,
+    PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_finalize(stats, (int)rpe_conv2d_fwd_stats_tiles(&c.d, e->dtype), c.d.out_c, c.rows, e->params[c.p_g], e->params[c.p_b], rm, rv,
                         e->nbt[c.bn_i], 0.1f, 1e-5f, c.scale, c.shift, c.mean, c.invstd, dpart, stream));
     if (stats_only) return 0;
     e->pending_bytes = conv_out_bytes(e, c) * (2.0 + (residual ? 1.0 : 0.0) + ((relu_mask && relu) ? 1.0 / 16 : 0.0));   // y (+residual) -> a (+mask)
@@ -752,7 +752,7 @@ static int dgrad_fused(rpe_resnet50* e, ConvL& c, const void* dy, void* dz, cons
     e->pending_flops = conv_flops(c);
     // reads dy; writes dz; the fused epilogue also reads y (and a_out for residual outputs) and the shortcut addend
     e->pending_bytes = conv_out_bytes(e, c) + conv_in_bytes(e, c) * (2.0 + (mask_mode == 1 ? (ep.a_mask ? 1.0 / 16 : 1.0) : 0.0) + (addend ? 1.0 : 0.0));
-    e->fused_tiles = (int)rpe_conv2d_dgrad_stats_tiles(&c.d);  // partial-sum rows this launch leaves behind
+    e->fused_tiles = (int)rpe_conv2d_dgrad_stats_tiles(&c.d, e->dtype);  // partial-sum rows this launch leaves behind
     PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad_bn(&c.d, e->dtype, dy, c.wd, dz, addend, &ep, stream));
     return 0;
 }
@@ -837,7 +837,7 @@ static int conv1x1_backward_folded(rpe_resnet50* e, ConvL& c, const void* dz, Co
     ep.stats_part = e->stats_part;
     e->pending_flops = conv_flops(c) * (1.0 + (double)c.d.in_c / c.d.out_c);
     e->pending_bytes = conv_out_bytes(e, c) + conv_in_bytes(e, c) * 3.0;   // reads dz, x, y_behind; writes dz_behind
-    e->fused_tiles = (int)rpe_conv2d_dgrad_stats_tiles(&c.d);
+    e->fused_tiles = (int)rpe_conv2d_dgrad_stats_tiles(&c.d, e->dtype);
     PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv1x1_dgrad_kcat(&c.d, e->dtype, dz, x, e->w_kcat, e->fold_bias, behind.dy, &ep, stream));
     return 0;
 }
@@ -1000,7 +1000,7 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
             }
             e->pending_flops = conv_flops(c1) * 2.0;
             e->pending_bytes = 2.0 * conv_out_bytes(e, c1) + conv_in_bytes(e, c1) * (2.0 + extra);   // dz1, y1; out, shortcut (, y3, mask)
-            e->fused_tiles = (int)rpe_conv2d_dgrad_stats_tiles(&c1.d);
+            e->fused_tiles = (int)rpe_conv2d_dgrad_stats_tiles(&c1.d, e->dtype);
             PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv1x1_dgrad_kcat_y(&c1.d, e->dtype, c1.dy, c1.y, e->w_kcat, e->fold_bias, gD, shortcut, epp, stream));
         } else
         if (bi > 0) {

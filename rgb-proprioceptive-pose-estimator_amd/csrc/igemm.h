@@ -4,7 +4,13 @@
 
 namespace rpe {
 
-enum { MODE_DENSE = 0, MODE_CONV = 1, MODE_STEM = 2 };
+enum { MODE_DENSE = 0, MODE_CONV = 1, MODE_STEM = 2, MODE_HALO = 3 };
+
+// MODE_HALO (nt_kernel; 3x3 / stride 1 / pad 1 convs and their data gradients, 16-bit types): the activation operand is staged ONCE per
+// 64-channel chunk as a halo patch -- the input rows a tile of whole output rows touches, zero padding included -- and the nine taps
+// read their MFMA fragments from it at shifted addresses; only the weight tile moves per K step (half the LDS fill of the gathered
+// form, no per-tap address refresh).  kHaloPatchPx: pixels (128 B each) of the patch region.
+constexpr int kHaloPatchPx = 256;
 
 // one 16 x 16 MFMA step over a 16-byte chunk per lane and operand (32 K elements of a 16-bit type, 16 of fp32): first operand =
 // the N side, second = the M side; acc element e of lane l is (row l & 15 of M, column 4 * (l >> 4) + e of N)
@@ -51,7 +57,21 @@ struct Gather {
     // instead of multiplying 3/4 zeros.  parity = 1: Ho/Wo above are the HALF dims, rows_q = B*(H/2)*(W/2) rows per class.
     int parity;
     int rows_q;
+    // MODE_HALO: a tile = halo_rt whole output rows (global row index b*H + h) = halo_px = halo_rt * W <= 128 pixels; the patch holds
+    // the padded input rows P0 .. P1 of the padded row space P(b, h) = b*(H+2) + h + 1 (two zero rows between images), W + 2 pixels each
+    int halo_rt, halo_px, halo_rows;   // halo_rows = B * H
+    FastDiv div_h, div_pw, div_hp;     // H, W + 2, H + 2
 };
+
+// rows per tile of the halo form for an H x W image, or 0 when the patch of no tile height fits (kHaloPatchPx pixels)
+static inline int halo_rows_per_tile(int H, int W) {
+    if (W + 2 > kHaloPatchPx / 3 || W > 128) return 0;
+    for (int rt = 128 / W; rt >= 1; --rt) {
+        const int cross = (H % rt == 0) ? 0 : (rt + H - 2) / H;    // image boundaries a tile can straddle
+        if ((rt + 2 + 2 * cross) * (W + 2) <= kHaloPatchPx) return rt;
+    }
+    return 0;
+}
 
 template <typename T> struct NTArgs {
     const T* A;     // activations (dense [M][lda] or NHWC tensor described by g)

@@ -19,7 +19,14 @@ template <typename T> int launch_nt(NTArgs<T>& a, int mode, hipStream_t s) {
     if ((a.ldb % CE) || (((uintptr_t)a.Bw) & 15) || (((uintptr_t)a.A) & 15))
         return rpe_set_error(RPE_ERR_ALIGN, "igemm_nt: operands must be 16-byte aligned with ld a multiple of the 16-byte chunk");
     if (mode == MODE_DENSE && ((a.lda % CE) || (a.K % CE))) return rpe_set_error(RPE_ERR_ALIGN, "igemm_nt: dense lda/K must be chunk multiples");
-    if (mode == MODE_CONV && (a.g.C % (8 * CE))) return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: conv channels must be a multiple of 8 chunks");
+    if ((mode == MODE_CONV || mode == MODE_HALO) && (a.g.C % (8 * CE))) return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: conv channels must be a multiple of 8 chunks");
+    if (mode == MODE_HALO) {
+        const Gather& g = a.g;
+        if (sizeof(T) != 2 || g.R != 3 || g.S != 3 || g.sn != 1 || g.sd_shift != 0 || g.parity || g.H != g.Ho || g.W != g.Wo || g.halo_rt <= 0 ||
+            g.halo_rt != halo_rows_per_tile(g.H, g.W) || g.halo_px != g.halo_rt * g.W || g.halo_px > 128 || g.halo_rows * (long)g.W != a.M ||
+            (g.base_h != -1 && g.base_h != 1) || g.base_h != g.base_w || g.tap_sign != -g.base_h || a.K != 9 * g.C || (a.slab && a.splits > 1))
+            return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: the halo form is for 3x3 / stride 1 / pad 1 convs of 16-bit types");
+    }
     if (mode != MODE_STEM) {
         // buffer-descriptor extents of the two DMA operands; rows that must read as zero use offset 2^31, so both stay below it
         // the activation operand may be of any size: the kernel's descriptors start at each tile's first row (dense) / first image
@@ -43,6 +50,10 @@ template <typename T> int launch_nt(NTArgs<T>& a, int mode, hipStream_t s) {
     }
     if (mode == MODE_STEM) return launch_nt_mode<T, MODE_STEM>(a, s);
     if (mode == MODE_DENSE) return launch_nt_mode<T, MODE_DENSE>(a, s);
+    if (mode == MODE_HALO) {
+        if constexpr (sizeof(T) == 2) return launch_nt_mode<T, MODE_HALO>(a, s);
+        else return rpe_set_error(RPE_ERR_DTYPE, "igemm_nt: the halo form needs a 16-bit type");
+    }
     return launch_nt_mode<T, MODE_CONV>(a, s);
 }
 template int launch_nt<float>(NTArgs<float>&, int, hipStream_t);

@@ -96,13 +96,16 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
     constexpr int RPI = 64 / KCH;                       // rows covered by one 64-lane x 16-B DMA instruction
     constexpr int AR = BM / RPI / NW, BR = BN / RPI / NW;  // DMA instructions (= 16-B chunks per thread) per K-step
     static_assert((BM / RPI) % NW == 0 && (BN / RPI) % NW == 0, "tile rows must split evenly over the waves");
-    constexpr int STAGE = (BM + BN) * KCH;             // 16-byte units
+    constexpr bool HALO = MODE == MODE_HALO;            // 3x3 / stride 1 / pad 1: activation operand as a resident halo patch (igemm.h)
+    static_assert(!HALO || (KCH == 8 && CE == 8 && WAVES_M == 2), "halo form: 16-bit types, 64-channel chunks, 128-row tiles");
+    constexpr int STAGE = HALO ? BN * KCH : (BM + BN) * KCH;   // 16-byte units (halo: the ring carries the weight tile only)
+    constexpr int PATCH16 = HALO ? kHaloPatchPx * 8 : 0;       // halo patch region behind the ring
     constexpr int EPI16 = NW * 16 * (WN + 4) / 4;      // epilogue staging (NW waves x 16 rows x (WN+4) floats)
     constexpr bool DMA = MODE != MODE_STEM;
     constexpr int NSTAGE = DMA ? NST : 2;              // DMA path: ring of NST slots, NST-1 tiles in flight
     static_assert(DMA || (WAVES_M == 2 && KCH == 4), "register staging is only wired for the 128-row / 64-B-row config");
-    static_assert(NST >= 2 && NST <= 3, "ring depth 2..3");
-    __shared__ u32x4 lds[(NSTAGE * STAGE > EPI16) ? NSTAGE * STAGE : EPI16];
+    static_assert(NST >= 2 && NST <= (MODE == MODE_HALO ? 4 : 3), "ring depth 2..3 (halo form: ..4)");
+    __shared__ u32x4 lds[(NSTAGE * STAGE + PATCH16 > EPI16) ? NSTAGE * STAGE + PATCH16 : EPI16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
@@ -119,6 +122,10 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
         m0 = (tile_m >> 2) * BM;
         ph = cls >> 1; pw = cls & 1;
         row_lim = g.rows_q;
+    }
+    if (HALO) {   // a tile = halo_rt whole output rows; its tail rows (halo_px .. 127) are masked like rows past M
+        m0 = tile_m * g.halo_px;
+        row_lim = m0 + g.halo_px < p.M ? m0 + g.halo_px : p.M;
     }
     // output row (for C / addend / BN operands) of tile-local row index `lr`, or -1 when outside the problem
     auto out_row = [&](int lr) -> long {
@@ -156,7 +163,8 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
     // The A descriptors start at THIS tile's first row (dense) / first image (conv), so the 32-bit offsets span one tile and a
     // tensor may be of any size (round 1 capped a tensor at 2 GiB = ~1300 images in bf16); num_records = the bytes from there to
     // the end of the tensor, clamped below 2^31 (a tile never reaches that far, and rows past M are masked by a_ok anyway).
-    const unsigned tile_b0 = (MODE == MODE_CONV) ? (unsigned)__builtin_amdgcn_readfirstlane((int)fd_div((unsigned)(m0 < row_lim ? m0 : 0), g.div_hw)) : 0u;
+    const unsigned tile_b0 = (MODE == MODE_CONV) ? (unsigned)__builtin_amdgcn_readfirstlane((int)fd_div((unsigned)(m0 < row_lim ? m0 : 0), g.div_hw))
+                             : HALO ? (unsigned)__builtin_amdgcn_readfirstlane((int)fd_div((unsigned)(tile_m * g.halo_rt), g.div_h)) : 0u;
     const long tile_a = (MODE == MODE_DENSE) ? (long)m0 * p.lda : (long)tile_b0 * g.img_stride;     // elements
     unsigned a_voff[AR], b_voff[BR], a_vbase[AR];
     long a_base[AR];
@@ -393,7 +401,112 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
 #pragma unroll
             for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (DMA) {
+    if constexpr (HALO) {
+        // ---- halo form -----------------------------------------------------------------------------
+        // Patch = padded input rows P0 .. P1 (P(b, h) = b*(H+2) + h + 1: one zero row above and below every image) x W + 2 pixels
+        // (one zero column left and right) x 64 channels = 128 B per pixel, LDS image [pixel q][8 slots of 16 B], slot = chunk ^ (q & 7).
+        // Output pixel (b, h, w) sits at patch pixel qc = (P(b, h) - P0) * (W+2) + w + 1; tap (r, s) reads pixel qc + dq with the
+        // UNIFORM dq = (base_h + sign*r) * (W+2) + base_w + sign*s  (forward: base -1, sign +1; data gradient: base +1, sign -1).
+        // K order: chunk-major, tap-minor -- the weight column of step (chunk c, tap t) is t*C + 64 c.
+        constexpr int NI = BR;                     // LDS-DMA instructions per wave and weight tile
+        constexpr int PF = NSTAGE - 1;
+        constexpr int PNI = kHaloPatchPx / 8 / NW;  // patch instructions per wave (8 pixels each)
+        const int H = g.H, W = g.W, PW = W + 2;
+        const int gr0 = tile_m * g.halo_rt;         // first output row (global row index b*H + h) of the tile
+        const int h0 = gr0 - (int)tile_b0 * H;
+        const int P0 = (int)tile_b0 * (H + 2) + h0;
+        int gr1 = gr0 + g.halo_rt; if (gr1 > g.halo_rows) gr1 = g.halo_rows; gr1 -= 1;
+        const int b1 = (int)fd_div((unsigned)gr1, g.div_h);
+        const int npx = (b1 * (H + 2) + (gr1 - b1 * H) + 2 - P0 + 1) * PW;
+        unsigned pv[PNI];
+#pragma unroll
+        for (int j = 0; j < PNI; ++j) {
+            const int q = (j * NW + wave) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ (q & 7);
+            const int pr = (int)fd_div((unsigned)q, g.div_pw), pc = q - pr * PW;
+            const int PR = P0 + pr;
+            const int b = (int)fd_div((unsigned)PR, g.div_hp), hp = PR - b * (H + 2);
+            const bool ok = q < npx && hp >= 1 && hp <= H && pc >= 1 && pc <= W;
+            pv[j] = ok ? (unsigned)(((long)(b - (int)tile_b0) * g.img_stride + (long)((hp - 1) * W + (pc - 1)) * g.C + chunk * CE) * ES) : OOB;
+        }
+        int qc[FM];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int lr = wave_m * WM + i * 16 + (lane & 15);
+            const int lrc = (m0 + lr < row_lim) ? lr : 0;
+            const int rr = (int)fd_div((unsigned)lrc, g.div_w), w = lrc - rr * W;
+            const int b = (int)fd_div((unsigned)(gr0 + rr), g.div_h);
+            qc[i] = (rr + 2 * (b - (int)tile_b0) + 1) * PW + w + 1;
+        }
+        nk = 9 * (g.C / BK);
+        lds_char* const patch = (lds_char*)lds + NSTAGE * (STAGE * 16);
+        int i_tap = 0, i_c0 = 0;   // issue side of the weight ring
+        auto dma_w = [&](int st) {
+            lds_char* base = (lds_char*)lds + st * (STAGE * 16);
+            const int so_b = (i_tap * g.C + i_c0) * ES;
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(base + (wave_u * BR + i) * 1024), 16, (int)b_voff[i], so_b, 0, 0);
+            if (++i_tap == 9) { i_tap = 0; i_c0 += BK; }
+        };
+        auto stage_patch = [&](int c0h) {
+#pragma unroll
+            for (int j = 0; j < PNI; ++j) {
+                const int t = j * NW + wave_u;
+                if (t * 8 < npx) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(patch + t * 1024), 16, (int)pv[j], c0h * ES, 0, 0);
+            }
+        };
+        const u32x4* const pbase = lds + NSTAGE * STAGE;
+        const int hfr = lane & 15, hfc = lane >> 4;
+        auto compute_halo = [&](int st, int dq, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const u32x4* wbase = lds + st * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < KCH / 4; ++ks) {
+                u32x4 af[FM], wf[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i) { const int q = qc[i] + dq; af[i] = pbase[q * 8 + ((ks * 4 + hfc) ^ (q & 7))]; }
+#pragma unroll
+                for (int i = 0; i < FN; ++i) { const int row = wave_n * WN + i * 16 + hfr; wf[i] = wbase[row * KCH + nt_swz<KCH>(row, ks * 4 + hfc)]; }
+#pragma unroll
+                for (int a = 0; a < FN; ++a)
+#pragma unroll
+                    for (int b = 0; b < FM; ++b) {
+                        if (FIRST && ks == 0) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        Mma<T>::run(wf[a], af[b], acc[a][b]);
+                    }
+            }
+        };
+        stage_patch(0);
+#pragma unroll
+        for (int t = 0; t < PF; ++t) dma_w(t);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        int st = 0, c_tap = 0, c_c0 = 0, c_tr = 0, c_ts = 0;
+        auto k_step = [&](int kt, auto first_tag) {
+            if (kt + PF < nk) { int s2 = st + PF; if (s2 >= NSTAGE) s2 -= NSTAGE; dma_w(s2); }
+            const int dq = (g.base_h + g.tap_sign * c_tr) * PW + g.base_w + g.tap_sign * c_ts;
+            compute_halo(st, dq, first_tag);
+            if (++c_ts == 3) { c_ts = 0; ++c_tr; }
+            if (++c_tap == 9 && kt + 1 < nk) {
+                // next 64-channel chunk: every wave is done with the patch (WAR), then it is re-filled; the weight tiles in flight land with it
+                c_tap = 0; c_tr = 0; c_c0 += BK;
+                wait_vmcnt<3 * NI>();
+                __builtin_amdgcn_s_barrier();
+                stage_patch(c_c0);
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+            } else {
+                int newer = nk - 2 - kt;
+                if (newer > PF - 1) newer = PF - 1;
+                if (newer >= 3) wait_vmcnt<3 * NI>(); else if (newer == 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+            }
+            if (++st == NSTAGE) st = 0;
+        };
+        k_step(0, TagFirst{});
+        for (int kt = 1; kt < nk; ++kt) k_step(kt, TagNext{});
+    } else if (DMA) {
         // 3-slot ring, tiles kt+1 and kt+2 in flight while tile kt is multiplied.  A tile is NI LDS-DMA instructions per
         // wave; vmcnt counts them in issue order, so "all but the newest NI landed" == tile kt+1 is complete.  The raw
         // s_barrier (not __syncthreads, which would drain vmcnt to 0) then publishes it to the other waves; slot (kt+2)%3
@@ -1053,7 +1166,7 @@ template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE>
 
 template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST = 3> static int launch_nt_cfg(NTArgs<T>& a, hipStream_t s) {
     constexpr int BM = 64 * WAVES_M;
-    a.tiles_m = (MODE == MODE_CONV && a.g.parity) ? 4 * ceil_div(a.g.rows_q, BM) : ceil_div(a.M, BM);
+    a.tiles_m = (MODE == MODE_CONV && a.g.parity) ? 4 * ceil_div(a.g.rows_q, BM) : MODE == MODE_HALO ? ceil_div(a.g.halo_rows, a.g.halo_rt) : ceil_div(a.M, BM);
     a.tiles_n = ceil_div(a.N, BN);
     const long nwg = (long)a.tiles_m * a.tiles_n;
     if (nwg <= 0 || nwg > 0x7fffffffL) return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: bad grid");
@@ -1070,6 +1183,11 @@ template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s) 
     // BN partial sums are always indexed by 128-row tiles (rpe_conv_stats_tiles), whatever the M tile
     if constexpr (MODE == MODE_STEM) {
         return launch_nt_cfg<T, 2, 64, 4, MODE_STEM>(a, s);
+    } else if constexpr (MODE == MODE_HALO) {
+        // 64 KB of LDS (2 x 16 KB weight ring + 32 KB patch; 48 KB with 64 output channels): two workgroups per CU
+        // (ring depth, isolated at 256 images: 3 slots = 80 KB level with 2 on layers 2-4 and 20 % slower on layer1; 4 slots = one workgroup
+        // per CU, 35 % slower everywhere: the second workgroup on the CU, not the prefetch distance, is what keeps the matrix cores fed)
+        return wide ? launch_nt_cfg<T, 2, 128, 8, MODE_HALO, 2>(a, s) : launch_nt_cfg<T, 2, 64, 8, MODE_HALO, 2>(a, s);
     } else {
         if ((a.role == 3 || (a.role == 2 && MODE == MODE_DENSE)) && a.slab && a.splits > 1) return launch_nt_split<T, MODE>(a, s);
         // (256-row / 8-wave tiles, 1 workgroup per CU: measured on the ResNet shapes at bs256 they gain 3..10 % in isolation for K >= 1024,

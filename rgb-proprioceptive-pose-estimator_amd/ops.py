@@ -66,7 +66,7 @@ def conv2d_fwd(x, w_krsc, stride, pad, want_stats=False):
     y = torch.empty((x.shape[0], ho, wo, co), dtype=x.dtype, device=x.device)
     st = None
     if want_stats:
-        st = torch.empty((stats_tiles(x.shape[0] * ho * wo), 2, co), dtype=torch.float32, device=x.device)
+        st = torch.empty((lib.rpe_conv2d_fwd_stats_tiles(ctypes.byref(d), dtype_code(x)), 2, co), dtype=torch.float32, device=x.device)
     lib.rpe_conv2d_fwd(ctypes.byref(d), dtype_code(x), _p(x), _p(w_krsc), _p(y), _p(st), _stream())
     return (y, st) if want_stats else y
 
@@ -105,7 +105,7 @@ def conv2d_dgrad_bn(dy, w_crsk, x_shape, stride, pad, y, mean, invstd, a_out=Non
     ci, k, co = w_crsk.shape[0], w_crsk.shape[1], w_crsk.shape[3]
     d = conv_desc(x_shape, co, k, stride, pad)
     dz = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device)
-    st = torch.empty((lib.rpe_conv2d_dgrad_stats_tiles(ctypes.byref(d)), 2, ci), dtype=torch.float32, device=dy.device)
+    st = torch.empty((lib.rpe_conv2d_dgrad_stats_tiles(ctypes.byref(d), dtype_code(dy)), 2, ci), dtype=torch.float32, device=dy.device)
     ep = BnBwdEpilogue(*(None if t is None else t.data_ptr() for t in (y, a_out, mean, invstd, scale, shift, st, a_mask)))
     lib.rpe_conv2d_dgrad_bn(ctypes.byref(d), dtype_code(dy), _p(dy), _p(w_crsk), _p(dz), _p(addend), ctypes.byref(ep), _stream())
     return dz, st
@@ -197,7 +197,7 @@ def conv1x1_dgrad_kcat_y(dz, y, w_kcat, bias, ci, addend=None, bn=None):
     if bn is None:
         lib.rpe_conv1x1_dgrad_kcat_y(ctypes.byref(d), dtype_code(dz), _p(dz), _p(y), _p(w_kcat), _p(bias), _p(dx), _p(addend), None, _stream())
         return dx
-    st = torch.empty((lib.rpe_conv2d_dgrad_stats_tiles(ctypes.byref(d)), 2, ci), dtype=torch.float32, device=dz.device)
+    st = torch.empty((lib.rpe_conv2d_dgrad_stats_tiles(ctypes.byref(d), dtype_code(dz)), 2, ci), dtype=torch.float32, device=dz.device)
     ep = BnBwdEpilogue(*(None if t is None else t.data_ptr() for t in (bn["y"], bn.get("a_out"), bn["mean"], bn["invstd"], bn.get("scale"), bn.get("shift"), st,
                                                                       bn.get("a_mask"))))
     lib.rpe_conv1x1_dgrad_kcat_y(ctypes.byref(d), dtype_code(dz), _p(dz), _p(y), _p(w_kcat), _p(bias), _p(dx), _p(addend), ctypes.byref(ep), _stream())
@@ -241,7 +241,7 @@ def conv1x1_dgrad_kcat(dz, a_in, w_kcat, bias, bn=None):
     if bn is None:
         lib.rpe_conv1x1_dgrad_kcat(ctypes.byref(d), dtype_code(dz), _p(dz), _p(a_in), _p(w_kcat), _p(bias), _p(dx), None, _stream())
         return dx
-    st = torch.empty((lib.rpe_conv2d_dgrad_stats_tiles(ctypes.byref(d)), 2, ci), dtype=torch.float32, device=dz.device)
+    st = torch.empty((lib.rpe_conv2d_dgrad_stats_tiles(ctypes.byref(d), dtype_code(dz)), 2, ci), dtype=torch.float32, device=dz.device)
     ep = BnBwdEpilogue(*(None if t is None else t.data_ptr() for t in (bn["y"], bn.get("a_out"), bn["mean"], bn["invstd"], bn.get("scale"), bn.get("shift"), st,
                                                                       bn.get("a_mask"))))
     lib.rpe_conv1x1_dgrad_kcat(ctypes.byref(d), dtype_code(dz), _p(dz), _p(a_in), _p(w_kcat), _p(bias), _p(dx), ctypes.byref(ep), _stream())

@@ -140,6 +140,16 @@ CONVS = [  # (B, H, Cin, Cout, k, stride, pad)
     (8, 24, 128, 128, 3, 1, 1),
     (8, 24, 1024, 64, 1, 1, 0),
     (6, 30, 128, 256, 3, 2, 1),
+    # 3x3 / stride 1 / pad 1 in the 16-bit types run the halo form (tiles of whole output rows, activation patch resident in LDS):
+    # several 64-channel chunks, tiles that straddle images, a last tile with fewer rows, a partial N tile, the widest rows that fit
+    (3, 9, 128, 192, 3, 1, 1),
+    (5, 7, 256, 64, 3, 1, 1),
+    (37, 7, 64, 64, 3, 1, 1),
+    (2, 56, 64, 64, 3, 1, 1),
+    (4, 28, 128, 128, 3, 1, 1),
+    (1, 3, 64, 128, 3, 1, 1),
+    (2, 80, 64, 64, 3, 1, 1),
+    (1, 100, 64, 64, 3, 1, 1),   # a row of 102 pixels x 3 does not fit the patch: gathered form
 ]
 
 
