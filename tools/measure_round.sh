@@ -18,9 +18,9 @@ echo "pmc done" >> $out/progress.txt
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/mfma -o m -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/mfma.err
 echo "mfma done" >> $out/progress.txt
 cd $root
-python tools/pmc_reduce.py $out/pmc/fetch_counter_collection.csv $out/pmc/write_counter_collection.csv 6 > $out/hbm_traffic_pmc.json
+python tools/pmc_reduce.py $out/pmc/fetch_counter_collection.csv $out/pmc/write_counter_collection.csv > $out/hbm_traffic_pmc.json
 python tools/mfma_reduce.py $out/mfma/m_counter_collection.csv > $out/mfma_busy_pmc.json
-python tools/timeline.py $out/stats/st_kernel_trace.csv 4 > $out/timeline.txt
+python tools/timeline.py $out/stats/st_kernel_trace.csv -5 > $out/timeline.txt
 for m in n td tdo_v2; do python bench.py --model $m --steps 20 --warmup 5 --no-cpu-baseline 2>> $out/models.err | tail -1 > $out/bench_$m.json; done
 python bench.py --model tdo --depth-head --steps 20 --warmup 5 --no-cpu-baseline 2>> $out/models.err | tail -1 > $out/bench_tdo_depth.json
 echo "models done" >> $out/progress.txt
@@ -30,5 +30,5 @@ python bench.py --steps 30 --warmup 8 --no-cpu-baseline 2>> $out/dist.err | tail
 echo "dist done" >> $out/progress.txt
 python tools/loss_record.py 32 200 20 > $out/loss_trace.json 2> $out/loss.err
 echo "loss done" >> $out/progress.txt
-rm -rf $out/pmc/*.db $out/mfma/*.db $out/stats/*.db 2>/dev/null || true
+rm -rf $out/pmc $out/mfma $out/stats/*.db 2>/dev/null || true   # (the raw counter tables are tens of MB; gpurun merges at most 64 MiB back)
 ls -la $out | tail -30

@@ -2,11 +2,11 @@
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc -o fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc -o write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline
-    python tools/pmc_reduce.py gpurun_out/pmc/fetch_counter_collection.csv gpurun_out/pmc/write_counter_collection.csv 6 > profiles/hbm_traffic_pmc.json
+    python tools/pmc_reduce.py gpurun_out/pmc/fetch_counter_collection.csv gpurun_out/pmc/write_counter_collection.csv > profiles/hbm_traffic_pmc.json
 
 Corrections (MI355X_MICROARCH.md, HBM / rocprofv3 section): both counters are in KB; on gfx950 FETCH_SIZE tallies 128-byte
-requests as 64 bytes, so the fetch side is doubled.  The third argument is the number of train steps the profiled command ran
-(bench.py: warm-up + timed + 3 profiled).  Kernel symbols are normalised to the names bench.py reports
+requests as 64 bytes, so the fetch side is doubled.  The number of train steps the profiled command ran is the number of optimizer launches in the
+trace (an optional third argument overrides it).  Kernel symbols are normalised to the names bench.py reports
 (`nt_kernel<bf16,2,128,4,0,3,1>`)."""
 import csv
 import json
@@ -65,21 +65,31 @@ def totals(path, counter):
 
 
 def main():
-    fetch_csv, write_csv, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    fetch_csv, write_csv = sys.argv[1], sys.argv[2]
     fkb, fl = totals(fetch_csv, "FETCH_SIZE")
-    wkb, _ = totals(write_csv, "WRITE_SIZE")
+    wkb, wl = totals(write_csv, "WRITE_SIZE")
+    # train steps of a pass = its optimizer launches: bench.py pre-conditions the device with a time-based, i.e. variable, number of
+    # untimed steps, so the two passes need not run the same number of steps and each side is normalised by its own count
+    nsteps = lambda l: l.get("adam_kernel", 0) + l.get("adam_amp_kernel", 0)
+    fs, ws = nsteps(fl), nsteps(wl)
+    if len(sys.argv) > 3:
+        fs = ws = int(sys.argv[3])
+    if fs <= 0 or ws <= 0:
+        raise SystemExit("pmc_reduce: no optimizer launch in a trace and no step count given")
     rows = []
     for s in fkb:
-        fetch_gb = 2.0 * fkb[s] * 1024 / 1e9
-        write_gb = wkb.get(s, 0.0) * 1024 / 1e9
-        rows.append({"kernel": s, "launches": fl[s], "fetch_GB_corrected": round(fetch_gb, 3), "write_GB": round(write_gb, 3),
-                     "per_launch_MB": round((fetch_gb + write_gb) * 1e3 / fl[s], 2)})
-    rows.sort(key=lambda r: -(r["fetch_GB_corrected"] + r["write_GB"]))
-    total = sum(r["fetch_GB_corrected"] + r["write_GB"] for r in rows)
+        fetch_gb = 2.0 * fkb[s] * 1024 / 1e9 / fs          # per train step
+        write_gb = wkb.get(s, 0.0) * 1024 / 1e9 / ws
+        lps = fl[s] / fs
+        rows.append({"kernel": s, "launches_per_step": round(lps, 2), "fetch_GB_per_step": round(fetch_gb, 4), "write_GB_per_step": round(write_gb, 4),
+                     "per_launch_MB": round((fetch_gb + write_gb) * 1e3 / lps, 2)})
+    rows.sort(key=lambda r: -(r["fetch_GB_per_step"] + r["write_GB_per_step"]))
+    total = sum(r["fetch_GB_per_step"] + r["write_GB_per_step"] for r in rows)
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 2 --warmup 1 "
                        "--no-cpu-baseline`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); counter "
-                       "unit KB; per_launch_MB = (corrected fetch + write) / launches",
-               "train_steps_in_run": steps, "per_step_GB": round(total / steps, 1), "kernels": rows}, sys.stdout, indent=1)
+                       "unit KB; every figure is per train step (each pass normalised by its own number of optimizer launches); "
+                       "per_launch_MB = (corrected fetch + write) / launches",
+               "train_steps_in_fetch_pass": fs, "train_steps_in_write_pass": ws, "per_step_GB": round(total, 1), "kernels": rows}, sys.stdout, indent=1)
 
 
 if __name__ == "__main__":

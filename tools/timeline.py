@@ -12,7 +12,9 @@ csv.field_size_limit(1 << 30)
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), symbol(r["Kernel_Name"]), r["Queue_Id"]) for r in rows)
 adam = [i for i, k in enumerate(ks) if k[2] == "adam_kernel"]
-step = int(sys.argv[2]) if len(sys.argv) > 2 else 3   # a timed step (warm-up steps come first)
+step = int(sys.argv[2]) if len(sys.argv) > 2 else -5   # a timed step: negative = counted from the end (bench.py ends with 3 event-bracketed steps; pre-conditioning and warm-up steps come first)
+if step < 0:
+    step += len(adam)
 lo, hi = adam[step - 1] + 1, adam[step] + 1
 seg = ks[lo:hi]
 t0, t1 = seg[0][0], max(k[1] for k in seg)
