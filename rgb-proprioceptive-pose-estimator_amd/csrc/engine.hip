@@ -319,7 +319,7 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
         }
         e->fold1 = getenv("RPE_BN1_FOLD") != nullptr;
         if (getenv("RPE_BN1_FOLD_MAX")) e->fold1_max = atoi(getenv("RPE_BN1_FOLD_MAX"));
-        e->fold_w = getenv("RPE_NO_WGRAD_FOLD") == nullptr && getenv("RPE_TN_REG") == nullptr;   // (the row-concatenated operand is an LDS-DMA path feature)
+        e->fold_w = getenv("RPE_NO_WGRAD_FOLD") == nullptr;
         if (e->fold_w) {
             if (getenv("RPE_WGRAD_FOLD_MAX")) e->fold_w_max = atoi(getenv("RPE_WGRAD_FOLD_MAX"));
             for (auto& b : e->blocks) {
