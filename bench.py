@@ -221,7 +221,13 @@ def main():
             w = now - t_w
             settled = prev is not None and abs(w - prev) <= 0.01 * prev
             prev = w
-            if (settled and now - t_pre >= PRECONDITION_MIN_S) or now - t_pre >= PRECONDITION_MAX_S:
+            stop = (settled and now - t_pre >= PRECONDITION_MIN_S) or now - t_pre >= PRECONDITION_MAX_S
+            if world > 1 or args.force_dist:
+                # every rank must run the SAME number of steps (each carries collectives): rank 0 decides for all
+                flag = torch.tensor([1 if stop else 0], dtype=torch.int32, device=dev)
+                dist.broadcast(flag, 0)
+                stop = bool(flag.item())
+            if stop:
                 break
         precondition_s = time.perf_counter() - t_pre
         for _ in range(args.warmup):

@@ -130,3 +130,26 @@ def test_rccl_backend_single_rank_staged_step():
     assert p.exitcode == 0
     assert backend == "nccl" and calls >= 5 and finite
     assert err < 1e-4
+
+
+def test_bench_two_ranks_sharing_one_gpu():
+    """The driver's multi-GPU command line (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`), rehearsed with two
+    gloo ranks on the one GPU at a small batch: both ranks must run the same number of steps (the pre-conditioning loop is time-based,
+    so rank 0 decides for all), rank 0 prints ONE JSON line with the whole-job throughput."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RPE_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "16", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
