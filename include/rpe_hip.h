@@ -233,6 +233,11 @@ int rpe_bn_backward_from_dz(int dtype, const void* dz, const void* y, const floa
 /* ------------------------------------------------------------------ pooling */
 /* replaces: nn.MaxPool2d(3, 2, 1) of the ResNet stem; idx keeps the winning tap. */
 int rpe_maxpool3x3s2_fwd(int dtype, const void* x, void* out, unsigned char* idx, int B, int H, int W, int C, void* stream);
+/* BatchNorm apply + ReLU and the 3x3 / stride 2 / pad 1 max pool behind it in one pass over the raw conv output y [B][H][W][C] (H, W even):
+ * a = relu(y * scale + shift) [B][H][W][C], out = maxpool(a) [B][H/2][W/2][C], idx = winner taps -- bitwise what rpe_bn_apply followed by
+ * rpe_maxpool3x3s2_fwd give (replaces bn1 -> relu -> maxpool of torchvision's ResNet stem, util/model_utils.py:136). */
+int rpe_bn_apply_maxpool3x3s2(int dtype, const void* y, const float* scale, const float* shift, void* a, void* out, unsigned char* idx, int B, int H,
+                              int W, int C, void* stream);
 int rpe_maxpool3x3s2_bwd(int dtype, const void* dout, const unsigned char* idx, const void* addend, void* dx, int B, int H, int W, int C,
                          void* stream);
 /* Stem backward in two passes over y (fused form of rpe_maxpool3x3s2_bwd + the aux head's scatter + rpe_bn_backward for the

@@ -88,6 +88,7 @@ _SPEC = {
     "rpe_bn_apply_res_bn": (I, [I, P, P, P, P, P, P, P, L, I, I, P, P]),
     "rpe_bn_backward": (I, [I, P, P, P, P, P, P, P, P, P, P, L, I, P, L, P, P, P]),
     "rpe_maxpool3x3s2_fwd": (I, [I, P, P, P, I, I, I, I, P]),
+    "rpe_bn_apply_maxpool3x3s2": (I, [I, P, P, P, P, P, P, I, I, I, I, P]),
     "rpe_maxpool3x3s2_bwd": (I, [I, P, P, P, P, I, I, I, I, P]),
     "rpe_stem_bwd": (I, [I, P, P, P, P, P, P, P, P, P, L, P, P, P, P, P, P, I, I, I, P, L, P, P, P]),
     "rpe_avgpool_fwd": (I, [I, P, P, I, I, I, P]),

@@ -666,9 +666,17 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
     TRY(capture_guard(e, stream, "resnet50_forward"));
     TRY(ensure_side(e));
     e->sync_next = 0;
-    TRY(conv_bn(e, st, e->x4, nullptr, 1, stream));
-    e->pending_bytes = conv_out_bytes(e, st) * 1.25 + (double)e->B * (st.Ho / 2) * (st.Wo / 2) * 64;   // a1 -> pool + winner index
-    PROF(e, RPE_PROF_OTHER, stream, rpe_maxpool3x3s2_fwd(e->dtype, st.a, e->pool, e->pool_idx, e->B, st.Ho, st.Wo, 64, stream));
+    static const bool pool_fuse_ok = getenv("RPE_NO_POOL_FUSE") == nullptr;
+    if (training && pool_fuse_ok && !((st.Ho | st.Wo) & 1)) {
+        // conv + statistics, then BatchNorm apply + ReLU + max pool in one pass over y (the separate pool pass re-read all of a1)
+        TRY(conv_bn(e, st, e->x4, nullptr, 1, stream, false, nullptr, nullptr, true));
+        e->pending_bytes = conv_out_bytes(e, st) * 2.25 + (double)e->B * (st.Ho / 2) * (st.Wo / 2) * 64;   // y -> a1, pool + winner index
+        PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_apply_maxpool3x3s2(e->dtype, st.y, st.scale, st.shift, st.a, e->pool, e->pool_idx, e->B, st.Ho, st.Wo, 64, stream));
+    } else {
+        TRY(conv_bn(e, st, e->x4, nullptr, 1, stream));
+        e->pending_bytes = conv_out_bytes(e, st) * 1.25 + (double)e->B * (st.Ho / 2) * (st.Wo / 2) * 64;   // a1 -> pool + winner index
+        PROF(e, RPE_PROF_OTHER, stream, rpe_maxpool3x3s2_fwd(e->dtype, st.a, e->pool, e->pool_idx, e->B, st.Ho, st.Wo, 64, stream));
+    }
     const void* x = e->pool;
     static const bool fwd_overlap = getenv("RPE_NO_FWD_OVERLAP") == nullptr;
     // training: the projection shortcut's BatchNorm is applied inside conv3's apply pass (no pass / normalised copy of its own);

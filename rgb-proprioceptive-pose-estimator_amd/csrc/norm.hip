@@ -339,6 +339,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_dz_kernel(const T* __restric
 // MaxPool 3x3 / stride 2 / pad 1 (ResNet stem).  Forward keeps the winning tap (0..8) per output
 // element so the backward is a gather.  Ties: first tap in (kh, kw) scan order, as torch does.
 // ---------------------------------------------------------------------------------------------
+// the CE winner taps of one chunk in one 4- / 8-byte store (CE single-byte stores were what bounded the pool pass: 3.4 TB/s)
+template <int CE> __device__ __forceinline__ void store_winners(unsigned char* dst, const unsigned char* bi) {
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lo |= (unsigned)bi[e] << (8 * e);
+    if (CE == 8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hi |= (unsigned)bi[4 + e] << (8 * e);
+        *(u32x2*)dst = u32x2{lo, hi};
+    } else {
+        *(unsigned*)dst = lo;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, unsigned char* __restrict__ idx,
                                                          int B, int H, int W, int C, int Ho, int Wo) {
@@ -369,9 +383,63 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
             }
         }
         *(u32x4*)(out + i * CE) = f_to_chunk<T>(best);
-        unsigned char* ip = idx + i * CE;
+        store_winners<CE>(idx + i * CE, bi);
+    }
+}
+
+// The stem's BatchNorm apply + ReLU and the max pool behind it in ONE pass over the conv output: a = relu(y * scale + shift) is written
+// (the aux head and the hooks read it) and pooled on the fly -- the separate pool pass re-read all of a (411 MB at 256 images).
+// One thread per pooled pixel and 16-byte channel chunk: it reads the 3 x 3 window of y (5 of the 9 chunks are its neighbours': cache
+// hits), writes the four a pixels of its own 2 x 2 block (taps (1..2, 1..2): every input pixel has exactly one owner; H and W even)
+// and the pooled chunk with its winner taps.  Values are compared AFTER rounding to T, ties / NaN exactly as maxpool_fwd_kernel on the
+// stored a: the results are bitwise those of bn_apply_kernel followed by maxpool_fwd_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_maxpool_kernel(const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              T* __restrict__ a, T* __restrict__ out, unsigned char* __restrict__ idx,
+                                                              int B, int H, int W, int C, int Ho, int Wo) {
+    constexpr int CE = Elem<T>::kChunk;
+    const int cpr = C / CE;
+    const long total = (long)B * Ho * Wo * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cpr);
+        long pix = i / cpr;
+        const int ow = (int)(pix % Wo); pix /= Wo;
+        const int oh = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        float sc[CE], sh[CE];
 #pragma unroll
-        for (int e = 0; e < CE; ++e) ip[e] = bi[e];
+        for (int e = 0; e < CE; ++e) { sc[e] = scale[cc * CE + e]; sh[e] = shift[cc * CE + e]; }
+        u32x4 raw[9];
+        bool ok[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int ih = oh * 2 - 1 + k / 3, iw = ow * 2 - 1 + k % 3;
+            ok[k] = ih >= 0 && ih < H && iw >= 0 && iw < W;
+            if (ok[k]) raw[k] = *(const u32x4*)(y + (((long)b * H + ih) * W + iw) * C + cc * CE);
+        }
+        float best[CE];
+        unsigned char bi[CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (!ok[k]) continue;
+            float v[CE];
+            chunk_to_f<T>(raw[k], v);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);   // bn_apply_kernel's expression
+            const u32x4 packed = f_to_chunk<T>(v);
+            if (k / 3 >= 1 && k % 3 >= 1) {   // this thread's own 2 x 2 block
+                const int ih = oh * 2 - 1 + k / 3, iw = ow * 2 - 1 + k % 3;
+                *(u32x4*)(a + (((long)b * H + ih) * W + iw) * C + cc * CE) = packed;
+            }
+            chunk_to_f<T>(packed, v);               // compare what the pool pass would have read back
+#pragma unroll
+            for (int e = 0; e < CE; ++e)
+                if (v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = (unsigned char)k; }
+        }
+        *(u32x4*)(out + i * CE) = f_to_chunk<T>(best);
+        store_winners<CE>(idx + i * CE, bi);
     }
 }
 
@@ -1023,6 +1091,21 @@ int rpe_maxpool3x3s2_fwd(int dtype, const void* x, void* out, unsigned char* idx
     else if (dtype == RPE_BF16) hipLaunchKernelGGL((maxpool_fwd_kernel<bf16>), dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out, idx, B, H, W, C, Ho, Wo);
     else if (dtype == RPE_F16) hipLaunchKernelGGL((maxpool_fwd_kernel<f16>), dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)out, idx, B, H, W, C, Ho, Wo);
     else return rpe_set_error(RPE_ERR_DTYPE, "maxpool: unsupported dtype");
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_bn_apply_maxpool3x3s2(int dtype, const void* y, const float* scale, const float* shift, void* a, void* out, unsigned char* idx, int B, int H,
+                              int W, int C, void* stream) {
+    note_kernel("bn_apply_maxpool_kernel");
+    if (B <= 0 || H <= 0 || W <= 0 || ((H | W) & 1) || C <= 0 || (C % 8)) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply_maxpool: H and W even, C % 8 == 0");
+    const int Ho = H / 2, Wo = W / 2;
+    const long n = (long)B * Ho * Wo * C;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == RPE_F32) hipLaunchKernelGGL((bn_apply_maxpool_kernel<float>), dim3(ew_grid(n / 4)), dim3(256), 0, s, (const float*)y, scale, shift, (float*)a, (float*)out, idx, B, H, W, C, Ho, Wo);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((bn_apply_maxpool_kernel<bf16>), dim3(ew_grid(n / 8)), dim3(256), 0, s, (const bf16*)y, scale, shift, (bf16*)a, (bf16*)out, idx, B, H, W, C, Ho, Wo);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((bn_apply_maxpool_kernel<f16>), dim3(ew_grid(n / 8)), dim3(256), 0, s, (const f16*)y, scale, shift, (f16*)a, (f16*)out, idx, B, H, W, C, Ho, Wo);
+    else return rpe_set_error(RPE_ERR_DTYPE, "bn_apply_maxpool: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;
 }

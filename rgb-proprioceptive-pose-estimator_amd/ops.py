@@ -366,6 +366,16 @@ def maxpool_fwd(x):
     return out, idx
 
 
+def bn_apply_maxpool(y, scale, shift):
+    """a = relu(y * scale + shift), pooled = maxpool3x3s2(a), winner taps -- one pass over y [B,H,W,C] (H, W even)"""
+    b, h, w, c = y.shape
+    a = torch.empty_like(y)
+    out = torch.empty((b, h // 2, w // 2, c), dtype=y.dtype, device=y.device)
+    idx = torch.empty((b, h // 2, w // 2, c), dtype=torch.uint8, device=y.device)
+    lib.rpe_bn_apply_maxpool3x3s2(dtype_code(y), _p(_chk(y, "y")), _p(scale), _p(shift), _p(a), _p(out), _p(idx), b, h, w, c, _stream())
+    return a, out, idx
+
+
 def maxpool_bwd(dout, idx, x_shape, addend=None):
     b, h, w, c = x_shape
     dx = torch.empty(tuple(x_shape), dtype=dout.dtype, device=dout.device)

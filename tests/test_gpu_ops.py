@@ -489,6 +489,23 @@ def test_maxpool_avgpool(dtype):
 
 # ------------------------------------------------------------------ heads
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,h,w,c", [(2, 16, 16, 64), (3, 6, 10, 64), (1, 2, 2, 8), (2, 112, 112, 64), (1, 8, 4, 128)])
+def test_bn_apply_maxpool_fused_is_bitwise_the_two_passes(dtype, b, h, w, c):
+    """the stem's BatchNorm apply + ReLU + max pool in one pass == rpe_bn_apply followed by rpe_maxpool3x3s2_fwd, bit for bit
+    (activated map, pooled map and winner taps; ties and all-zero windows included: ReLU makes many)"""
+    g = torch.Generator().manual_seed(b * 100 + h)
+    y = torch.randn(b, h, w, c, generator=g).to(dtype).to(DEV)
+    scale = (0.5 + torch.rand(c, generator=g)).to(DEV)
+    shift = (torch.rand(c, generator=g) - 0.7).to(DEV)
+    a_ref = ops.bn_apply(y, scale, shift, None, relu=True)
+    p_ref, i_ref = ops.maxpool_fwd(a_ref)
+    a, p, i = ops.bn_apply_maxpool(y, scale, shift)
+    assert torch.equal(a, a_ref) and torch.equal(p, p_ref) and torch.equal(i, i_ref)
+    ref = F.max_pool2d(F.relu(nchw(y.float().cpu()) * scale.cpu()[None, :, None, None] + shift.cpu()[None, :, None, None]).to(dtype).float(), 3, 2, 1)
+    assert rel_err(nchw(p), ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("use_depth", [False, True])
 def test_aux_and_depth_heads(dtype, use_depth):
     import ctypes

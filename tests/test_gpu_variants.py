@@ -19,9 +19,10 @@ ENGINE_VARIANTS = [
     # projection-shortcut branch on the main stream; dense early-feature gradient + separate pool / BN backward passes for the
     # stem; conv3 backward through a materialised dy on the main stream
     {"RPE_NO_FWD_OVERLAP": "1", "RPE_STEM_UNFUSED": "1", "RPE_NO_BN_FOLD": "1"},
-    # conv3 weight gradient from dy; fp32 atomics instead of slabs; the 3x3 convs gather their activation operand per tap (the path
+    # conv3 weight gradient from dy; fp32 atomics instead of slabs; the stem's BN apply and max pool as two passes (the eval path);
+    # the 3x3 convs gather their activation operand per tap (the path
     # the fp32 engines and rows too wide for the halo patch take)
-    {"RPE_NO_WGRAD_FOLD": "1", "RPE_WGRAD_ATOMIC": "1", "RPE_NO_HALO": "1"},
+    {"RPE_NO_WGRAD_FOLD": "1", "RPE_WGRAD_ATOMIC": "1", "RPE_NO_HALO": "1", "RPE_NO_POOL_FUSE": "1"},
     # bn1's backward folded into conv1's gradients (y-form; measured slower in the step, off by default), every layer
     {"RPE_BN1_FOLD": "1", "RPE_BN1_FOLD_MAX": "512"},
     # the projection shortcut's BN as a pass of its own; folded weight gradient for layers 1-2 only; inference convs unsplit

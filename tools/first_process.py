@@ -36,7 +36,34 @@ def sclk():
 
 
 print("setup %.1f s" % (time.perf_counter() - t_start), flush=True)
-w = 0
+
+
+def hbm_probe():
+    """TB/s of a 411 MB device-to-device copy (read + write), best of 3"""
+    x = torch.empty(411 * 1000 * 1000 // 2, dtype=torch.bfloat16, device="cuda")
+    y = torch.empty_like(x)
+    best = 0.0
+    for _ in range(3):
+        a, c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); y.copy_(x); c.record(); torch.cuda.synchronize()
+        best = max(best, 2 * x.numel() * 2 / (a.elapsed_time(c) * 1e-3) / 1e12)
+    return best
+
+
+def mfma_probe():
+    """TF/s of a bf16 8192^3 matmul through torch (hipBLASLt), best of 3"""
+    a = torch.randn(8192, 8192, device="cuda").bfloat16()
+    b = torch.randn(8192, 8192, device="cuda").bfloat16()
+    best = 0.0
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); (a @ b); e1.record(); torch.cuda.synchronize()
+        best = max(best, 2 * 8192 ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    return best
+
+
+print("probes at start: copy %.2f TB/s, matmul %.0f TF/s, clocks %s" % (hbm_probe(), mfma_probe(), sclk()), flush=True)
+w, acc, t_rep = 0, [], time.perf_counter()
 while time.perf_counter() - t_start < seconds:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -46,5 +73,10 @@ while time.perf_counter() - t_start < seconds:
     torch.cuda.synchronize()
     td = time.perf_counter() - t0
     w += 1
-    extra = ("  clocks: " + sclk()) if w % 10 == 1 else ""
-    print("t=%5.1f s  window %3d: %.2f ms/step (host issue %.2f ms/step)%s" % (time.perf_counter() - t_start, w, td * 100, th * 100, extra), flush=True)
+    acc.append((td * 100, th * 100))
+    if time.perf_counter() - t_rep >= 5.0:   # one line per ~5 s
+        ds = sorted(a for a, _ in acc)
+        print("t=%5.1f s  %3d windows: device ms/step min %.2f median %.2f max %.2f, host issue median %.2f" %
+              (time.perf_counter() - t_start, len(acc), ds[0], ds[len(ds) // 2], ds[-1], sorted(b for _, b in acc)[len(acc) // 2]), flush=True)
+        acc, t_rep = [], time.perf_counter()
+print("probes at end: copy %.2f TB/s, matmul %.0f TF/s, clocks %s" % (hbm_probe(), mfma_probe(), sclk()), flush=True)
