@@ -500,56 +500,71 @@ struct StemAux {
     const float* w;               // [64] aux conv weight
 };
 
-// One a1 pixel (b, h, w), CE channels from c0.  A pixel belongs to the pool windows oh in {(h+1)/2 [tap row 1 for even h, 0 for
-// odd h], (h-1)/2 [tap row 2, odd h only]} x the same in w: 1, 2 or 4 windows.  The callers walk a row with all lanes on the
-// same column parity, so which windows exist is wave-uniform (only the right/bottom edge is a lane predicate).
+// The 2 x 2 block of a1 pixels (2 oh + r, 2 ow + c), r, c in {0, 1}, CE channels from c0 -- the pixels pooled window (oh, ow) owns (its taps
+// (1..2, 1..2); every a1 pixel has exactly one owner: H, W even).  Their pool gradient comes from four windows: the own one, and for
+// the block's right column / bottom row the neighbours (oh, ow + 1) [tap column 0], (oh + 1, ow) [tap row 0], (oh + 1, ow + 1) [tap 0]:
+//   (0,0): tap 4 of W00                      (0,1): tap 5 of W00 + tap 3 of W01
+//   (1,0): tap 7 of W00 + tap 1 of W10       (1,1): tap 8 of W00 + tap 6 of W01 + tap 2 of W10 + tap 0 of W11
+// so a thread loads four (gradient chunk, winner word) pairs and four y chunks for four output chunks -- the per-PIXEL gather of
+// rounds 1-2 (1..4 windows each: 34 loads per four chunks, 1.7 TB/s) was bound by its loads, not by HBM.  The aux head's 2 x 2 max pool
+// has the same blocks: one winner per thread.  dz[r * 2 + c][e]; yy = the four y chunks.
 template <typename T>
-__device__ __forceinline__ void stem_dz_chunk(const T* __restrict__ dpool, const unsigned char* __restrict__ pidx, const StemAux& ax, const float* axw,
-                                              const float* sc, const float* sh, const float* yy, int b, int h, int w, int c0,
-                                              int H, int W, int Ho, int Wo, float* dz) {
+__device__ __forceinline__ void stem_dz_block(const T* __restrict__ dpool, const unsigned char* __restrict__ pidx, const StemAux& ax, const float* axw,
+                                              const float* sc, const float* sh, const float (*yy)[Elem<T>::kChunk], int b, int oh, int ow, int c0,
+                                              int Ho, int Wo, float (*dz)[Elem<T>::kChunk]) {
     constexpr int CE = Elem<T>::kChunk;
+    const long o00 = (((long)b * Ho + oh) * Wo + ow) * 64 + c0;
+    const bool right = ow + 1 < Wo, below = oh + 1 < Ho;
+    float d[4][CE];
+    unsigned long long taps[4];
+    auto window = [&](int k, long o, bool ok) {
+        if (ok) {
+            chunk_to_f<T>(*(const u32x4*)(dpool + o), d[k]);
+            taps[k] = CE == 8 ? *(const unsigned long long*)(pidx + o) : (unsigned long long)*(const unsigned*)(pidx + o);
+        } else {
 #pragma unroll
-    for (int e = 0; e < CE; ++e) dz[e] = 0.f;
-    const int oh_a = (h + 1) >> 1, kh_a = h + 1 - 2 * oh_a, ow_a = (w + 1) >> 1, kw_a = w + 1 - 2 * ow_a;
-    auto window = [&](int oh, int ow, int tap) {
-        const long o = (((long)b * Ho + oh) * Wo + ow) * 64 + c0;
-        float d[CE];
-        chunk_to_f<T>(*(const u32x4*)(dpool + o), d);
-        unsigned long long taps;   // the CE winner taps of this chunk in one load (o is a multiple of CE)
-        if (CE == 8) taps = *(const unsigned long long*)(pidx + o);
-        else taps = *(const unsigned*)(pidx + o);
-#pragma unroll
-        for (int e = 0; e < CE; ++e)
-            if (((taps >> (8 * e)) & 0xffull) == (unsigned long long)tap) dz[e] += d[e];
-    };
-    const bool row_a = oh_a < Ho, col_a = ow_a < Wo, row_b = h & 1, col_b = w & 1;
-    if (row_a && col_a) window(oh_a, ow_a, kh_a * 3 + kw_a);
-    if (row_a && col_b) window(oh_a, ow_a - 1, kh_a * 3 + 2);
-    if (row_b && col_a) window(oh_a - 1, ow_a, 6 + kw_a);
-    if (row_b && col_b) window(oh_a - 1, ow_a - 1, 8);
-    if (ax.dout) {
-        const int Ho2 = H >> 1, Wo2 = W >> 1;
-        const long pos = (long)(h >> 1) * Wo2 + (w >> 1);
-        const long flat = (long)b * Ho2 * Wo2 + pos;
-        if (ax.idx[flat] == (unsigned char)((h & 1) * 2 + (w & 1))) {
-            float g = ax.dout[(long)b * ax.ld + pos];
-            if (ax.depth_feat) g *= ax.depth_feat[flat];
-#pragma unroll
-            for (int e = 0; e < CE; ++e) dz[e] += g * axw[e];
+            for (int e = 0; e < CE; ++e) d[k][e] = 0.f;
+            taps[k] = ~0ull;   // (no tap is 255)
         }
+    };
+    window(0, o00, true);
+    window(1, o00 + 64, right);
+    window(2, o00 + (long)Wo * 64, below);
+    window(3, o00 + (long)Wo * 64 + 64, right && below);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+        const unsigned t0 = (unsigned)(taps[0] >> (8 * e)) & 0xffu, t1 = (unsigned)(taps[1] >> (8 * e)) & 0xffu;
+        const unsigned t2 = (unsigned)(taps[2] >> (8 * e)) & 0xffu, t3 = (unsigned)(taps[3] >> (8 * e)) & 0xffu;
+        dz[0][e] = t0 == 4u ? d[0][e] : 0.f;
+        dz[1][e] = (t0 == 5u ? d[0][e] : 0.f) + (t1 == 3u ? d[1][e] : 0.f);
+        dz[2][e] = (t0 == 7u ? d[0][e] : 0.f) + (t2 == 1u ? d[2][e] : 0.f);
+        dz[3][e] = (t0 == 8u ? d[0][e] : 0.f) + (t1 == 6u ? d[1][e] : 0.f) + (t2 == 2u ? d[2][e] : 0.f) + (t3 == 0u ? d[3][e] : 0.f);
+    }
+    if (ax.dout) {
+        const long pos = (long)oh * Wo + ow, flat = (long)b * Ho * Wo + pos;   // (the aux head pools the same 2 x 2 blocks: Ho = H / 2)
+        const int win = ax.idx[flat];
+        float g = ax.dout[(long)b * ax.ld + pos];
+        if (ax.depth_feat) g *= ax.depth_feat[flat];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < CE; ++e) dz[k][e] += win == k ? g * axw[e] : 0.f;
     }
 #pragma unroll
-    for (int e = 0; e < CE; ++e)
-        if (!(fmaf(yy[e], sc[e], sh[e]) > 0.f)) dz[e] = 0.f;   // the forward's expression (bn_apply_kernel)
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < CE; ++e)
+            if (!(fmaf(yy[k][e], sc[e], sh[e]) > 0.f)) dz[k][e] = 0.f;   // the forward's expression (bn_apply_kernel)
 }
 
-// pass 1: block partial sums of dz and dz*xhat -> part [gridDim.x][2][64]
+// pass 1: block partial sums of dz and dz*xhat -> part [gridDim.x][2][64].  A block owns `rows_per_block` consecutive POOLED rows
+// (b, oh) = two image rows each (a contiguous span of y); thread = (pooled pixel lane, 16-byte channel chunk).
 template <typename T>
 __global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(const T* __restrict__ dpool, const unsigned char* __restrict__ pidx, const StemAux ax,
                                                              const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd, int B, int H, int W,
                                                              int Ho, int Wo, int rows_per_block, float* __restrict__ part) {
-    constexpr int CE = Elem<T>::kChunk, CPR = 64 / CE, PPB = 256 / CPR;   // chunks per pixel, pixels per block pass
+    constexpr int CE = Elem<T>::kChunk, CPR = 64 / CE, PPB = 256 / CPR;   // chunks per pixel, pooled pixels per block pass
     __shared__ float sh[PPB][64][2];
     const int cc = threadIdx.x % CPR, pl = threadIdx.x / CPR, c0 = cc * CE;
     float sc[CE], sf[CE], mu[CE], is[CE], s1[CE], s2[CE];
@@ -558,21 +573,22 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(const T* __restric
     float axw[CE];
 #pragma unroll
     for (int e = 0; e < CE; ++e) axw[e] = ax.dout ? ax.w[c0 + e] : 0.f;
-    // one image row (b, h) at a time per block: the row decomposition is one scalar division per row, not two 64-bit
-    // divisions per element (which, not HBM, bounded the first version of this kernel: 0.5 ms per pass).  A block owns
-    // `rows_per_block` CONSECUTIVE rows (a contiguous span of y: see bn_apply_kernel on why blocks do not stride over the tensor)
-    const int row_end = min(B * H, ((int)blockIdx.x + 1) * rows_per_block);
+    const int row_end = min(B * Ho, ((int)blockIdx.x + 1) * rows_per_block);
     for (int row = blockIdx.x * rows_per_block; row < row_end; ++row) {
-        const int b = row / H, h = row - b * H;
-        for (int pw = 0; pw < 2; ++pw)   // all lanes on the same column parity: the set of pool windows is wave-uniform
-            for (int w = 2 * pl + pw; w < W; w += 2 * PPB) {
-                const long pix = (long)row * W + w;
-                float yy[CE], dz[CE];
-                chunk_to_f<T>(*(const u32x4*)(y + pix * 64 + c0), yy);
-                stem_dz_chunk<T>(dpool, pidx, ax, axw, sc, sf, yy, b, h, w, c0, H, W, Ho, Wo, dz);
+        const int b = row / Ho, oh = row - b * Ho;
+        for (int ow = pl; ow < Wo; ow += PPB) {
+            const long p00 = (((long)b * H + 2 * oh) * W + 2 * ow) * 64 + c0;
+            float yy[4][CE], dz[4][CE];
+            chunk_to_f<T>(*(const u32x4*)(y + p00), yy[0]);
+            chunk_to_f<T>(*(const u32x4*)(y + p00 + 64), yy[1]);
+            chunk_to_f<T>(*(const u32x4*)(y + p00 + (long)W * 64), yy[2]);
+            chunk_to_f<T>(*(const u32x4*)(y + p00 + (long)W * 64 + 64), yy[3]);
+            stem_dz_block<T>(dpool, pidx, ax, axw, sc, sf, yy, b, oh, ow, c0, Ho, Wo, dz);
 #pragma unroll
-                for (int e = 0; e < CE; ++e) { s1[e] += dz[e]; s2[e] += dz[e] * (yy[e] - mu[e]) * is[e]; }
-            }
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < CE; ++e) { s1[e] += dz[k][e]; s2[e] += dz[k][e] * (yy[k][e] - mu[e]) * is[e]; }
+        }
     }
 #pragma unroll
     for (int e = 0; e < CE; ++e) { sh[pl][c0 + e][0] = s1[e]; sh[pl][c0 + e][1] = s2[e]; }
@@ -606,19 +622,23 @@ __global__ __launch_bounds__(256) void stem_bwd_apply_kernel(const T* __restrict
     float axw[CE];
 #pragma unroll
     for (int e = 0; e < CE; ++e) axw[e] = ax.dout ? ax.w[c0 + e] : 0.f;
-    const int row_end = min(B * H, ((int)blockIdx.x + 1) * rows_per_block);
+    const int row_end = min(B * Ho, ((int)blockIdx.x + 1) * rows_per_block);
     for (int row = blockIdx.x * rows_per_block; row < row_end; ++row) {
-        const int b = row / H, h = row - b * H;
-        for (int pw = 0; pw < 2; ++pw)
-            for (int w = 2 * pl + pw; w < W; w += 2 * PPB) {
-                const long pix = (long)row * W + w;
-                float yy[CE], dz[CE];
-                chunk_to_f<T>(*(const u32x4*)(y + pix * 64 + c0), yy);
-                stem_dz_chunk<T>(dpool, pidx, ax, axw, sc, sf, yy, b, h, w, c0, H, W, Ho, Wo, dz);
+        const int b = row / Ho, oh = row - b * Ho;
+        for (int ow = pl; ow < Wo; ow += PPB) {
+            const long p00 = (((long)b * H + 2 * oh) * W + 2 * ow) * 64 + c0;
+            const long off[4] = {p00, p00 + 64, p00 + (long)W * 64, p00 + (long)W * 64 + 64};
+            float yy[4][CE], dz[4][CE];
 #pragma unroll
-                for (int e = 0; e < CE; ++e) dz[e] = fmaf(k0[e], dz[e], fmaf(k2[e], yy[e], k1[e]));
-                *(u32x4*)(dy + pix * 64 + c0) = f_to_chunk<T>(dz);
+            for (int k = 0; k < 4; ++k) chunk_to_f<T>(*(const u32x4*)(y + off[k]), yy[k]);
+            stem_dz_block<T>(dpool, pidx, ax, axw, sc, sf, yy, b, oh, ow, c0, Ho, Wo, dz);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int e = 0; e < CE; ++e) dz[k][e] = fmaf(k0[e], dz[k][e], fmaf(k2[e], yy[k][e], k1[e]));
+                *(u32x4*)(dy + off[k]) = f_to_chunk<T>(dz[k]);
             }
+        }
     }
 }
 
@@ -952,10 +972,10 @@ int stem_bwd_launch(const void* dpool, const unsigned char* pidx, const StemAux&
     // the gather is latency-bound (a few dependent loads per pixel): as many rows in flight as the partial-sum workspace allows
     long nbl = part_floats / (2 * 64);
     if (nbl > 8192) nbl = 8192;
-    if (nbl > (long)B * H) nbl = (long)B * H;
+    if (nbl > (long)B * Ho) nbl = (long)B * Ho;
     if (nbl < 1) return rpe_set_error(RPE_ERR_WORKSPACE, "stem_bwd: partial-sum workspace too small");
-    const int rpb = (int)(((long)B * H + nbl - 1) / nbl);          // consecutive image rows per block
-    const int nb = (int)(((long)B * H + rpb - 1) / rpb);
+    const int rpb = (int)(((long)B * Ho + nbl - 1) / nbl);          // consecutive POOLED rows (two image rows each) per block
+    const int nb = (int)(((long)B * Ho + rpb - 1) / rpb);
     note_kernel("stem_bwd_reduce_kernel");
     hipLaunchKernelGGL((stem_bwd_reduce_kernel<T>), dim3(nb), dim3(256), 0, s, (const T*)dpool, pidx, ax, (const T*)y, scale, shift, mean, invstd, B, H, W,
                        Ho, Wo, rpb, part);
@@ -965,8 +985,8 @@ int stem_bwd_launch(const void* dpool, const unsigned char* pidx, const StemAux&
     prof_split(s, "reduce_finalize_kernel<BnBwdFin>");
     if (int e = reduce_finalize(part, nb, 64, dpart, BnBwdFin{(double)B * H * W, dgamma, dbeta, c1, c2}, s)) return e;
     prof_split(s, "stem_bwd_apply_kernel");
-    const int rpa = (B * H + (1 << 20) - 1) >> 20;   // one image row (14 KB of y at 112 pixels) per block, up to 2^20 blocks
-    hipLaunchKernelGGL((stem_bwd_apply_kernel<T>), dim3((B * H + rpa - 1) / rpa), dim3(256), 0, s, (const T*)dpool, pidx, ax, (const T*)y, scale, shift, mean, invstd,
+    const int rpa = (B * Ho + (1 << 20) - 1) >> 20;   // one pooled row (two image rows: 28 KB of y at 112 pixels) per block, up to 2^20 blocks
+    hipLaunchKernelGGL((stem_bwd_apply_kernel<T>), dim3((B * Ho + rpa - 1) / rpa), dim3(256), 0, s, (const T*)dpool, pidx, ax, (const T*)y, scale, shift, mean, invstd,
                        gamma, (const float*)c1, (const float*)c2, (T*)dy, B, H, W, Ho, Wo, rpa);
     RPE_CHECK_LAUNCH();
     return 0;
