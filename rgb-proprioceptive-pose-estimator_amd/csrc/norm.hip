@@ -969,9 +969,8 @@ int stem_bwd_launch(const void* dpool, const unsigned char* pidx, const StemAux&
                     const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta, void* dy, int B, int H, int W,
                     float* part, long part_floats, float* c1c2, double* dpart, hipStream_t s) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    // the gather is latency-bound (a few dependent loads per pixel): as many rows in flight as the partial-sum workspace allows
     long nbl = part_floats / (2 * 64);
-    if (nbl > 8192) nbl = 8192;
+    if (nbl > 1024) nbl = 1024;   // (512 .. 8192 blocks measured within 5 %: the block form is no longer latency-bound)
     if (nbl > (long)B * Ho) nbl = (long)B * Ho;
     if (nbl < 1) return rpe_set_error(RPE_ERR_WORKSPACE, "stem_bwd: partial-sum workspace too small");
     const int rpb = (int)(((long)B * Ho + nbl - 1) / nbl);          // consecutive POOLED rows (two image rows each) per block
@@ -985,7 +984,7 @@ int stem_bwd_launch(const void* dpool, const unsigned char* pidx, const StemAux&
     prof_split(s, "reduce_finalize_kernel<BnBwdFin>");
     if (int e = reduce_finalize(part, nb, 64, dpart, BnBwdFin{(double)B * H * W, dgamma, dbeta, c1, c2}, s)) return e;
     prof_split(s, "stem_bwd_apply_kernel");
-    const int rpa = (B * Ho + (1 << 20) - 1) >> 20;   // one pooled row (two image rows: 28 KB of y at 112 pixels) per block, up to 2^20 blocks
+    const int rpa = 2;   // two pooled rows (four image rows: 57 KB of y at 112 pixels) per block
     hipLaunchKernelGGL((stem_bwd_apply_kernel<T>), dim3((B * Ho + rpa - 1) / rpa), dim3(256), 0, s, (const T*)dpool, pidx, ax, (const T*)y, scale, shift, mean, invstd,
                        gamma, (const float*)c1, (const float*)c2, (T*)dy, B, H, W, Ho, Wo, rpa);
     RPE_CHECK_LAUNCH();
