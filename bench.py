@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 CATS = ["conv_fwd", "conv_dgrad", "conv_wgrad", "bn_fwd", "bn_bwd", "other"]
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-PRECONDITION_MIN_S, PRECONDITION_MAX_S = 1.5, 12.0   # untimed train steps before the W warm-up steps (reported in the line as `precondition_s`)
+PRECONDITION_MIN_S, PRECONDITION_QUIET_S, PRECONDITION_MAX_S = 3.0, 3.0, 20.0   # untimed train steps before the W warm-up steps (reported in the line as `precondition_s`)
 
 
 def log(*a):
@@ -207,11 +207,13 @@ def main():
             run_step()
     else:
         run_step = lambda: train_step(model, batch, criterion, opt, train_obj_pose, "train", sync)
-        # Device pre-conditioning, BEFORE the W warm-up steps and outside every timed region: the first process on a freshly leased box
-        # has measured 5-10 % slow for its first seconds (profiles/r03_ab_wgrad_hold.txt: first run 22.08 ms/step, the same build 20.05 a
-        # minute later; r03_ab_stream_ew.txt: 22.47 vs 20.32) -- with --warmup 5 those seconds would land in the timed steps.  Windows of 10
-        # untimed steps are run until two consecutive windows agree within 1 % (at least PRECONDITION_MIN_S, at most PRECONDITION_MAX_S).
-        t_pre, prev = time.perf_counter(), None
+        # Device pre-conditioning, BEFORE the W warm-up steps and outside every timed region.  A freshly PROVISIONED box runs 5-12 % slow
+        # at first and recovers over tens of seconds of load (first process 22.1 ms/step, the next ones 20.1, 20.0, 19.9, 19.8:
+        # profiles/r03_ab_head_side.txt; 20.9 first, 19.6 two minutes later: profiles/r03_bench_first_process_on_fresh_box.json; a box that
+        # has run before is at full speed from its second window: tools/first_process.py) -- with --warmup 5 those seconds would land in
+        # the timed steps.  Windows of 10 untimed steps are run until the best window time has not improved by 0.3 % for
+        # PRECONDITION_QUIET_S seconds (at least PRECONDITION_MIN_S, at most PRECONDITION_MAX_S in all).
+        t_pre, best, t_best = time.perf_counter(), None, None
         while True:
             t_w = time.perf_counter()
             for _ in range(10):
@@ -219,9 +221,9 @@ def main():
             torch.cuda.synchronize()
             now = time.perf_counter()
             w = now - t_w
-            settled = prev is not None and abs(w - prev) <= 0.01 * prev
-            prev = w
-            stop = (settled and now - t_pre >= PRECONDITION_MIN_S) or now - t_pre >= PRECONDITION_MAX_S
+            if best is None or w < best * 0.997:
+                best, t_best = (w if best is None else min(best, w)), now
+            stop = (now - t_best >= PRECONDITION_QUIET_S and now - t_pre >= PRECONDITION_MIN_S) or now - t_pre >= PRECONDITION_MAX_S
             if world > 1 or args.force_dist:
                 # every rank must run the SAME number of steps (each carries collectives): rank 0 decides for all
                 flag = torch.tensor([1 if stop else 0], dtype=torch.int32, device=dev)
