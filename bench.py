@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 CATS = ["conv_fwd", "conv_dgrad", "conv_wgrad", "bn_fwd", "bn_bwd", "other"]
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-PRECONDITION_MIN_S, PRECONDITION_QUIET_S, PRECONDITION_MAX_S = 3.0, 3.0, 20.0   # untimed train steps before the W warm-up steps (reported in the line as `precondition_s`)
+PRECONDITION_MIN_S, PRECONDITION_QUIET_S, PRECONDITION_MAX_S = 10.0, 3.0, 25.0   # untimed train steps before the W warm-up steps (reported in the line as `precondition_s`)
 
 
 def log(*a):
@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precondition-min", type=float, default=PRECONDITION_MIN_S,
+                    help="least seconds of untimed steps before the W warm-up steps (a freshly provisioned box runs 5-12 %% slow for its first ~10 s of load; A/B tools on an already warm box pass 2)")
     ap.add_argument("--model", default="no", choices=["no", "n", "td", "tdo", "tdo_v2"],
                     help="model family: no = NaiveObjectStateEstimator (BASELINE configs[1], the default and the metric's workload); td / tdo / tdo_v2 = the "
                          "sequence models of configs[2..4] at (S, N) = (4, batch/4), latent 512, hidden 512 (proprio hidden 64)")
@@ -211,8 +213,10 @@ def main():
         # at first and recovers over tens of seconds of load (first process 22.1 ms/step, the next ones 20.1, 20.0, 19.9, 19.8:
         # profiles/r03_ab_head_side.txt; 20.9 first, 19.6 two minutes later: profiles/r03_bench_first_process_on_fresh_box.json; a box that
         # has run before is at full speed from its second window: tools/first_process.py) -- with --warmup 5 those seconds would land in
-        # the timed steps.  Windows of 10 untimed steps are run until the best window time has not improved by 0.3 % for
-        # PRECONDITION_QUIET_S seconds (at least PRECONDITION_MIN_S, at most PRECONDITION_MAX_S in all).
+        # the timed steps.  The slow state is a PLATEAU (23.1 ms/step for the whole first process -- 3.6 s of pre-conditioning + 25 steps --
+        # then 19.7 in the next process, which still began slow and recovered 4 s in: about 10 s of load in all), so "two windows agree"
+        # cannot detect it: windows of 10 untimed steps are run for at least --precondition-min seconds (default PRECONDITION_MIN_S)
+        # and until the best window time has not improved by 0.3 % for PRECONDITION_QUIET_S seconds (at most PRECONDITION_MAX_S in all).
         t_pre, best, t_best = time.perf_counter(), None, None
         while True:
             t_w = time.perf_counter()
@@ -223,7 +227,7 @@ def main():
             w = now - t_w
             if best is None or w < best * 0.997:
                 best, t_best = (w if best is None else min(best, w)), now
-            stop = (now - t_best >= PRECONDITION_QUIET_S and now - t_pre >= PRECONDITION_MIN_S) or now - t_pre >= PRECONDITION_MAX_S
+            stop = (now - t_best >= PRECONDITION_QUIET_S and now - t_pre >= args.precondition_min) or now - t_pre >= max(PRECONDITION_MAX_S, args.precondition_min)
             if world > 1 or args.force_dist:
                 # every rank must run the SAME number of steps (each carries collectives): rank 0 decides for all
                 flag = torch.tensor([1 if stop else 0], dtype=torch.int32, device=dev)

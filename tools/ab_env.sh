@@ -8,6 +8,6 @@ out=gpurun_out/ab_$var.txt
 for v in "$@"; do
   echo "== $var=$v" >> $out
   if [ "$v" = "-" ]; then unset $var; else export $var=$v; fi   # "-": the variable is unset for this run
-  timeout -k 10 200 python bench.py --steps 30 --warmup 8 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])" >> $out
+  timeout -k 10 200 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --precondition-min 2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])" >> $out
 done
 cat $out

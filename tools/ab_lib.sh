@@ -9,7 +9,7 @@ out=gpurun_out/ab_lib.txt
 for i in $(seq 1 $n); do
   for lib in "" "$other"; do
     echo "== ${lib:-this tree}" >> $out
-    RPE_LIB_PATH=$lib timeout -k 10 300 python bench.py --steps 30 --warmup 8 --no-cpu-baseline "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])" >> $out
+    RPE_LIB_PATH=$lib timeout -k 10 300 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --precondition-min 2 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])" >> $out
   done
 done
 cat $out

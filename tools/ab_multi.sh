@@ -7,6 +7,6 @@ out=gpurun_out/ab_multi.txt
 for cfg in "$@"; do
   echo "== $cfg" >> $out
   if [ "$cfg" = "base" ]; then pre=""; else pre="env $cfg"; fi
-  $pre timeout -k 10 200 python bench.py --steps 30 --warmup 8 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])" >> $out
+  $pre timeout -k 10 200 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --precondition-min 2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])" >> $out
 done
 cat $out

@@ -10,7 +10,7 @@ here=$(pwd)
 for i in $(seq 1 $n); do
   for t in "$here" "$other"; do
     echo "== $t" >> $out
-    (cd $t && timeout -k 10 200 python bench.py --steps 30 --warmup 8 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])") >> $out
+    (cd $t && timeout -k 10 200 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --precondition-min 2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])") >> $out
   done
 done
 cat $out
