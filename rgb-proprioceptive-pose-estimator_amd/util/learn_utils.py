@@ -149,7 +149,7 @@ class GraphedRolloutFrame:
     """One eval-mode rollout frame (BN folded into the convs, LSTM state carried in place on the device) as a hipGraph:
     the per-frame path of rollout() (util/learn_utils.py:322-323,342,446 of the reference) is launch-bound at batch 1."""
 
-    def __init__(self, model, img, depth, x0bar, warmup=2):
+    def __init__(self, model, img, depth, x0bar, warmup=2, calibrate=8):
         self.model = model
         model.eval()
         self.img, self.x0bar = img.clone(), x0bar.clone()
@@ -165,8 +165,37 @@ class GraphedRolloutFrame:
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.out = model(self.img, self.depth, self.x0bar)
         self._keep = _graph_keepalive(model)
+        # A replay is worth it only where the runtime launches the graph cheaply.  On the round-3 boxes the SAME captured frame
+        # replayed in 0.56 ms in one process and in 3.2 ms in the next (hipGraphLaunch itself taking 2.6 ms of host time; round 2's
+        # tree shows the same on these boxes: profiles/r03_rollout_latency.txt) against 1.1-1.3 ms for the eager frame -- so both are
+        # timed here, over `calibrate` frames each, and the slower one is dropped.  (These frames advance the carried LSTM state like
+        # the warm-up frames do: the caller starts its episode with reset_initial_state afterwards.)
+        self.replay_ms = self.eager_ms = None
+        if calibrate > 0:
+            def timed(fn):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(calibrate):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / calibrate * 1e3
+            with torch.no_grad():
+                self.graph.replay()
+                self.replay_ms = timed(self.graph.replay)
+                self.eager_ms = timed(lambda: model(self.img, self.depth, self.x0bar))
+            if self.replay_ms > self.eager_ms:
+                self.graph = None
+                self._keep = None
+
+    @property
+    def replaying(self):
+        return self.graph is not None
 
     def __call__(self, img, depth, x0bar):
+        if self.graph is None:   # (the eager frame measured faster than the replay on this box)
+            dev = self.img.device
+            with torch.no_grad():
+                return self.model(img.to(dev, non_blocking=True), None if depth is None else depth.to(dev, non_blocking=True), x0bar.to(dev, non_blocking=True))
         self.img.copy_(img, non_blocking=True)
         self.x0bar.copy_(x0bar, non_blocking=True)
         if self.depth is not None:

@@ -451,11 +451,18 @@ def test_graphed_rollout_frame_matches_eager():
     with torch.no_grad():
         eager = [model(*f).clone() for f in frames]
     model.reset_initial_state(1)
-    g = GraphedRolloutFrame(model, *frames[0])
+    g = GraphedRolloutFrame(model, *frames[0], calibrate=0)   # (no calibration: the replay itself is under test)
+    assert g.replaying
     model.reset_initial_state(1)          # the warm-up frames advanced the carried state: start the episode again (in place)
     graphed = [g(*f).clone() for f in frames]
     for a, c in zip(eager, graphed):
         assert torch.allclose(a, c, rtol=1e-5, atol=1e-6)
+    # calibrated (the default): replay and eager frame are timed and the faster one serves the frames -- same results either way
+    g2 = GraphedRolloutFrame(model, *frames[0])
+    assert g2.replay_ms > 0 and g2.eager_ms > 0 and g2.replaying == (g2.replay_ms <= g2.eager_ms)
+    model.reset_initial_state(1)
+    for a, f in zip(eager, frames):
+        assert torch.allclose(a, g2(*f).clone(), rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("opt_cls", ["fused", "torch"])

@@ -35,7 +35,7 @@ def bench(name, make, dtype):
     dt = (time.perf_counter() - t0) / N
     # the same frame as ONE captured hipGraph (util.learn_utils.GraphedRolloutFrame)
     from rgb_proprioceptive_pose_estimator_amd.util.learn_utils import GraphedRolloutFrame
-    g = GraphedRolloutFrame(model, img, None, x0)
+    g = GraphedRolloutFrame(model, img, None, x0, calibrate=0)   # (the replay itself; GraphedRolloutFrame's default times both and keeps the faster)
     for _ in range(10):
         g(img, None, x0)
     torch.cuda.synchronize()
