@@ -687,7 +687,11 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
         ConvL &c1 = e->convs[b.c1], &c2 = e->convs[b.c2], &c3 = e->convs[b.c3];
         const void* idn = x;
         hipEvent_t ds_done = nullptr;
-        if (b.cd >= 0 && e->overlap && e->side && fwd_overlap) {
+        // (training only.  An INFERENCE frame stays on one stream: with the fork / join to the second stream a batch-1 frame took 3-4 ms
+        // instead of 1.1 (eager) / 0.45 (captured graph replayed; hipGraphLaunch itself 2.6 ms on the host) in some processes on the
+        // round-3 boxes -- which model is hit changes from process to process, profiles/r03_rollout_latency.txt -- and at batch 1 the
+        // branch has nothing to overlap with anyway)
+        if (b.cd >= 0 && e->overlap && e->side && fwd_overlap && training) {
             // projection shortcut (conv + BN, no ReLU): independent of conv1..conv2, joined before conv3's BN adds it
             ConvL& cd = e->convs[b.cd];
             hipEvent_t x_ready = sync_event(e);

@@ -154,35 +154,39 @@ class GraphedRolloutFrame:
         model.eval()
         self.img, self.x0bar = img.clone(), x0bar.clone()
         self.depth = None if depth is None else depth.clone()
+        def timed(fn):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(calibrate):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / calibrate * 1e3
+
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        self.replay_ms = self.eager_ms = None
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(warmup):
                 model(self.img, self.depth, self.x0bar)
+            # A replay is worth it only where the runtime launches the graph cheaply: both forms are timed over `calibrate` frames and the
+            # slower one is dropped (see below).  The eager frames come BEFORE the capture: the captured frame bakes in the addresses of
+            # the carried LSTM state as the last eager frame left them.  (Like the warm-up frames they advance that state: the caller
+            # starts its episode with reset_initial_state afterwards.)
+            if calibrate > 0:
+                self.eager_ms = timed(lambda: model(self.img, self.depth, self.x0bar))
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.out = model(self.img, self.depth, self.x0bar)
         self._keep = _graph_keepalive(model)
-        # A replay is worth it only where the runtime launches the graph cheaply.  On the round-3 boxes the SAME captured frame
-        # replayed in 0.56 ms in one process and in 3.2 ms in the next (hipGraphLaunch itself taking 2.6 ms of host time; round 2's
-        # tree shows the same on these boxes: profiles/r03_rollout_latency.txt) against 1.1-1.3 ms for the eager frame -- so both are
-        # timed here, over `calibrate` frames each, and the slower one is dropped.  (These frames advance the carried LSTM state like
-        # the warm-up frames do: the caller starts its episode with reset_initial_state afterwards.)
-        self.replay_ms = self.eager_ms = None
+        # On the round-3 boxes a captured frame that forks to the engine's second stream replayed in 0.56 ms in one process and in
+        # 3.2 ms in the next (hipGraphLaunch itself 2.6 ms of host time; round 2's tree behaves the same there:
+        # profiles/r03_rollout_latency.txt); the engine now keeps a captured inference frame on ONE stream (0.45 ms, reliably), and
+        # this check stays as the guard: replay slower than the eager frame -> the eager frame serves.
         if calibrate > 0:
-            def timed(fn):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(calibrate):
-                    fn()
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t0) / calibrate * 1e3
-            with torch.no_grad():
-                self.graph.replay()
-                self.replay_ms = timed(self.graph.replay)
-                self.eager_ms = timed(lambda: model(self.img, self.depth, self.x0bar))
+            self.graph.replay()
+            self.replay_ms = timed(self.graph.replay)
             if self.replay_ms > self.eager_ms:
                 self.graph = None
                 self._keep = None
