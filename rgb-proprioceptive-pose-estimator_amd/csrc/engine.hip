@@ -581,11 +581,19 @@ static int ensure_side(rpe_resnet50* e) {
     if (e->overlap && !e->side) {
         if (getenv("RPE_NO_OVERLAP")) e->overlap = false;
         else {
-            // weight gradients are off the critical path (the data-gradient chain is): the second stream gets the LOWEST dispatch
-            // priority (measured on one box, three alternations: 20.86 vs 20.98 ms/step at equal priority, 21.41 at high)
+            // NORMAL dispatch priority.  Round 2 gave the second stream the LOWEST priority (weight gradients are off the critical path:
+            // 20.86 vs 20.98 ms/step then).  Round 3 found that fragile: streams are dealt to a few hardware queues in creation order, and
+            // a LOW-priority stream created as the 4th .. 8th stream of the process (three or more streams made before it by the host
+            // framework, a communication library, a data loader) is starved outright -- 28.1-28.8 ms/step instead of 19.6, and the first
+            // process on a freshly provisioned box measured 22-26 ms the same way -- while a normal-priority stream runs 19.53-19.58 ms/step
+            // wherever it lands (profiles/r03_ab_stream_priority.txt).  RPE_SIDE_LOW_PRIO=1 restores the round-2 choice.
             int least = 0, greatest = 0;
             HIPTRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIPTRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, least));
+            static const bool low = getenv("RPE_SIDE_LOW_PRIO") != nullptr;
+            // RPE_TEST_STREAM_SKIP=n: n streams created first, as another component of the host process might (A/B of the above)
+            const int skip = getenv("RPE_TEST_STREAM_SKIP") ? atoi(getenv("RPE_TEST_STREAM_SKIP")) : 0;
+            for (int i = 0; i < skip; ++i) { hipStream_t d; HIPTRY(hipStreamCreateWithFlags(&d, hipStreamNonBlocking)); }
+            HIPTRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, low ? least : 0));
         }
     }
     return 0;
