@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 CATS = ["conv_fwd", "conv_dgrad", "conv_wgrad", "bn_fwd", "bn_bwd", "other"]
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-PRECONDITION_MIN_S, PRECONDITION_QUIET_S, PRECONDITION_MAX_S = 10.0, 3.0, 25.0   # untimed train steps before the W warm-up steps (reported in the line as `precondition_s`)
+PRECONDITION_MIN_S, PRECONDITION_QUIET_S, PRECONDITION_MAX_S = 3.0, 2.0, 15.0   # untimed train steps before the W warm-up steps (reported in the line as `precondition_s`)
 
 
 def log(*a):
@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precondition-min", type=float, default=PRECONDITION_MIN_S,
-                    help="least seconds of untimed steps before the W warm-up steps (a freshly provisioned box runs 5-12 %% slow for its first ~10 s of load; A/B tools on an already warm box pass 2)")
+                    help="least seconds of untimed 10-step windows before the W warm-up steps")
     ap.add_argument("--model", default="no", choices=["no", "n", "td", "tdo", "tdo_v2"],
                     help="model family: no = NaiveObjectStateEstimator (BASELINE configs[1], the default and the metric's workload); td / tdo / tdo_v2 = the "
                          "sequence models of configs[2..4] at (S, N) = (4, batch/4), latent 512, hidden 512 (proprio hidden 64)")
@@ -207,16 +207,15 @@ def main():
         run_step = lambda: graphed(batch)
         for _ in range(max(0, args.warmup - graphed.warmup_steps)):
             run_step()
+        _z = torch.zeros((), device=dev)
+        torch.zeros(1, dtype=torch.bool, device=dev)[0] = _z != _z   # (loads the two small kernels of the timed loop's NaN test: see below)
     else:
         run_step = lambda: train_step(model, batch, criterion, opt, train_obj_pose, "train", sync)
-        # Device pre-conditioning, BEFORE the W warm-up steps and outside every timed region.  A freshly PROVISIONED box runs 5-12 % slow
-        # at first and recovers over tens of seconds of load (first process 22.1 ms/step, the next ones 20.1, 20.0, 19.9, 19.8:
-        # profiles/r03_ab_head_side.txt; 20.9 first, 19.6 two minutes later: profiles/r03_bench_first_process_on_fresh_box.json; a box that
-        # has run before is at full speed from its second window: tools/first_process.py) -- with --warmup 5 those seconds would land in
-        # the timed steps.  The slow state is a PLATEAU (23.1 ms/step for the whole first process -- 3.6 s of pre-conditioning + 25 steps --
-        # then 19.7 in the next process, which still began slow and recovered 4 s in: about 10 s of load in all), so "two windows agree"
-        # cannot detect it: windows of 10 untimed steps are run for at least --precondition-min seconds (default PRECONDITION_MIN_S)
-        # and until the best window time has not improved by 0.3 % for PRECONDITION_QUIET_S seconds (at most PRECONDITION_MAX_S in all).
+        # Device pre-conditioning, BEFORE the W warm-up steps and outside every timed region: windows of 10 untimed steps (each closed by a
+        # synchronize) for at least --precondition-min seconds and until the best window time has not improved by 0.3 % for
+        # PRECONDITION_QUIET_S seconds (at most PRECONDITION_MAX_S): clocks, caches and the allocator settle within the first two windows
+        # (33 -> 19.6 ms/step).  The window times go to stderr; `precondition_s` is reported in the line.  (The "first process on a box is
+        # 10-25 % slow" of this round's early A/B records was NOT the device: see the warm-up loop below.)
         t_pre, best, t_best = time.perf_counter(), None, None
         while True:
             t_w = time.perf_counter()
@@ -225,6 +224,7 @@ def main():
             torch.cuda.synchronize()
             now = time.perf_counter()
             w = now - t_w
+            log("[bench] pre-conditioning window at %.1f s: %.2f ms/step" % (now - t_pre, w * 100))
             if best is None or w < best * 0.997:
                 best, t_best = (w if best is None else min(best, w)), now
             stop = (now - t_best >= PRECONDITION_QUIET_S and now - t_pre >= args.precondition_min) or now - t_pre >= max(PRECONDITION_MAX_S, args.precondition_min)
@@ -236,8 +236,15 @@ def main():
             if stop:
                 break
         precondition_s = time.perf_counter() - t_pre
-        for _ in range(args.warmup):
-            run_step()
+        # the W warm-up steps run EXACTLY the statements of the timed loop -- incl. the NaN test of the loss value: its two small
+        # kernels are loaded on first use (hipModuleLoad of the host framework's code object: ~10 ms in a process on a warm box, ~60 ms
+        # in the first process after the box was leased or the repository copied), which inside a 20-step timed region read as
+        # +0.5 / +3 ms per step (the "first process is slow" of profiles/r03_ab_*.txt; the pre-conditioning windows, which did not
+        # contain those statements, ran at full speed in the same process: profiles/r03_bench_first_process.txt)
+        warm_flags = torch.zeros(max(1, args.warmup), dtype=torch.bool, device=dev)
+        for i in range(args.warmup):
+            loss, _, _ = run_step()
+            warm_flags[i] = loss != loss
 
     def fence():
         if world > 1 or args.force_dist:
@@ -251,6 +258,7 @@ def main():
     for i in range(args.steps):
         loss, _, _ = run_step()
         nan_flags[i] = loss != loss
+    host_issue_ms = (time.perf_counter() - t0) / args.steps * 1e3   # what the host needs to ISSUE a step (it runs ahead of the device when this is < ms_per_step)
     fence()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -336,6 +344,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "precondition_s": round(precondition_s, 2),
+            "host_issue_ms_per_step": round(host_issue_ms, 2),
             "config": {"workload": workloads[args.model] + (" [use_depth=True]" if dh else ""), "model": args.model,
                        "images_per_gpu": args.batch, "global_batch": args.batch * world, "resolution": 224, "latent_dim": 512,
                        "parallelism": "dp%d" % world + (" (RCCL world 1: staged joins + bucketed all-reduce on one GPU)" if args.force_dist else ""),
