@@ -584,8 +584,8 @@ static int ensure_side(rpe_resnet50* e) {
             // NORMAL dispatch priority.  Round 2 gave the second stream the LOWEST priority (weight gradients are off the critical path:
             // 20.86 vs 20.98 ms/step then).  Round 3 found that fragile: streams are dealt to a few hardware queues in creation order, and
             // a LOW-priority stream created as the 4th .. 8th stream of the process (three or more streams made before it by the host
-            // framework, a communication library, a data loader) is starved outright -- 28.1-28.8 ms/step instead of 19.6, and the first
-            // process on a freshly provisioned box measured 22-26 ms the same way -- while a normal-priority stream runs 19.53-19.58 ms/step
+            // framework, a communication library, a data loader) is starved outright -- 28.1-28.8 ms/step instead of 19.6 --
+            // while a normal-priority stream runs 19.53-19.58 ms/step
             // wherever it lands (profiles/r03_ab_stream_priority.txt).  RPE_SIDE_LOW_PRIO=1 restores the round-2 choice.
             int least = 0, greatest = 0;
             HIPTRY(hipDeviceGetStreamPriorityRange(&least, &greatest));

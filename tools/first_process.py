@@ -1,4 +1,4 @@
-"""Diagnostic: how long does the first process on a freshly leased box run slow?  Windows of 10 train steps (256 images, bf16) for
+"""Diagnostic: is the first process on a freshly leased box slow?  (No: profiles/r03_bench_first_process.txt.)  Windows of 10 train steps (256 images, bf16) for
 ~SECONDS seconds: per window the device time per step and the host's issue time per step, plus the GPU clock rocm-smi reports.
 
     python tools/first_process.py [seconds=45]
