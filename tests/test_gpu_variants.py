@@ -16,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # schedule / fusion switches of the trunk engine: one golden train step per model family must still match the reference
 ENGINE_VARIANTS = [
     {"RPE_NO_OVERLAP": "1"},        # everything on one stream
+    {"RPE_SIDE_LOW_PRIO": "1", "RPE_TEST_STREAM_SKIP": "3"},   # round 2's low-priority second stream, created as the 4th stream of the process
     # projection-shortcut branch on the main stream; dense early-feature gradient + separate pool / BN backward passes for the
     # stem; conv3 backward through a materialised dy on the main stream
     {"RPE_NO_FWD_OVERLAP": "1", "RPE_STEM_UNFUSED": "1", "RPE_NO_BN_FOLD": "1"},
