@@ -200,6 +200,7 @@ def main():
         broadcast_parameters(model._arena.flat, list(model.buffers()))
         sync = GradSync(model._arena.grad, reduce_single=args.force_dist).attach(model)   # slices are all-reduced under the backward
     precondition_s = 0.0
+    precondition_steps = 0
     if use_graph:
         # the whole step as ONE captured hipGraph (forward, loss, val metrics, backward on both streams, Adam); replayed per step
         graphed = GraphedTrainStep(model, criterion, opt, train_obj_pose, batch, warmup=min(3, max(1, args.warmup)))
@@ -221,6 +222,7 @@ def main():
             t_w = time.perf_counter()
             for _ in range(10):
                 run_step()
+            precondition_steps += 10
             torch.cuda.synchronize()
             now = time.perf_counter()
             w = now - t_w
@@ -314,16 +316,24 @@ def main():
     ai = dom["flops"] / max(dom["bytes"], 1.0)
     hbm_bound = dom["flops"] <= 0 or ai < PEAK_TFLOPS[args.dtype] * 1e12 / (PEAK_HBM_GBS * 1e9)
     traffic, traffic_source = None, None
+    build_id = lib.rpe_build_id().decode()   # hash of the sources the LOADED library was built from (compiled into it)
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic_pmc.json")
     if os.path.exists(tpath):  # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) of this same command, committed per round
-        for k in json.load(open(tpath)).get("kernels", []):
-            if k["kernel"] == dom["kernel"]:
-                traffic = round(k["per_launch_MB"] * 1e6)
-                traffic_source = "lookup in profiles/hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the committed build; NOT measured by this run)"
+        tj = json.load(open(tpath))
+        if tj.get("build_id") != build_id:
+            # the counters were collected on another build of the library: no number is better than a number about different kernels
+            traffic_source = "profiles/hbm_traffic_pmc.json was measured on build %s, this process loaded build %s: traffic withheld" % (tj.get("build_id"), build_id)
+        else:
+            for k in tj.get("kernels", []):
+                if k["kernel"] == dom["kernel"]:
+                    traffic = round(k["per_launch_MB"] * 1e6)
+                    traffic_source = ("lookup in profiles/hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on build %s = the library "
+                                      "this process loaded; NOT measured by this run)" % build_id)
     roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": dom["kernel"],
                 "achieved": round(gbs if hbm_bound else tflops, 2), "peak": PEAK_HBM_GBS if hbm_bound else PEAK_TFLOPS[args.dtype],
                 "unit": "GB/s" if hbm_bound else "TFLOP/s",
                 "frac": round((gbs / PEAK_HBM_GBS) if hbm_bound else (tflops / PEAK_TFLOPS[args.dtype]), 4), "traffic": traffic, "traffic_source": traffic_source,
+                "build_id": build_id,
                 "avg_launch_ms": round(avg_ms, 4), "launches_per_step": dom["launches"] // n_prof,
                 "algorithmic_mb_per_launch": round(dom["bytes"] / dom["launches"] / 1e6, 2),
                 "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 2),
@@ -343,7 +353,10 @@ def main():
             "metric": "images/sec (train step, 224x224 bs256 per GPU)", "value": round(imgs / dt, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "precondition_s": round(precondition_s, 2),
+            # optimizer steps taken on the synthetic batch BEFORE the W warm-up steps (untimed 10-step windows): final_loss / nan_loss_steps
+            # describe the state after precondition_steps + warmup + steps updates.  The timed loop's statements are `run_step()` and the
+            # device-side NaN test of the loss value (two small elementwise launches per step, inside the timed region since round 3).
+            "precondition_s": round(precondition_s, 2), "precondition_steps": precondition_steps,
             "host_issue_ms_per_step": round(host_issue_ms, 2),
             "config": {"workload": workloads[args.model] + (" [use_depth=True]" if dh else ""), "model": args.model,
                        "images_per_gpu": args.batch, "global_batch": args.batch * world, "resolution": 224, "latent_dim": 512,

@@ -45,6 +45,9 @@ enum {
 };
 
 int rpe_abi_version(void);
+/* the first 16 hex digits of the SHA-256 of the sources this library was built from (fixed at build time; csrc/Makefile): ties
+ * measurements kept beside the repository (profiles/hbm_traffic_pmc.json, "build_id") to the library a process actually loaded */
+const char* rpe_build_id(void);
 const char* rpe_last_error(void);
 
 /* ------------------------------------------------------------------ convolution */
@@ -88,7 +91,9 @@ int rpe_conv2d_dgrad(const rpe_conv_desc* d, int dtype, const void* dy, const vo
  * mask: a_mask != NULL: its bits;  else a_out != NULL: a_out > 0;  else scale/shift != NULL: y*scale+shift > 0 (BN+ReLU
  * without residual);  else none. */
 typedef struct {
-    const void* y;       /* raw conv output the BN normalised, same shape as dz */
+    const void* y;       /* raw conv output the BN normalised, same shape as dz.  NULL together with a_mask (1x1 / stride-1 convs of a 16-bit
+                          * type): that output does not exist -- only sum dz is emitted (the second half of every partial row is 0),
+                          * sum dz*xhat then follows from the weight gradient's first product (rpe_bn_backward_coeffs_t) */
     const void* a_out;   /* BN(+residual)+ReLU output, or NULL */
     const float *mean, *invstd, *scale, *shift;
     float* stats_part;
@@ -98,6 +103,22 @@ typedef struct {
 long rpe_conv2d_dgrad_stats_tiles(const rpe_conv_desc* d, int dtype);
 int rpe_conv2d_dgrad_bn(const rpe_conv_desc* d, int dtype, const void* dy, const void* w_crsk, void* dz, const void* addend,
                         const rpe_bn_bwd_epilogue* bn, void* stream);
+/* A bottleneck block WITHOUT its raw conv3 output (16-bit element types; replaces conv3 -> bn3 -> (+identity) -> ReLU of torchvision's
+ * Bottleneck in training mode -- util/model_utils.py:136 builds it, models/naive.py:316 calls it -- and their backward).
+ * BatchNorm statistics of a 1x1 conv follow from its INPUT: y = x W^T gives mean_c = w_c . colsum(x) / M, E[y_c^2] = w_c^T (x^T x) w_c / M.
+ * rpe_gram: x [M][C] -> out fp32 [rpe_gram_ones_row(C) + 1][C]: x^T x in rows [0, C), colsum(x) in row rpe_gram_ones_row(C) (one
+ * weight-gradient-style launch, fixed-order slab sum).  rpe_bn_stats_from_gram: what rpe_bn_finalize produces (scale, shift, saved
+ * mean / invstd, running statistics), from the Gram matrix and the compute-dtype weight.  rpe_conv1x1_fwd_bn: the conv with
+ * out = relu(acc * scale + shift + residual [* res_scale + res_shift]) and the packed ReLU mask in its epilogue -- the raw output
+ * is written only when y_out is given. */
+long rpe_gram_ones_row(int C);
+long rpe_gram_workspace_bytes(int dtype, long M, int C);
+int rpe_gram(int dtype, const void* x, long M, int C, float* out, void* workspace, long workspace_bytes, void* stream);
+int rpe_bn_stats_from_gram(int dtype, const void* w, int Co, int Ci, const float* gram, int ones_row, long count, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, long long* num_batches, float momentum, float eps, float* scale, float* shift,
+                           float* save_mean, float* save_invstd, void* stream);
+int rpe_conv1x1_fwd_bn(const rpe_conv_desc* d, int dtype, const void* x, const void* w, void* out, void* y_out, const float* scale, const float* shift,
+                       const void* residual, const float* res_scale, const float* res_shift, unsigned char* relu_mask, void* stream);
 /* BatchNorm backward folded into the data gradient of the 1x1 / stride-1 conv in front of it (y = a_in W^T, z = BN(y)):
  *   dx = dz (A o W) + a_in G + 1 b^T   with A = gamma invstd, G = W^T diag(C') W, b = W^T B'  (C', B' from the BN coefficients),
  * so the data gradient reads dz and the conv's INPUT instead of a materialised dy = BN'(dz, y).
@@ -130,6 +151,16 @@ int rpe_conv1x1_wgrad_folded_y(const rpe_conv_desc* d, int dtype, const void* dz
 long rpe_conv1x1_wgrad_folded_scratch_bytes(const rpe_conv_desc* d, int dtype);
 int rpe_conv1x1_wgrad_folded(const rpe_conv_desc* d, int dtype, const void* dz, const void* a_in, const float* w_master, const float* gamma,
                              const float* invstd, const float* mean, const float* c1c2, float* dw, void* scratch, long scratch_bytes, void* stream);
+/* Backward of a block whose raw conv3 output was never written (rpe_conv1x1_fwd_bn with y_out = NULL).  The fused data gradient that
+ * produces dz (rpe_conv2d_dgrad_bn with bn->y = NULL, bn->a_mask set) emits sum dz only; the weight gradient's first product
+ * T = dz^T a_in ([out_c][in_c] fp32 = rpe_conv2d_wgrad_det(x = a_in, dy = dz)) then gives sum dz*y = rowdot(T_c, W_c):
+ * rpe_bn_backward_coeffs_t = rpe_bn_backward_coeffs with that second sum (w: the compute-dtype weight [C][Ci] the forward used), and
+ * rpe_conv1x1_wgrad_combine = the last step of rpe_conv1x1_wgrad_folded from T and the FORWARD's Gram buffer (rpe_gram of a_in):
+ * dw = A o (T - c1 s1^T) + C' o (W S - mean s1^T).  Replaces autograd's BatchNorm2d + conv3 backward of a torchvision Bottleneck. */
+int rpe_bn_backward_coeffs_t(int dtype, const float* stats_part, int tiles, int C, long rows, const float* dzt_a, const void* w, int Ci, const float* mean,
+                             const float* invstd, float* dgamma, float* dbeta, float* c1c2, double* dpart, void* stream);
+int rpe_conv1x1_wgrad_combine(const rpe_conv_desc* d, const float* dzt_a, const float* gram, const float* w_master, const float* gamma, const float* invstd,
+                              const float* mean, const float* c1c2, float* dw, void* stream);
 /* the two halves of rpe_bn_backward_from_dz as separate calls (c1c2: [2][C] fp32 = mean(dz), mean(dz xhat)) */
 int rpe_bn_backward_coeffs(const float* stats_part, int tiles, int C, long rows, float* dgamma, float* dbeta, float* c1c2, double* dpart, void* stream);
 int rpe_bn_backward_apply_dz(int dtype, const void* dz, const void* y, const float* mean, const float* invstd, const float* gamma, const float* c1c2,

@@ -43,6 +43,7 @@ PD = POINTER(ConvDesc)
 _SPEC = {
     "rpe_abi_version": (I, []),
     "rpe_last_error": (c_char_p, []),
+    "rpe_build_id": (c_char_p, []),
     "rpe_conv_out_hw": (I, [PD, POINTER(c_int), POINTER(c_int)]),
     "rpe_conv_stats_tiles": (L, [L]),
     "rpe_conv2d_fwd": (I, [PD, I, P, P, P, P, P]),
@@ -85,6 +86,13 @@ _SPEC = {
     "rpe_bn_eval_affine": (I, [I, P, P, P, P, F, P, P, P]),
     "rpe_bn_apply": (I, [I, P, P, P, P, P, L, I, I, P]),
     "rpe_bn_apply_mask": (I, [I, P, P, P, P, P, L, I, P, P]),
+    "rpe_bn_backward_coeffs_t": (I, [I, P, I, I, L, P, P, I, P, P, P, P, P, P, P]),
+    "rpe_conv1x1_wgrad_combine": (I, [PD, P, P, P, P, P, P, P, P, P]),
+    "rpe_gram_ones_row": (L, [I]),
+    "rpe_gram_workspace_bytes": (L, [I, L, I]),
+    "rpe_gram": (I, [I, P, L, I, P, P, L, P]),
+    "rpe_bn_stats_from_gram": (I, [I, P, I, I, P, I, L, P, P, P, P, P, c_float, c_float, P, P, P, P, P]),
+    "rpe_conv1x1_fwd_bn": (I, [PD, I, P, P, P, P, P, P, P, P, P, P, P]),
     "rpe_bn_apply_res_bn": (I, [I, P, P, P, P, P, P, P, L, I, I, P, P]),
     "rpe_bn_backward": (I, [I, P, P, P, P, P, P, P, P, P, P, L, I, P, L, P, P, P]),
     "rpe_maxpool3x3s2_fwd": (I, [I, P, P, P, I, I, I, I, P]),

@@ -98,8 +98,11 @@ static int conv_dgrad_t(const rpe_conv_desc* d, const void* dy, const void* w_cr
     a.addend = (const T*)addend; a.ld_add = d->in_c;
     a.role = 1;
     if (bn) {
-        if (!bn->y || !bn->mean || !bn->invstd || !bn->stats_part) return rpe_set_error(RPE_ERR_SHAPE, "conv2d_dgrad_bn: y, mean, invstd, stats_part are required");
-        a.bn_mode = bn->a_mask ? 4 : bn->a_out ? 1 : (bn->scale && bn->shift ? 2 : 3);
+        // y == null with a_mask: the layer's raw output does not exist (y3-free bottleneck) -- mask from the bits, only sum dz is emitted
+        const bool no_y = !bn->y && bn->a_mask;
+        if (!bn->stats_part || (!no_y && (!bn->y || !bn->mean || !bn->invstd))) return rpe_set_error(RPE_ERR_SHAPE, "conv2d_dgrad_bn: y, mean, invstd, stats_part are required (y may be null with a_mask: sum dz only)");
+        a.bn_mode = no_y ? 5 : bn->a_mask ? 4 : bn->a_out ? 1 : (bn->scale && bn->shift ? 2 : 3);
+        if (no_y && (!is_dense(d) || sizeof(T) != 2)) return rpe_set_error(RPE_ERR_SHAPE, "conv2d_dgrad_bn: the sum-dz-only form is for 1x1 / stride-1 convs of a 16-bit element type");
         if (bn->a_mask && (d->in_c % 8)) return rpe_set_error(RPE_ERR_SHAPE, "conv2d_dgrad_bn: a_mask needs in_c % 8 == 0");
         a.bn_y = (const T*)bn->y; a.bn_a = (const T*)bn->a_out; a.bn_mask = bn->a_mask;
         a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bn_scale = bn->scale; a.bn_shift = bn->shift;
@@ -346,16 +349,18 @@ template <typename T> static int bn_fold_scratch_t(int Co, int Ci, long* bytes) 
 // dw[c][n] = A_c (D1[c][n] - c1_c s1[n]) + C'_c ((W S)[c][n] - mean_c s1[n]);  dp = [D1 (Co rows) ; S (Ci rows) ; ... ; s1 (row `ones_row`)]
 // One block = 16 rows c x 64 columns n: W rows and the S column chunk go through LDS, W S is formed in fp32 on the vector units
 // (Co Ci Ci MACs in all: 1 M .. 67 M for layers 1-3).
-__global__ __launch_bounds__(256) void wgrad_fold_combine_kernel(float* __restrict__ dw, const float* __restrict__ dp, const float* __restrict__ w,
+// (d1 = dz^T a_in [Co][Ci], S = a_in^T a_in [Ci][Ci], s1 = colsum(a_in) [Ci]: three pointers -- one launch's output buffer in the folded
+// weight gradient, the backward's T and the forward's Gram buffer in a y3-free block)
+__global__ __launch_bounds__(256) void wgrad_fold_combine_kernel(float* __restrict__ dw, const float* __restrict__ d1, const float* __restrict__ S,
+                                                                const float* __restrict__ s1v, const float* __restrict__ w,
                                                                 const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                                 const float* __restrict__ mean, const float* __restrict__ c1, const float* __restrict__ c2,
-                                                                int Co, int Ci, int ones_row) {
+                                                                int Co, int Ci) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // Ws [16][Ci] | Ss [KC][64], KC = min(Ci, 128) rows of S at a time
     float* Ws = sm;
     float* Ss = sm + 16 * Ci;
     const int KC = Ci < 128 ? Ci : 128;
     const int c0 = blockIdx.x * 16, n0 = blockIdx.y * 64;
-    const float* S = dp + (long)Co * Ci;
     for (int i = threadIdx.x; i < 16 * Ci; i += 256) Ws[i] = w[(long)c0 * Ci + i];
     const int cl = threadIdx.x >> 4, nq = (threadIdx.x & 15) * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -379,8 +384,8 @@ __global__ __launch_bounds__(256) void wgrad_fold_combine_kernel(float* __restri
     for (int j = 0; j < 4; ++j) {
         const int n = n0 + nq + j;
         if (n < Ci) {
-            const float s1 = dp[(long)ones_row * Ci + n];
-            dw[(long)c * Ci + n] = a * (dp[(long)c * Ci + n] - c1[c] * s1) + cp * (acc[j] - mean[c] * s1);
+            const float s1 = s1v[n];
+            dw[(long)c * Ci + n] = a * (d1[(long)c * Ci + n] - c1[c] * s1) + cp * (acc[j] - mean[c] * s1);
         }
     }
 }
@@ -425,10 +430,47 @@ static int conv1x1_wgrad_folded_t(const rpe_conv_desc* d, const void* dz, const 
     if (int e = launch_tn<T>(a, MODE_DENSE, s)) return e;
     prof_split(s, "wgrad_fold_combine_kernel");
     const size_t lds = (size_t)(16 * Ci + (Ci < 128 ? Ci : 128) * 64) * 4;
-    hipLaunchKernelGGL(wgrad_fold_combine_kernel, dim3(Co / 16, (Ci + 63) / 64), dim3(256), lds, s, dw, dp, w_master, gamma, invstd, mean, c1c2, c1c2 + Co, Co, Ci,
-                       pl.ones_row);
+    hipLaunchKernelGGL(wgrad_fold_combine_kernel, dim3(Co / 16, (Ci + 63) / 64), dim3(256), lds, s, dw, dp, dp + (long)Co * Ci, dp + (long)pl.ones_row * Ci, w_master,
+                       gamma, invstd, mean, c1c2, c1c2 + Co, Co, Ci);
     RPE_CHECK_LAUNCH();
     return 0;
+}
+
+// Gram matrix and column sums of x [M][C] in one TN launch (P = Q = x plus the all-ones tile): out [ones_row + 1][C] fp32 with
+// x^T x in rows [0, C) and colsum(x) in row ones_row = roundup(C, 128).  ws: the launch's slab (deterministic fixed-order sum).
+static inline int gram_ones_row(int C) { return (C + 127) / 128 * 128; }
+template <typename T>
+static int gram_t(const void* x, long M, int C, float* out, void* ws, long ws_bytes, long* query, hipStream_t s) {
+    TNArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.M = (int)M; a.I = gram_ones_row(C) + 1; a.J = C; a.ldp = C; a.ldq = C; a.ldd = C;
+    a.ones_i0 = gram_ones_row(C); a.p_cols = C;
+    if (query) return launch_tn<T>(a, MODE_DENSE, nullptr, query);
+    a.P = (const T*)x; a.Q = (const T*)x; a.D = out;
+    a.slab = (float*)ws; a.slab_bytes = ws_bytes;
+    long need = 0;
+    {
+        TNArgs<T> q = a;
+        if (int e = launch_tn<T>(q, MODE_DENSE, nullptr, &need)) return e;
+    }
+    if (!ws || ws_bytes < need) return rpe_set_error(RPE_ERR_WORKSPACE, "gram: workspace smaller than rpe_gram_workspace_bytes()");
+    return launch_tn<T>(a, MODE_DENSE, s);
+}
+
+// training forward of a 1x1 / stride-1 conv with its BatchNorm (+ residual [under its own BN]) + ReLU + packed mask fused into the
+// epilogue; scale / shift come from rpe_bn_stats_from_gram
+template <typename T>
+static int conv1x1_fwd_bn_t(const rpe_conv_desc* d, const void* x, const void* w, void* out, void* y_out, const float* scale, const float* shift,
+                            const void* residual, const float* res_scale, const float* res_shift, unsigned char* mask, hipStream_t s) {
+    NTArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.A = (const T*)x; a.Bw = (const T*)w; a.C = (T*)out; a.y_out = (T*)y_out;
+    a.M = d->batch * d->in_h * d->in_w; a.N = d->out_c; a.K = d->in_c;
+    a.lda = d->in_c; a.ldb = d->in_c; a.ldc = d->out_c;
+    a.addend = (const T*)residual; a.ld_add = d->out_c;
+    a.fwd_scale = scale; a.fwd_shift = shift; a.res_scale = res_scale; a.res_shift = res_shift; a.mask_out = mask;
+    a.role = 5;
+    return launch_nt<T>(a, MODE_DENSE, s);
 }
 
 // data gradient of a 1x1 / stride-1 conv from A = [dz (M x Co) | a_in (M x Ci)] and the folded weight w_kcat [Ci][Co + Ci]
@@ -852,6 +894,50 @@ int rpe_conv1x1_wgrad_folded_y(const rpe_conv_desc* d, int dtype, const void* dz
     if (d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_wgrad_folded_y: 1x1 / stride 1 / no padding only");
     if (!dz || !y || !x || !gamma || !invstd || !mean || !c1c2 || !dw) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_wgrad_folded_y: null argument");
     return wfold_y_dispatch(d, dtype, dz, y, x, gamma, invstd, mean, c1c2, dw, scratch, scratch_bytes, nullptr, (hipStream_t)stream);
+}
+
+int rpe_conv1x1_wgrad_combine(const rpe_conv_desc* d, const float* dzt_a, const float* gram, const float* w_master, const float* gamma, const float* invstd,
+                              const float* mean, const float* c1c2, float* dw, void* stream) {
+    if (int e = check_desc(d)) return e;
+    const int Co = d->out_c, Ci = d->in_c;
+    if (!is_dense(d) || (Co % 16) || (Ci % 4) || Ci > 512) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_wgrad_combine: 1x1 / stride 1, out_c % 16 == 0, in_c % 4 == 0, in_c <= 512");
+    if (!dzt_a || !gram || !w_master || !gamma || !invstd || !mean || !c1c2 || !dw) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_wgrad_combine: null argument");
+    note_kernel("wgrad_fold_combine_kernel");
+    const size_t lds = (size_t)(16 * Ci + (Ci < 128 ? Ci : 128) * 64) * 4;
+    hipLaunchKernelGGL(wgrad_fold_combine_kernel, dim3(Co / 16, (Ci + 63) / 64), dim3(256), lds, (hipStream_t)stream, dw, dzt_a, gram, gram + (long)gram_ones_row(Ci) * Ci,
+                       w_master, gamma, invstd, mean, c1c2, c1c2 + Co, Co, Ci);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+long rpe_gram_ones_row(int C) { return gram_ones_row(C); }
+
+long rpe_gram_workspace_bytes(int dtype, long M, int C) {
+    long bytes = 0;
+    int rc;
+    if (M <= 0 || C <= 0 || (C % 64)) return -1;
+    if (dtype == RPE_F32) rc = gram_t<float>(nullptr, M, C, nullptr, nullptr, 0, &bytes, nullptr);
+    else if (dtype == RPE_BF16) rc = gram_t<bf16>(nullptr, M, C, nullptr, nullptr, 0, &bytes, nullptr);
+    else if (dtype == RPE_F16) rc = gram_t<f16>(nullptr, M, C, nullptr, nullptr, 0, &bytes, nullptr);
+    else return -1;
+    return rc ? -1 : bytes;
+}
+
+int rpe_gram(int dtype, const void* x, long M, int C, float* out, void* workspace, long workspace_bytes, void* stream) {
+    if (!x || !out || M <= 0 || C <= 0 || (C % 64)) return rpe_set_error(RPE_ERR_SHAPE, "gram: x [M][C] with C % 64 == 0");
+    DISPATCH(dtype, gram_t, x, M, C, out, workspace, workspace_bytes, nullptr, (hipStream_t)stream);
+}
+
+int rpe_conv1x1_fwd_bn(const rpe_conv_desc* d, int dtype, const void* x, const void* w, void* out, void* y_out, const float* scale, const float* shift,
+                       const void* residual, const float* res_scale, const float* res_shift, unsigned char* relu_mask, void* stream) {
+    if (int e = check_desc(d)) return e;
+    if (d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_fwd_bn: 1x1 / stride 1 / no padding only");
+    if (dtype == RPE_F32) return rpe_set_error(RPE_ERR_DTYPE, "conv1x1_fwd_bn: 16-bit element types only (the fp32 path keeps the two-pass form)");
+    if (!x || !w || !out || !scale || !shift || (res_scale && (!res_shift || !residual)) || (d->out_c % 8))
+        return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_fwd_bn: bad arguments");
+    if (dtype == RPE_BF16) return conv1x1_fwd_bn_t<bf16>(d, x, w, out, y_out, scale, shift, residual, res_scale, res_shift, relu_mask, (hipStream_t)stream);
+    if (dtype == RPE_F16) return conv1x1_fwd_bn_t<f16>(d, x, w, out, y_out, scale, shift, residual, res_scale, res_shift, relu_mask, (hipStream_t)stream);
+    return rpe_set_error(RPE_ERR_DTYPE, "conv1x1_fwd_bn: unsupported dtype");
 }
 
 int rpe_conv1x1_dgrad_kcat(const rpe_conv_desc* d, int dtype, const void* dz, const void* a_in, const void* w_kcat, const float* bias, void* dx,

@@ -38,6 +38,10 @@ struct ConvL {
 struct Block {
     int c1, c2, c3, cd;  // conv indices (cd = -1: identity shortcut)
     void* dz = nullptr;  // backward: ReLU-masked gradient at the block output (kept as the shortcut gradient)
+    // y3-free block (rpe_resnet50::y3free): fp32 [ones_row + 1][planes] Gram matrix + column sums of conv3's input, written by the forward
+    // (BN3 statistics without y3) and read again by the backward's weight-gradient combine; dzt_a: fp32 [4 planes][planes] = dz3^T a2
+    float* gram = nullptr;
+    float* dzt_a = nullptr;
     unsigned char* relu_mask = nullptr;  // 16-bit element types: packed ReLU mask of the block output (1 bit per element), written by its bn_apply
 };
 
@@ -121,6 +125,18 @@ struct rpe_resnet50 {
     bool stem_raw = false;
     void* fc_ws = nullptr;               // split-K workspace of the ResNet fc forward / data gradient (rpe_linear_fwd_ws)
     long fc_ws_bytes = 0;
+    // Bottleneck blocks WITHOUT the raw conv3 output (16-bit element types, planes <= y3free_max: layers 1-2 by default).  Forward: BN3's
+    // batch statistics follow from the Gram matrix of conv3's INPUT (rpe_gram + rpe_bn_stats_from_gram), so conv3 applies BN + identity
+    // + ReLU + mask in its own epilogue -- y3 is neither written nor re-read by an apply pass.  Backward: the next block's fused conv1
+    // data gradient emits sum dz only; sum dz*y3 = rowdot(dz3^T a2, W3) comes from the weight gradient's first product, which therefore
+    // runs on the caller's stream in front of the coefficients (rpe_bn_backward_coeffs_t); the second stream only combines
+    // (rpe_conv1x1_wgrad_combine, with the forward's Gram buffer).  RPE_NO_Y3FREE=1: the round-3 dataflow; RPE_Y3_KEEP=1: the new
+    // forward but y3 still written and the round-3 backward (A/B of the two halves); RPE_Y3FREE_MAX: widest planes handled this way.
+    bool y3free = false;
+    bool y3_keep = false;
+    int y3free_max = 128;
+    void* gram_ws = nullptr;     // slab of the Gram launches (caller's stream)
+    long gram_ws_bytes = 0;
     void* sk_ws = nullptr;               // split-K workspace of the inference forward (rpe_conv2d_fwd_affine_ws); 0 bytes when no layer splits
     long sk_ws_bytes = 0;
     rpe_pack_desc* pack_tab_fold = nullptr;  // ... with the BN scale folded into the forward copy (inference)
@@ -339,6 +355,24 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
         want(e, (void**)&e->fold_bias, 2048L * 4);
         want(e, &e->fold_scratch, e->fold_scratch_bytes);
     }
+    e->y3free = dtype != RPE_F32 && e->fold && e->fold_w && !e->fold1 && !getenv("RPE_NO_Y3FREE") && !getenv("RPE_NO_RELU_MASK") &&
+                !getenv("RPE_WGRAD_ATOMIC");
+    long y3_slab = 0;
+    if (e->y3free) {
+        if (getenv("RPE_Y3FREE_MAX")) e->y3free_max = atoi(getenv("RPE_Y3FREE_MAX"));
+        e->y3_keep = getenv("RPE_Y3_KEEP") != nullptr;
+        for (auto& b : e->blocks) {
+            const ConvL& c3 = e->convs[b.c3];
+            if (c3.d.in_c > e->y3free_max || c3.d.in_c > 256 || (c3.d.in_c % 64)) continue;
+            want(e, (void**)&b.gram, (long)(rpe_gram_ones_row(c3.d.in_c) + 1) * c3.d.in_c * 4);
+            want(e, (void**)&b.dzt_a, (long)c3.d.out_c * c3.d.in_c * 4);
+            const long wsb = rpe_gram_workspace_bytes(dtype, c3.rows, c3.d.in_c);
+            if (wsb > e->gram_ws_bytes) e->gram_ws_bytes = wsb;
+            const long tb = rpe_conv2d_wgrad_workspace_bytes(&c3.d, dtype);   // dz3^T a2 runs on the caller's stream: its slab
+            if (tb > y3_slab) y3_slab = tb;
+        }
+        if (e->gram_ws_bytes > 0) want(e, &e->gram_ws, e->gram_ws_bytes);
+    }
     if (!getenv("RPE_WGRAD_ATOMIC")) {
         for (size_t i = 1; i < e->convs.size(); ++i) {
             const long b = rpe_conv2d_wgrad_workspace_bytes(&e->convs[i].d, dtype);
@@ -348,6 +382,7 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
         e->main_slab_bytes = rpe_stem_conv_wgrad_workspace_bytes(dtype, batch, height, width);
         const long fcb = rpe_linear_wgrad_workspace_bytes(RPE_F32, batch, latent_dim, 2048);
         if (fcb > e->main_slab_bytes) e->main_slab_bytes = fcb;
+        if (y3_slab > e->main_slab_bytes) e->main_slab_bytes = y3_slab;
         if (e->main_slab_bytes > 0) want(e, &e->main_slab, e->main_slab_bytes);
     }
     {
@@ -647,7 +682,7 @@ static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residua
 // join events (sync_next = 0 in the forward AND in the backward of one capture) under capture.
 static int capture_guard(rpe_resnet50* e, void* stream, const char* who) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess) { (void)hipGetLastError(); e->capturing = false; return 0; }   // (no stale 'true' from an earlier capture)
     e->capturing = st != hipStreamCaptureStatusNone;
     if (!e->capturing) return 0;
     if (e->profiling) return rpe_set_error(RPE_ERR_STATE, "trunk engine: per-launch profiling events cannot be recorded inside a stream capture");
@@ -663,6 +698,7 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
                         float* features, long ld_features, int training, void* stream, const rpe_resize_plan* rs = nullptr) {
     if (!e || !e->bound) return rpe_set_error(RPE_ERR_STATE, "resnet50_forward: engine not bound");
     if ((!img_nchw && !frames) || !features || ld_features < e->latent) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_forward: bad img/features");
+    TRY(capture_guard(e, stream, "resnet50_forward"));   // first: a refusal (profiling under capture, no second stream yet) must come before any launch is recorded
     e->train_mode = training;
     if (training && e->pack_state != 1) TRY(rpe_resnet50_pack_weights(e, stream));
     if (!training && e->pack_state != 2) TRY(fold_for_eval(e, stream));
@@ -671,7 +707,6 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
     else if (frames) PROF(e, RPE_PROF_OTHER, stream, rpe_stage_frames_u8(e->dtype, frames, e->x4, e->B, Hs, Ws, e->H, e->W, mean3, std3, stream));
     else PROF(e, RPE_PROF_OTHER, stream, rpe_stage_image_nhwc4(e->dtype, img_nchw, e->x4, e->B, e->H, e->W, stream));
     ConvL& st = e->convs[0];
-    TRY(capture_guard(e, stream, "resnet50_forward"));
     TRY(ensure_side(e));
     e->sync_next = 0;
     static const bool pool_fuse_ok = getenv("RPE_NO_POOL_FUSE") == nullptr;
@@ -716,6 +751,21 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
         if (b.cd >= 0 && !ds_done) { ConvL& cd = e->convs[b.cd]; TRY(conv_bn(e, cd, x, nullptr, 0, stream, false, nullptr, nullptr, fuse_ds)); idn = cd.a; }
         if (ds_done) HIPTRY(hipStreamWaitEvent((hipStream_t)stream, ds_done, 0));
         static const bool use_mask = getenv("RPE_NO_RELU_MASK") == nullptr;
+        if (training && b.gram && b.relu_mask) {
+            // y3-free: Gram matrix of a2 -> BN3 statistics -> conv3 with BN + identity (under the shortcut's BN) + ReLU + mask in its epilogue
+            const ConvL* cdp = (b.cd >= 0 && fuse_ds) ? &e->convs[b.cd] : nullptr;
+            e->pending_flops = 2.0 * (double)c3.rows * c3.d.in_c * c3.d.in_c;
+            e->pending_bytes = conv_in_bytes(e, c3);
+            PROF(e, RPE_PROF_BN_FWD, stream, rpe_gram(e->dtype, c2.a, c3.rows, c3.d.in_c, b.gram, e->gram_ws, e->gram_ws_bytes, stream));
+            e->pending_bytes = 0;
+            PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_stats_from_gram(e->dtype, c3.wf, c3.d.out_c, c3.d.in_c, b.gram, (int)rpe_gram_ones_row(c3.d.in_c), c3.rows,
+                                                                    e->params[c3.p_g], e->params[c3.p_b], e->running[2 * c3.bn_i], e->running[2 * c3.bn_i + 1],
+                                                                    e->nbt[c3.bn_i], 0.1f, 1e-5f, c3.scale, c3.shift, c3.mean, c3.invstd, stream));
+            e->pending_flops = conv_flops(c3);
+            e->pending_bytes = conv_in_bytes(e, c3) + conv_out_bytes(e, c3) * (2.0 + (e->y3_keep ? 1.0 : 0.0) + 1.0 / 16);   // x, residual -> out (+ y) + mask
+            PROF(e, RPE_PROF_CONV_FWD, stream, rpe_conv1x1_fwd_bn(&c3.d, e->dtype, c2.a, c3.wf, c3.a, e->y3_keep ? c3.y : nullptr, c3.scale, c3.shift,
+                                                                 cdp ? cdp->y : idn, cdp ? cdp->scale : nullptr, cdp ? cdp->shift : nullptr, b.relu_mask, stream));
+        } else
         if (b.cd >= 0 && fuse_ds) TRY(conv_bn(e, c3, c2.a, e->convs[b.cd].y, 1, stream, false, use_mask ? b.relu_mask : nullptr, &e->convs[b.cd]));
         else
         TRY(conv_bn(e, c3, c2.a, idn, 1, stream, false, use_mask ? b.relu_mask : nullptr));   // (relu_mask is null for fp32 engines)
@@ -760,9 +810,9 @@ static int bn_back(rpe_resnet50* e, ConvL& c, const void* dA, int relu, void* dy
 // data gradient of conv `c` with the BN-backward reduction of layer `bnl` (the layer producing c's input) fused in.
 // mask_mode 1: ReLU mask from bnl.a (residual block output); 2: mask recomputed from bnl.y, scale, shift.
 static int dgrad_fused(rpe_resnet50* e, ConvL& c, const void* dy, void* dz, const void* addend, ConvL* bnl, int mask_mode, void* stream,
-                       const unsigned char* relu_mask = nullptr) {
+                       const unsigned char* relu_mask = nullptr, bool no_y = false) {
     rpe_bn_bwd_epilogue ep;
-    ep.y = bnl->y;
+    ep.y = no_y ? nullptr : bnl->y;                      // (y3-free block: sum dz only, rpe_conv2d_dgrad_bn)
     ep.a_mask = mask_mode == 1 ? relu_mask : nullptr;   // block outputs: 1 bit per element instead of re-reading a_out
     ep.a_out = (mask_mode == 1 && !ep.a_mask) ? bnl->a : nullptr;
     ep.mean = bnl->mean; ep.invstd = bnl->invstd;
@@ -771,7 +821,7 @@ static int dgrad_fused(rpe_resnet50* e, ConvL& c, const void* dy, void* dz, cons
     ep.stats_part = e->stats_part;
     e->pending_flops = conv_flops(c);
     // reads dy; writes dz; the fused epilogue also reads y (and a_out for residual outputs) and the shortcut addend
-    e->pending_bytes = conv_out_bytes(e, c) + conv_in_bytes(e, c) * (2.0 + (mask_mode == 1 ? (ep.a_mask ? 1.0 / 16 : 1.0) : 0.0) + (addend ? 1.0 : 0.0));
+    e->pending_bytes = conv_out_bytes(e, c) + conv_in_bytes(e, c) * ((no_y ? 1.0 : 2.0) + (mask_mode == 1 ? (ep.a_mask ? 1.0 / 16 : 1.0) : 0.0) + (addend ? 1.0 : 0.0));
     e->fused_tiles = (int)rpe_conv2d_dgrad_stats_tiles(&c.d, e->dtype);  // partial-sum rows this launch leaves behind
     PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad_bn(&c.d, e->dtype, dy, c.wd, dz, addend, &ep, stream));
     return 0;
@@ -819,14 +869,29 @@ static int wgrad(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, void*
 // output and this BN's partial sums in stats_part (left by the data gradient that produced dz):
 //   main: coefficients -> fold (w_kcat, bias) -> K-concatenated data gradient [dz | x] with the epilogue of the layer behind;
 //   side: dz, y -> dy (streaming), weight gradient from dy.   The main stream never touches dy.
-static int conv1x1_backward_folded(rpe_resnet50* e, ConvL& c, const void* dz, ConvL& behind, void* stream) {
+static int conv1x1_backward_folded(rpe_resnet50* e, ConvL& c, const void* dz, ConvL& behind, void* stream, const Block* y3f = nullptr) {
     const void* x = behind.a;
+    if (y3f) {
+        // y3-free block: T = dz^T a2 first (caller's stream: the coefficients need it), then sum dz (partials) + rowdot(T, W) -> c1, c2
+        e->pending_flops = conv_flops(c);
+        e->pending_bytes = conv_in_bytes(e, c) + conv_out_bytes(e, c);
+        PROF(e, RPE_PROF_CONV_WGRAD, stream, rpe_conv2d_wgrad_det(&c.d, e->dtype, x, dz, y3f->dzt_a, e->main_slab, e->main_slab_bytes, stream));
+        e->pending_bytes = 0;
+        PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_backward_coeffs_t(e->dtype, e->stats_part, e->fused_tiles, c.d.out_c, c.rows, y3f->dzt_a, c.wf, c.d.in_c, c.mean, c.invstd,
+                                                                   e->grads[c.p_g], e->grads[c.p_b], c.c1c2, e->dpart, stream));
+    } else {
     e->pending_bytes = 0;
     PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_backward_coeffs(e->stats_part, e->fused_tiles, c.d.out_c, c.rows, e->grads[c.p_g], e->grads[c.p_b], c.c1c2, e->dpart, stream));
+    }
     ConvL* cp = &c;
-    auto side_part = [e, cp, dz, x](hipStream_t run) -> int {
+    auto side_part = [e, cp, dz, x, y3f](hipStream_t run) -> int {
     ConvL& c = *cp;
     float* dw = e->grads[c.p_w];
+    if (y3f) {
+        e->pending_flops = 2.0 * (double)c.d.out_c * c.d.in_c * c.d.in_c;
+        e->pending_bytes = 0;
+        PROF(e, RPE_PROF_CONV_WGRAD, run, rpe_conv1x1_wgrad_combine(&c.d, y3f->dzt_a, y3f->gram, e->params[c.p_w], e->params[c.p_g], c.invstd, c.mean, c.c1c2, dw, run));
+    } else
     if (e->fold_w && e->wfold_scratch && c.d.in_c <= e->fold_w_max) {
         // weight gradient from dz and x alone (no dy): dz^T x, x^T x, colsum(x), W (x^T x), combine
         e->pending_flops = conv_flops(c) * (1.0 + (double)c.d.in_c / c.d.out_c);
@@ -933,8 +998,9 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
             if (layer >= 2 && layer <= 4) hook_in = e->hook_grad[layer - 1];
         }
         static const bool ds_fold_ok = getenv("RPE_NO_DS_FOLD") == nullptr;
+        const bool y3f = b.gram && b.relu_mask && !e->y3_keep;   // this block's y3 was never written
         if (e->fold && c3.d.in_c <= 256 && e->train_mode) {   // layers 1-3 (layer4's tensors are small: the unfolded form is faster there)
-            TRY(conv1x1_backward_folded(e, c3, gA, c2, stream));                                  // dz2 (dy3 exists on the side stream only)
+            TRY(conv1x1_backward_folded(e, c3, gA, c2, stream, y3f ? &b : nullptr));              // dz2 (dy3 exists on the side stream only)
         } else {
             if (bi == (int)e->blocks.size() - 1) TRY(bn_back(e, c3, gA, 1, c3.dy, gA, stream));  // unfused: dy3, dz3 (in place)
             else TRY(bn_from_dz(e, c3, gA, c3.dy, stream));                                       // dy3 (gA keeps dz3 = shortcut gradient)
@@ -1024,8 +1090,9 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
             PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv1x1_dgrad_kcat_y(&c1.d, e->dtype, c1.dy, c1.y, e->w_kcat, e->fold_bias, gD, shortcut, epp, stream));
         } else
         if (bi > 0) {
-            TRY(dgrad_fused(e, c1, c1.dy, gD, shortcut, &e->convs[e->blocks[bi - 1].c3], 1, stream,
-                            use_mask ? e->blocks[bi - 1].relu_mask : nullptr));  // dz3 of the previous block
+            const Block& pb = e->blocks[bi - 1];
+            TRY(dgrad_fused(e, c1, c1.dy, gD, shortcut, &e->convs[pb.c3], 1, stream, use_mask ? pb.relu_mask : nullptr,
+                            pb.gram && pb.relu_mask && !e->y3_keep));             // dz3 of the previous block
         } else {
             PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&c1.d, e->dtype, c1.dy, c1.wd, gD, shortcut, stream));
         }

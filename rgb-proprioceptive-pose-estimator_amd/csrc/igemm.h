@@ -93,16 +93,25 @@ template <typename T> struct NTArgs {
                          //   bn_mode == 0: (sum acc, sum acc^2)  -> forward batch statistics
                          //   bn_mode != 0: (sum dz, sum dz*xhat) -> fused BatchNorm-backward reduction
     // fused BN backward on the data-gradient output: C = dz = (acc + addend) * [relu mask]
-    int bn_mode;         // 0 off; 1 mask = bn_a > 0; 2 mask = bn_y*bn_scale + bn_shift > 0; 3 no mask; 4 mask = bits of bn_mask
+    int bn_mode;         // 0 off; 1 mask = bn_a > 0; 2 mask = bn_y*bn_scale + bn_shift > 0; 3 no mask; 4 mask = bits of bn_mask;
+                         // 5 mask = bits of bn_mask and ONLY sum dz is emitted (bn_y is not read: the layer's raw output does not exist,
+                         //   sum dz*xhat follows from the weight gradient's first product, rpe_bn_backward_coeffs_t)
     const unsigned char* bn_mask;   // [M][ldc/8] bytes (mode 4)
     const T* bn_y;       // raw conv output the BN normalised, [M][ldc]
     const T* bn_a;       // BN(+residual)+ReLU output, [M][ldc] (mode 1)
     const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
     int tiles_m, tiles_n;
-    int role;            // 0 conv forward (training), 1 conv data gradient, 2 Linear, 3 conv forward (inference: bias/addend/ReLU):
+    int role;            // 0 conv forward (training), 1 conv data gradient, 2 Linear, 3 conv forward (inference: bias/addend/ReLU),
+                         // 5 1x1 conv forward (training) with BatchNorm + residual + ReLU + mask in the epilogue:
                          // selects the epilogue variant compiled into the kernel and tags its symbol in profiles
     long a_elems;        // elements of the tensor behind A (conv modes: set by the caller; dense: M * lda, filled by the launcher)
     unsigned b_bytes;    // buffer-descriptor extent of Bw (filled by the launcher, < 2 GiB)
+    // role 5: training forward of a 1x1 conv whose BatchNorm statistics are known BEFORE the launch (from the Gram matrix of its
+    // input: rpe_gram + rpe_bn_stats_from_gram): C = relu(acc * fwd_scale + fwd_shift + addend [* res_scale + res_shift]) with the
+    // packed ReLU mask (mask_out, 16-bit element types) -- the raw conv output is written only when y_out is set
+    const float *fwd_scale, *fwd_shift, *res_scale, *res_shift;
+    unsigned char* mask_out;
+    T* y_out;
     // Split-K form of the inference forward (few output tiles, long K: one rollout frame).  role 3 with `slab` set and
     // splits > 1 runs as role 4: grid.y = splits, workgroup (tile, z) walks K steps [z * split_steps, (z+1) * split_steps)
     // and stores its raw fp32 accumulators (fragment order) into slab[z][tile]; nt_split_epilogue_kernel then adds the

@@ -340,7 +340,10 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
     // forward / Linear roles have bias and ReLU.
     // Roles: 0 conv forward in training (batch-statistics partial sums only), 1 conv data gradient (addend, BN modes),
     // 2 Linear (bias / addend / ReLU, any alignment), 3 conv forward in inference (bias = BN shift, addend = identity, ReLU).
-    constexpr bool VEC_ONLY = ROLE != 2, HAS_BN = ROLE == 1, HAS_AFFINE = ROLE >= 2, HAS_ADDEND = ROLE != 0, HAS_FWD_STATS = ROLE == 0;
+    // 5 1x1 conv forward in training with the BatchNorm apply (+ residual [under its own BN]) + ReLU + packed mask fused (statistics known
+    // before the launch: Gram matrix of the input).
+    constexpr bool VEC_ONLY = ROLE != 2, HAS_BN = ROLE == 1, HAS_AFFINE = ROLE >= 2 && ROLE != 5, HAS_ADDEND = ROLE != 0, HAS_FWD_STATS = ROLE == 0;
+    constexpr bool FWD_BN = ROLE == 5;
     const bool nfull = VEC_ONLY ? ncol_ok : n + 7 < p.N;
     const bool vec_c = VEC_ONLY ? ncol_ok : nfull && (p.ldc % CE == 0) && (((uintptr_t)p.C) & 15) == 0;
     const T* const e_addend = HAS_ADDEND ? p.addend : nullptr;
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
     // three reads and one write per output element against K/N-th of that for the GEMM operands).  One step at a time
     // keeps ~1-3 KB per wave in flight; here the operands of the next DEPTH steps are requested ahead (the first DEPTH
     // before the K loop even starts), 16 B per lane and operand, into registers that are recycled step by step.
-    constexpr bool PIPE = ROLE == 1 && CE == 8;
+    constexpr bool PIPE = (ROLE == 1 || ROLE == 5) && CE == 8;
     constexpr int DEPTH = PIPE ? (NSTEP < kEpiDepth ? NSTEP : kEpiDepth) : 1;
     u32x4 qd[DEPTH], qy[DEPTH], qa[DEPTH];
     auto step_row = [&](int t) -> long { return out_row(wave_m * WM + (t / NPASS) * 16 + (t % NPASS) * RPP + erow); };
@@ -363,9 +366,9 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
         if (m < 0 || !ncol_ok) return;
         if (vec_add) qd[sl] = ld16(e_addend + m * p.ld_add + n);
         if (bn_mode && vec_c) {
-            qy[sl] = ld16(p.bn_y + m * p.ldc + n);
+            if (bn_mode != 5) qy[sl] = ld16(p.bn_y + m * p.ldc + n);
             if (bn_mode == 1) qa[sl] = ld16(p.bn_a + m * p.ldc + n);
-            if (bn_mode == 4) qa[sl].x = p.bn_mask[(m * p.ldc + n) >> 3];   // one byte: the ReLU bits of this lane's 8 channels
+            if (bn_mode == 4 || bn_mode == 5) qa[sl].x = p.bn_mask[(m * p.ldc + n) >> 3];   // one byte: the ReLU bits of this lane's 8 channels
         }
     };
     if (PIPE) {
@@ -578,8 +581,20 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
         cs[j] = 0.f; cq[j] = 0.f; cmean[j] = 0.f; cinv[j] = 0.f; csc[j] = 0.f; csh[j] = 0.f; cbias[j] = 0.f;
         if (n + j < p.N) {
             if (e_bias) cbias[j] = e_bias[n + j];
-            if (bn_mode) { cinv[j] = p.bn_invstd[n + j]; cmean[j] = -p.bn_mean[n + j] * cinv[j]; }   // xhat = y*inv + (-mean*inv): one fma
+            if (bn_mode && bn_mode != 5) { cinv[j] = p.bn_invstd[n + j]; cmean[j] = -p.bn_mean[n + j] * cinv[j]; }   // xhat = y*inv + (-mean*inv): one fma
             if (bn_mode == 2) { csc[j] = p.bn_scale[n + j]; csh[j] = p.bn_shift[n + j]; }
+        }
+    }
+    float fsc[8], fsh[8], frs[8];   // role 5: BN scale / shift of this layer (the shift carries the residual's shift) and the residual's scale
+    if constexpr (FWD_BN) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            fsc[j] = 0.f; fsh[j] = 0.f; frs[j] = 1.f;
+            if (n + j < p.N) {
+                fsc[j] = p.fwd_scale[n + j];
+                fsh[j] = p.fwd_shift[n + j] + (p.res_shift ? p.res_shift[n + j] : 0.f);
+                if (p.res_scale) frs[j] = p.res_scale[n + j];
+            }
         }
     }
     auto load8 = [&](const T* base, long off, bool vec, float* out) {
@@ -625,6 +640,23 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += cbias[j];
                 }
+                if constexpr (FWD_BN) {
+                    if (p.y_out) *(u32x4*)(p.y_out + m * p.ldc + n) = f_to_chunk<T>(v);   // (16-bit element types only: CE == 8)
+                    float ad[8];
+                    if (e_addend) {
+                        if (PIPE && vec_add) chunk_to_f<T>(qd[sl], ad);
+                        else load8(e_addend, m * p.ld_add + n, vec_add, ad);
+                    }
+                    unsigned bits = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float t = fmaf(v[j], fsc[j], fsh[j]);       // same expression order as bn_apply_kernel
+                        if (e_addend) t = fmaf(ad[j], frs[j], t);
+                        bits |= (t > 0.f ? 1u : 0u) << j;
+                        v[j] = fmaxf(t, 0.f);
+                    }
+                    if (p.mask_out) p.mask_out[(m * p.ldc + n) >> 3] = (unsigned char)bits;
+                } else
                 if (e_addend) {
                     float ad[8];
                     if (PIPE && vec_add) chunk_to_f<T>(qd[sl], ad);
@@ -637,23 +669,31 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
                     float yy[8], aa[8];
                     unsigned mbits = 0;
                     if (PIPE && vec_c) {
-                        chunk_to_f<T>(qy[sl], yy);
+                        if (bn_mode != 5) chunk_to_f<T>(qy[sl], yy);
                         if (bn_mode == 1) chunk_to_f<T>(qa[sl], aa);
-                        if (bn_mode == 4) mbits = qa[sl].x;
+                        if (bn_mode == 4 || bn_mode == 5) mbits = qa[sl].x;
                     } else {
-                        load8(p.bn_y, m * p.ldc + n, vec_c, yy);
+                        if (bn_mode != 5) load8(p.bn_y, m * p.ldc + n, vec_c, yy);
                         if (bn_mode == 1) load8(p.bn_a, m * p.ldc + n, vec_c, aa);
-                        if (bn_mode == 4) mbits = p.bn_mask[(m * p.ldc + n) >> 3];
+                        if (bn_mode == 4 || bn_mode == 5) mbits = p.bn_mask[(m * p.ldc + n) >> 3];
                     }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const bool on = bn_mode == 1 ? (aa[j] > 0.f)
                                         : bn_mode == 2 ? (fmaf(yy[j], csc[j], csh[j]) > 0.f)
-                                        : bn_mode == 4 ? ((mbits >> j) & 1u) != 0 : true;
+                                        : (bn_mode == 4 || bn_mode == 5) ? ((mbits >> j) & 1u) != 0 : true;
                         const float dz = on ? v[j] : 0.f;
-                        cs[j] += dz;
-                        cq[j] = fmaf(dz, fmaf(yy[j], cinv[j], cmean[j]), cq[j]);
+                        if (bn_mode != 5) { cs[j] += dz; cq[j] = fmaf(dz, fmaf(yy[j], cinv[j], cmean[j]), cq[j]); }   // (mode 5: the second sum stays 0)
                         v[j] = dz;
+                    }
+                    if (bn_mode == 5) {
+                        // sum of the dz values AS STORED (rounded to T): the other half of this BatchNorm's reduction, sum dz*y, is formed
+                        // from the stored tensor (T = dz^T a, rpe_bn_backward_coeffs_t), and sum dz*xhat = invstd (sum dz*y - mean sum dz)
+                        // cancels: with the unrounded sum here the two halves disagreed by the rounding noise times mean / std
+                        float vr[8];
+                        chunk_to_f<T>(f_to_chunk<T>(v), vr);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) cs[j] += vr[j];
                     }
                 }
                 if (e_relu) {
@@ -1155,6 +1195,9 @@ template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE>
             case 2: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 2 : 0>), grid, block, 0, s, a); break;
             case 3: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 3 : 0>), grid, block, 0, s, a); break;
             case 4: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 4 : 0>), grid, block, 0, s, a); break;
+            case 5:   // (the fused conv1 data gradients of the y3-free bottleneck blocks: dense launches of a 16-bit type only)
+                if constexpr (MODE == MODE_DENSE && sizeof(T) == 2 && WAVES_M == 2) { hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 5 : 0>), grid, block, 0, s, a); break; }
+                else return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: BN-backward mode 5 is a dense 128-row launch of a 16-bit element type");
             default: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, 0>), grid, block, 0, s, a); break;
         }
     } else {
@@ -1190,6 +1233,16 @@ template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s) 
         return wide ? launch_nt_cfg<T, 2, 128, 8, MODE_HALO, 2>(a, s) : launch_nt_cfg<T, 2, 64, 8, MODE_HALO, 2>(a, s);
     } else {
         if ((a.role == 3 || (a.role == 2 && MODE == MODE_DENSE)) && a.slab && a.splits > 1) return launch_nt_split<T, MODE>(a, s);
+        if (a.role == 5) {   // 1x1 training forward with the BatchNorm apply fused (rpe_conv1x1_fwd_bn): 16-bit element types, dense
+            if constexpr (MODE == MODE_DENSE && sizeof(T) == 2) {
+                a.tiles_m = ceil_div(a.M, 128); a.tiles_n = ceil_div(a.N, 128);
+                const long nwg = (long)a.tiles_m * a.tiles_n;
+                if (a.K <= 8 * CE && a.M >= 4096) return launch_nt_role<T, 2, 128, 4, MODE_DENSE, 2, 5>(a, s, nwg);   // (K = 64: both steps up front, 32 KB of LDS)
+                return launch_nt_role<T, 2, 128, 4, MODE_DENSE, 3, 5>(a, s, nwg);
+            } else {
+                return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: the fused-BN forward is a dense launch of a 16-bit element type");
+            }
+        }
         // (256-row / 8-wave tiles, 1 workgroup per CU: measured on the ResNet shapes at bs256 they gain 3..10 % in isolation for K >= 1024,
         // lose 10..25 % for short K, and LOSE inside the train step -- fused epilogues, 2 waves/SIMD in lockstep: 34.4 vs 32.9 ms/step.)
         // Long reductions (K >= 1024: the 3x3 convs from layer2 on and the deep 1x1s): 128-B K rows (BK 64) with a 2-slot

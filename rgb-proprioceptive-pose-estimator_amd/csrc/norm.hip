@@ -50,6 +50,34 @@ struct BnBwdFin {
     }
 };
 
+// BN backward coefficients of a bottleneck's bn3 when the raw conv3 output y = a W^T was never written (y3-free block): only sum dz
+// comes from the partial rows (their second half is 0); sum dz*y = rowdot(T_c, W_c) with T = dz^T a -- the weight gradient's first
+// product, [C][Ci] fp32 -- and W the compute-dtype weight the forward multiplied with, so sum dz*xhat = invstd (sum dz*y - mean sum dz).
+// The row dot products are formed by the 8 row lanes of the finishing block (dot / kDot below), summed in lane order.
+template <typename T> struct BnBwdFinT {
+    static constexpr bool kDot = true;
+    double count;
+    float *dgamma, *dbeta, *c1, *c2;
+    const float* Tm;
+    const T* w;
+    int Ci;
+    const float *mean, *invstd;
+    __device__ double dot(int c, int part, int nparts) const {
+        double r = 0.0;
+        for (int k = part; k < Ci; k += nparts) r += (double)Tm[(long)c * Ci + k] * (double)Elem<T>::to_f(w[(long)c * Ci + k]);
+        return r;
+    }
+    __device__ void operator()(int c, double s, double d) const {
+        const double q = (double)invstd[c] * (d - (double)mean[c] * s);
+        if (dbeta) dbeta[c] = (float)s;
+        if (dgamma) dgamma[c] = (float)q;
+        c1[c] = (float)(s / count);
+        c2[c] = (float)(q / count);
+    }
+};
+template <typename Fin, typename = void> struct FinHasDot { static constexpr bool value = false; };
+template <typename Fin> struct FinHasDot<Fin, decltype((void)Fin::kDot)> { static constexpr bool value = true; };
+
 template <typename Fin>
 __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ part, int tiles, int C, int NS, double* dpart,
                                                              unsigned* counters, const Fin fin) {
@@ -131,7 +159,51 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
             for (int i = 1; i < 8; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
         }
     }
+    if constexpr (FinHasDot<Fin>::value) {
+        double d = c < C ? fin.dot(c, rl, 8) : 0.0;
+        __syncthreads();   // (sh was read by the row-0 lanes above)
+        sh[0][rl][cl] = d;
+        __syncthreads();
+        if (rl == 0 && c < C) {
+            for (int i = 1; i < 8; ++i) d += sh[0][i][cl];
+            fin(c, s, d);
+        }
+        return;
+    }
     if (rl == 0 && c < C) fin(c, s, q);
+}
+
+// Batch statistics of y = x W^T (a 1x1 conv) WITHOUT y: mean_c = w_c . colsum(x) / M,  E[y_c^2] = w_c^T (x^T x) w_c / M.  gram: fp32
+// [rows >= Ci + 1][Ci] with x^T x in rows [0, Ci) and colsum(x) in row `ones_row` (rpe_gram); W is the compute-dtype copy the conv
+// multiplies with.  One block per output channel; the quadratic form is centred (S - s1 s1^T / M) and summed in double, the
+// threads' partial sums meet in a fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_gram_stats_kernel(const T* __restrict__ w, int Ci, const float* __restrict__ gram, int ones_row, const BnFwdFin fin) {
+    __shared__ float ws[1024];
+    __shared__ double red[2][256];
+    const int c = blockIdx.x;
+    for (int i = threadIdx.x; i < Ci; i += 256) ws[i] = Elem<T>::to_f(w[(long)c * Ci + i]);
+    __syncthreads();
+    const float* s1 = gram + (long)ones_row * Ci;
+    double q = 0.0, m = 0.0;
+    for (int i = threadIdx.x; i < Ci; i += 256) m += (double)ws[i] * (double)s1[i];
+    const double inv_count = 1.0 / fin.count;
+    for (int i = threadIdx.x >> 6; i < Ci; i += 4) {          // wave i-th row of S, lanes over its columns: coalesced
+        const float* row = gram + (long)i * Ci;
+        const double wi = ws[i], s1i = s1[i];
+        double r = 0.0;
+        for (int j = threadIdx.x & 63; j < Ci; j += 64) r += (double)ws[j] * ((double)row[j] - s1i * (double)s1[j] * inv_count);
+        q += wi * r;
+    }
+    red[0][threadIdx.x] = m;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sm = 0.0, sq = 0.0;
+        for (int i = 0; i < 256; ++i) { sm += red[0][i]; sq += red[1][i]; }
+        // fin expects (sum y, sum y^2): sum y^2 = centred form + (sum y)^2 / M
+        fin(c, sm, sq + sm * sm * inv_count);
+    }
 }
 
 __global__ void bn_eval_affine_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
@@ -882,14 +954,18 @@ int bn_apply_launch(const void* y, const void* res, void* out, const float* scal
     if (C % CE) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply: C must be a multiple of the 16-byte chunk");
     const long n = M * C / CE;
     const int cpr = C / CE;
-    const EwCfg cfg = ew_cfg();
+    EwCfg cfg = ew_cfg();
+    // the unrolled forms keep the per-channel coefficients in registers across the unroll, which needs the unroll stride (256 chunks or
+    // a multiple) to be a multiple of the chunks per row: a power of two.  Any other channel count (e.g. C = 192) takes the form without
+    // unroll, whose coefficients are re-read per 256-chunk piece.
+    if (!ew_pow2(cpr)) cfg.unr = 1;
     const long g = ew_grid_rows(n, cpr, cfg);
-    if (!ew_pow2(cpr)) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply: C / (16-byte chunk) must be a power of two");
     if (mask && sizeof(T) != 2) return rpe_set_error(RPE_ERR_DTYPE, "bn_apply_mask: the packed ReLU mask is written for 16-bit element types only");
 #define RPE_BN_APPLY(U, N, R) hipLaunchKernelGGL((bn_apply_kernel<T, U, N, R>), dim3((unsigned)g), dim3(256), 0, s, (const T*)y, (const T*)res, (T*)out, scale, shift, n, C, relu, mask, res_scale, res_shift)
     if (res_scale) {   // the residual under its own BatchNorm (rpe_bn_apply_res_bn): one configuration
         if (!res || !res_shift) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply: the residual and its shift are required with res_scale");
-        if (cfg.nt) RPE_BN_APPLY(4, true, true); else RPE_BN_APPLY(4, false, true);
+        if (cfg.unr == 1) { if (cfg.nt) RPE_BN_APPLY(1, true, true); else RPE_BN_APPLY(1, false, true); }
+        else if (cfg.nt) RPE_BN_APPLY(4, true, true); else RPE_BN_APPLY(4, false, true);
     }
     else if (cfg.nt) { if (cfg.unr == 1) RPE_BN_APPLY(1, true, false); else if (cfg.unr == 2) RPE_BN_APPLY(2, true, false); else RPE_BN_APPLY(4, true, false); }
     else { if (cfg.unr == 1) RPE_BN_APPLY(1, false, false); else if (cfg.unr == 2) RPE_BN_APPLY(2, false, false); else RPE_BN_APPLY(4, false, false); }
@@ -904,9 +980,9 @@ static int bn_apply_dz_launch(const void* dz, const void* y, const float* mean, 
     constexpr int CE = Elem<T>::kChunk;
     const int cpr = C / CE;
     const long n = M * C / CE;
-    const EwCfg cfg = ew_cfg();
+    EwCfg cfg = ew_cfg();
+    if (!ew_pow2(cpr)) cfg.unr = 1;   // (see bn_apply_launch)
     const long g = ew_grid_rows(n, cpr, cfg);
-    if (!ew_pow2(cpr)) return rpe_set_error(RPE_ERR_SHAPE, "bn_bwd_from_dz: C / (16-byte chunk) must be a power of two");
 #define RPE_BN_DZ(U, N) hipLaunchKernelGGL((bn_bwd_apply_dz_kernel<T, U, N>), dim3((unsigned)g), dim3(256), 0, s, (const T*)dz, (const T*)y, mean, invstd, gamma, c1, c2, (T*)dy, n, C)
     if (cfg.nt) { if (cfg.unr == 1) RPE_BN_DZ(1, true); else if (cfg.unr == 2) RPE_BN_DZ(2, true); else RPE_BN_DZ(4, true); }
     else { if (cfg.unr == 1) RPE_BN_DZ(1, false); else if (cfg.unr == 2) RPE_BN_DZ(2, false); else RPE_BN_DZ(4, false); }
@@ -1012,6 +1088,21 @@ int rpe_bn_finalize(const float* part, int tiles, int C, long count, const float
                                                            shift, save_mean, save_invstd}, (hipStream_t)stream);
 }
 
+int rpe_bn_stats_from_gram(int dtype, const void* w, int Co, int Ci, const float* gram, int ones_row, long count, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, long long* num_batches, float momentum, float eps, float* scale, float* shift,
+                           float* save_mean, float* save_invstd, void* stream) {
+    note_kernel("bn_gram_stats_kernel");
+    if (!w || !gram || Co <= 0 || Ci <= 0 || Ci > 1024 || count <= 0 || ones_row < Ci) return rpe_set_error(RPE_ERR_SHAPE, "bn_stats_from_gram: bad arguments (in_c <= 1024)");
+    const BnFwdFin fin{(double)count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, scale, shift, save_mean, save_invstd};
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == RPE_F32) hipLaunchKernelGGL((bn_gram_stats_kernel<float>), dim3(Co), dim3(256), 0, s, (const float*)w, Ci, gram, ones_row, fin);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((bn_gram_stats_kernel<bf16>), dim3(Co), dim3(256), 0, s, (const bf16*)w, Ci, gram, ones_row, fin);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((bn_gram_stats_kernel<f16>), dim3(Co), dim3(256), 0, s, (const f16*)w, Ci, gram, ones_row, fin);
+    else return rpe_set_error(RPE_ERR_DTYPE, "bn_stats_from_gram: unsupported dtype");
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
 int rpe_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                        float* scale, float* shift, void* stream) {
     hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma, beta, running_mean,
@@ -1091,6 +1182,18 @@ int rpe_bn_backward_coeffs(const float* stats_part, int tiles, int C, long rows,
     note_kernel("reduce_finalize_kernel<BnBwdFin>");
     if (!stats_part || !c1c2 || !dpart || tiles <= 0 || C <= 0 || rows <= 0) return rpe_set_error(RPE_ERR_SHAPE, "bn_backward_coeffs: bad arguments");
     return reduce_finalize(stats_part, tiles, C, dpart, BnBwdFin{(double)rows, dgamma, dbeta, c1c2, c1c2 + C}, (hipStream_t)stream);
+}
+
+int rpe_bn_backward_coeffs_t(int dtype, const float* stats_part, int tiles, int C, long rows, const float* dzt_a, const void* w, int Ci, const float* mean,
+                             const float* invstd, float* dgamma, float* dbeta, float* c1c2, double* dpart, void* stream) {
+    note_kernel("reduce_finalize_kernel<BnBwdFinT>");
+    if (!stats_part || !c1c2 || !dpart || !dzt_a || !w || !mean || !invstd || tiles <= 0 || C <= 0 || Ci <= 0 || rows <= 0)
+        return rpe_set_error(RPE_ERR_SHAPE, "bn_backward_coeffs_t: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == RPE_BF16) return reduce_finalize(stats_part, tiles, C, dpart, BnBwdFinT<bf16>{(double)rows, dgamma, dbeta, c1c2, c1c2 + C, dzt_a, (const bf16*)w, Ci, mean, invstd}, s);
+    if (dtype == RPE_F16) return reduce_finalize(stats_part, tiles, C, dpart, BnBwdFinT<f16>{(double)rows, dgamma, dbeta, c1c2, c1c2 + C, dzt_a, (const f16*)w, Ci, mean, invstd}, s);
+    if (dtype == RPE_F32) return reduce_finalize(stats_part, tiles, C, dpart, BnBwdFinT<float>{(double)rows, dgamma, dbeta, c1c2, c1c2 + C, dzt_a, (const float*)w, Ci, mean, invstd}, s);
+    return rpe_set_error(RPE_ERR_DTYPE, "bn_backward_coeffs_t: unsupported dtype");
 }
 
 int rpe_bn_backward_apply_dz(int dtype, const void* dz, const void* y, const float* mean, const float* invstd, const float* gamma, const float* c1c2,

@@ -68,6 +68,13 @@ class GradSync:
         # the blocking-API form costs nothing measurable (20.35 vs 20.30 ms).
         self._comm = None
         self._pending = False
+        # With blocking waits every collective would stall the HOST inside the backward's issue loop (the stage boundaries sit between
+        # the trunk engine's launches), serialising launch and exchange: refuse loudly rather than run 1.5x slower silently.
+        for var in ("TORCH_NCCL_BLOCKING_WAIT", "NCCL_BLOCKING_WAIT"):
+            if os.environ.get(var, "0") not in ("0", ""):
+                import warnings
+                warnings.warn("%s=%s: the staged gradient exchange issues its collectives inside the backward and relies on them being "
+                              "asynchronous to the host; with blocking waits each stage boundary stalls the launch loop" % (var, os.environ[var]))
 
     def buckets(self, lo=0, hi=None):
         hi = self.flat.numel() if hi is None else hi
@@ -143,6 +150,13 @@ def stage_slices(model):
          "layer4": (marks[3][1], marks[4][1]), "fc": (marks[4][1], marks[5][1])}
     # layer1 finishes before the stem but shares its slice: reduce the slice once, when the stem is done
     s["layer1"] = (0, 0)
+    # A frozen trunk body (feature_extract and use_pretrained, util/model_utils.py:110-113 of the reference: every published job) leaves
+    # ~23.5 M gradient elements that are zero on every rank: exchanging them (94 MB per step under a third of the full step's work)
+    # buys nothing.  Every stage is clipped to the span of the arena's TRAINABLE segments inside it; a stage without any becomes empty.
+    segs = arena.trainable_segments()
+    for name, (lo, hi) in list(s.items()):
+        inside = [(max(lo, a), min(hi, b)) for a, b in segs if min(hi, b) > max(lo, a)]
+        s[name] = (min(a for a, _ in inside), max(b for _, b in inside)) if inside else (lo, lo)
     return s
 
 

@@ -101,7 +101,9 @@ def conv2d_dgrad(dy, w_crsk, x_shape, stride, pad, addend=None):
 def conv2d_dgrad_bn(dy, w_crsk, x_shape, stride, pad, y, mean, invstd, a_out=None, scale=None, shift=None, addend=None, a_mask=None):
     """Data gradient with the producing layer's ReLU mask and BN-backward partial sums fused into the epilogue.
     Returns (dz [B,H,W,Ci], stats partials [tiles,2,Ci])."""
-    _chk(dy, "dy"), _chk(w_crsk, "w"), _chk(y, "y")
+    _chk(dy, "dy"), _chk(w_crsk, "w")
+    if y is not None:   # (y = None with a_mask: the producing layer's raw output was never written -- only sum dz is emitted)
+        _chk(y, "y")
     ci, k, co = w_crsk.shape[0], w_crsk.shape[1], w_crsk.shape[3]
     d = conv_desc(x_shape, co, k, stride, pad)
     dz = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device)
@@ -154,6 +156,31 @@ def bn_backward_coeffs(stats_part, rows):
     dpart = torch.zeros(256 * 2 * c + 64, dtype=torch.float64, device=dev)
     lib.rpe_bn_backward_coeffs(_p(stats_part), tiles, c, rows, _p(dgamma), _p(dbeta), _p(c1c2), _p(dpart), _stream())
     return dgamma, dbeta, c1c2
+
+
+def bn_backward_coeffs_t(stats_part, rows, dzt_a, w, mean, invstd):
+    """y3-free block: partial sums [tiles, 2, C] whose first half is sum dz, T = dz^T a_in [C, Ci] fp32 and the compute-dtype weight
+    [C, Ci] -> (dgamma, dbeta, c1c2): sum dz*xhat = invstd (rowdot(T, w) - mean sum dz)"""
+    tiles, _, c = stats_part.shape
+    ci = w.shape[1]
+    dev = stats_part.device
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    c1c2 = torch.empty((2, c), dtype=torch.float32, device=dev)
+    dpart = torch.zeros(256 * 2 * c + 64, dtype=torch.float64, device=dev)
+    lib.rpe_bn_backward_coeffs_t(dtype_code(w), _p(stats_part), tiles, c, rows, _p(_chk(dzt_a, "dzt_a")), _p(_chk(w, "w")), ci, _p(mean), _p(invstd), _p(dgamma),
+                                 _p(dbeta), _p(c1c2), _p(dpart), _stream())
+    return dgamma, dbeta, c1c2
+
+
+def conv1x1_wgrad_combine(dzt_a, gram_buf, w_master, gamma, invstd, mean, c1c2):
+    """dW [Co, Ci] fp32 of a y3-free block's conv3: A o (T - c1 s1^T) + C' o (W S - mean s1^T), S / s1 from the forward's Gram buffer"""
+    co, ci = dzt_a.shape
+    d = conv_desc((1, 1, 1, ci), co, 1, 1, 0)
+    dw = torch.empty((co, ci), dtype=torch.float32, device=dzt_a.device)
+    lib.rpe_conv1x1_wgrad_combine(ctypes.byref(d), _p(_chk(dzt_a, "dzt_a")), _p(gram_buf), _p(_chk(w_master, "w")), _p(gamma), _p(invstd), _p(mean), _p(c1c2),
+                                  _p(dw), _stream())
+    return dw
 
 
 def bn_backward_apply_dz(dz, y, mean, invstd, gamma, c1c2):
@@ -340,6 +367,40 @@ def bn_apply_res_bn(y, scale, shift, res_y, res_scale, res_shift, relu=True, wan
     lib.rpe_bn_apply_res_bn(dtype_code(y), _p(_chk(y, "y")), _p(res_y), _p(res_scale), _p(res_shift), _p(out), _p(scale), _p(shift), y.numel() // c, c,
                             int(relu), _p(mask), _stream())
     return (out, mask) if want_mask else out
+
+
+def gram(x):
+    """x [..., C] (NHWC activations) -> (x^T x [C, C], colsum(x) [C], the whole buffer) fp32, one launch + fixed-order slab sum"""
+    c = x.shape[-1]
+    m = x.numel() // c
+    code = dtype_code(x)
+    ones_row = lib.rpe_gram_ones_row(c)
+    out = torch.empty((ones_row + 1, c), dtype=torch.float32, device=x.device)
+    ws = scratch(lib.rpe_gram_workspace_bytes(code, m, c), x.device)
+    lib.rpe_gram(code, _p(_chk(x, "x")), m, c, _p(out), _p(ws), ws.numel(), _stream())
+    return out[:c], out[ones_row], out
+
+
+def bn_stats_from_gram(w, gram_buf, count, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    """BatchNorm statistics of y = x w^T from the Gram buffer of x (ops.gram): (scale, shift, mean, invstd)"""
+    co, ci = w.shape
+    dev = w.device
+    scale, shift, mean, invstd = (torch.empty(co, dtype=torch.float32, device=dev) for _ in range(4))
+    lib.rpe_bn_stats_from_gram(dtype_code(w), _p(_chk(w, "w")), co, ci, _p(gram_buf), lib.rpe_gram_ones_row(ci), int(count), _p(gamma), _p(beta),
+                               _p(running_mean), _p(running_var), None, momentum, eps, _p(scale), _p(shift), _p(mean), _p(invstd), _stream())
+    return scale, shift, mean, invstd
+
+
+def conv1x1_fwd_bn(x, w, scale, shift, residual=None, res_scale=None, res_shift=None, want_y=False):
+    """relu((x w^T) * scale + shift + residual [* res_scale + res_shift]) with the packed ReLU mask, one launch (16-bit types)"""
+    co, ci = w.shape
+    d = conv_desc(x.shape, co, 1, 1, 0)
+    out = torch.empty(tuple(x.shape[:-1]) + (co,), dtype=x.dtype, device=x.device)
+    y = torch.empty_like(out) if want_y else None
+    mask = torch.empty(out.numel() // 8, dtype=torch.uint8, device=x.device)
+    lib.rpe_conv1x1_fwd_bn(ctypes.byref(d), dtype_code(x), _p(_chk(x, "x")), _p(_chk(w, "w")), _p(out), _p(y), _p(scale), _p(shift), _p(residual),
+                           _p(res_scale), _p(res_shift), _p(mask), _stream())
+    return out, mask, y
 
 
 def bn_backward(dA, a_out, y, mean, invstd, gamma, want_dz=False):

@@ -13,7 +13,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from rgb_proprioceptive_pose_estimator_amd.dist import GradSync, broadcast_parameters, init_from_env, shard_bounds
+from rgb_proprioceptive_pose_estimator_amd.dist import GradSync, broadcast_parameters, init_from_env, shard_bounds, stage_slices
+from rgb_proprioceptive_pose_estimator_amd.params import ParamArena
 
 
 def _free_port():
@@ -82,3 +83,45 @@ def test_single_process_is_a_noop():
     flat = torch.arange(10.0)
     GradSync(flat).all_reduce()
     assert torch.equal(flat, torch.arange(10.0))
+
+
+def test_stage_slices_skip_the_frozen_trunk_body():
+    """feature_extract and use_pretrained (util/model_utils.py:110-113 of the reference) freeze the ResNet body: its gradient elements are
+    zero on every rank, so the staged exchange must cover the trainable segments only -- the replaced fc and the heads -- and every
+    body stage must come out empty; with nothing frozen the stages tile the whole arena."""
+    import torch.nn as nn
+
+    class Trunk(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = nn.Conv2d(3, 4, 3, bias=False)
+            self.bn1 = nn.BatchNorm2d(4)
+            self.layer1, self.layer2, self.layer3, self.layer4 = (nn.Sequential(nn.Conv2d(4, 4, 1, bias=False), nn.BatchNorm2d(4)) for _ in range(4))
+            self.fc = nn.Linear(4, 6)
+
+    class Model(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.trunk = Trunk()
+            self.head = nn.Linear(6, 7)
+
+    m = Model()
+    m._arena = ParamArena(m)
+    full = stage_slices(m)
+    spans = sorted(v for k, v in full.items() if k != "layer1")
+    assert spans[0][0] == 0 and spans[-1][1] == m._arena.numel and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    for name, p in m.trunk.named_parameters():
+        if not name.startswith("fc."):
+            p.requires_grad = False
+    frozen = stage_slices(m)
+    for name in ("stem", "layer1", "layer2", "layer3", "layer4"):
+        assert frozen[name][1] == frozen[name][0], name
+    lo, hi = frozen["fc"]
+    off = {id(p): o for p, o in zip(m._arena.params, m._arena.offsets)}
+    assert lo == off[id(m.trunk.fc.weight)] and hi == m._arena.numel
+    flat = torch.ones(m._arena.numel)
+    sync = GradSync(flat, reduce_single=False)
+    sync._slices, sync._seen = frozen, set()
+    for name in ("fc", "layer4", "layer3", "layer2", "layer1", "stem"):
+        sync.stage_done(name)
+    sync.finish()

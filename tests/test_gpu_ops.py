@@ -463,6 +463,32 @@ def test_bn_train_fwd_bwd(dtype, c, rows_hw, residual):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c", [192, 48, 2304])
+def test_bn_streaming_kernels_any_channel_count(dtype, c):
+    """The unrolled streaming BN kernels keep their per-channel coefficients in registers, which needs C / (16-byte chunk) to be a
+    power of two; any other channel count (C = 192, ...) must take the form without unroll instead of being refused: rpe_bn_apply,
+    rpe_bn_apply_mask, rpe_bn_apply_res_bn, rpe_bn_backward_apply_dz."""
+    g = torch.Generator().manual_seed(c)
+    rows = 700
+    y, r = q(torch.randn(rows, c, generator=g) * 1.5 + 0.2, dtype), q(torch.randn(rows, c, generator=g), dtype)
+    sc, sh = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    rsc, rsh = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    yd, rd = y.to(dtype).to(DEV), r.to(dtype).to(DEV)
+    assert rel_err(ops.bn_apply(yd, sc.to(DEV), sh.to(DEV), rd, relu=True), F.relu(y * sc + sh + r)) < tol(dtype)
+    assert rel_err(ops.bn_apply_res_bn(yd, sc.to(DEV), sh.to(DEV), rd, rsc.to(DEV), rsh.to(DEV)), F.relu(y * sc + sh + r * rsc + rsh)) < tol(dtype)
+    if dtype != torch.float32:
+        out, mask = ops.bn_apply_mask(yd, sc.to(DEV), sh.to(DEV), rd)
+        bits = ((mask.cpu()[:, None] >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(rows, c).bool()
+        assert torch.equal(bits, out.cpu().float() > 0)
+    mean, invstd, gamma = torch.randn(c, generator=g) * 0.2, torch.rand(c, generator=g) + 0.5, torch.rand(c, generator=g) + 0.5
+    c1c2 = torch.randn(2, c, generator=g) * 0.1
+    dz = q(torch.randn(rows, c, generator=g), dtype)
+    ref = gamma * invstd * (dz - c1c2[0] - (y - mean) * invstd * c1c2[1])
+    dy = ops.bn_backward_apply_dz(dz.to(dtype).to(DEV), yd, mean.to(DEV), invstd.to(DEV), gamma.to(DEV), c1c2.to(DEV))
+    assert rel_err(dy, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_maxpool_avgpool(dtype):
     g = torch.Generator().manual_seed(1)
     x = q(torch.randn(2, 64, 16, 16, generator=g), dtype).clamp_min(0).requires_grad_(True)  # post-ReLU-like (ties at 0)
@@ -778,6 +804,120 @@ def test_bn_apply_with_shortcut_bn_on_the_fly(dtype, rows, c):
         assert torch.equal(out2, out)
         bits = ((mask.cpu()[:, None] >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(rows, c).bool()
         assert torch.equal(bits, out.cpu().float() > 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cfg", [(8, 28, 64, 256), (4, 14, 128, 512), (6, 14, 256, 1024), (2, 6, 64, 256)])
+@pytest.mark.parametrize("shortcut", ["identity", "projection", "none"])
+def test_conv1x1_forward_with_bn_from_gram(dtype, cfg, shortcut):
+    """conv3 -> bn3 -> (+identity) -> ReLU without writing or re-reading the conv output: BatchNorm statistics from the Gram matrix of
+    the INPUT (rpe_gram + rpe_bn_stats_from_gram) against the statistics of the conv output itself; the fused forward
+    (rpe_conv1x1_fwd_bn) against conv -> batch_norm -> add -> relu; mask = the positive outputs."""
+    b, h, ci, co = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = q(F.relu(torch.randn(b, h, h, ci, generator=g) * 1.5 + 0.4), dtype)          # post-ReLU activations: positive means
+    w = q(torch.randn(co, ci, generator=g) / ci ** 0.5, dtype)
+    gamma, beta = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.3
+    rows = b * h * h
+    y64 = x.reshape(rows, ci).double() @ w.double().t()
+    mean_ref, var_ref = y64.mean(0), y64.var(0, unbiased=False)
+    xd, wd = x.to(dtype).to(DEV), w.to(dtype).to(DEV)
+    S, s1, buf = ops.gram(xd)
+    assert rel_err(S, (x.reshape(rows, ci).double().t() @ x.reshape(rows, ci).double()).float()) < 2e-5
+    assert rel_err(s1, x.reshape(rows, ci).double().sum(0).float()) < 2e-5
+    assert torch.equal(buf, ops.gram(xd)[2])                                          # fixed-order sums
+    rm, rv = torch.zeros(co, device=DEV), torch.ones(co, device=DEV)
+    scale, shift, mean, invstd = ops.bn_stats_from_gram(wd, buf, rows, gamma.to(DEV), beta.to(DEV), rm, rv)
+    assert rel_err(mean, mean_ref.float()) < 1e-4
+    assert ((invstd.cpu().double() * torch.sqrt(var_ref + 1e-5) - 1).abs().max()) < 2e-4
+    assert rel_err(rm, 0.1 * mean_ref.float()) < 1e-4
+    assert rel_err(rv, (0.9 + 0.1 * var_ref * rows / (rows - 1)).float()) < 2e-4
+    res = rs = rb = None
+    ref = (y64 - mean_ref) / torch.sqrt(var_ref + 1e-5) * gamma.double() + beta.double()
+    if shortcut != "none":
+        res = q(torch.randn(rows, co, generator=g), dtype)
+        if shortcut == "projection":
+            rs, rb = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.3
+            ref = ref + res.double() * rs.double() + rb.double()
+        else:
+            ref = ref + res.double()
+    ref = F.relu(ref).float().reshape(b, h, h, co)
+    dev = lambda t: None if t is None else t.to(DEV)
+    out, mask, y = ops.conv1x1_fwd_bn(xd, wd, scale, shift, None if res is None else res.to(dtype).to(DEV).reshape(b, h, h, co), dev(rs), dev(rb), want_y=True)
+    assert rel_err(out, ref) < tol(dtype)
+    assert rel_err(y, y64.float().reshape(b, h, h, co)) < tol(dtype)
+    bits = ((mask.cpu()[:, None] >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(rows, co).bool()
+    assert torch.equal(bits, out.cpu().float().reshape(rows, co) > 0)
+    out2, mask2, none = ops.conv1x1_fwd_bn(xd, wd, scale, shift, None if res is None else res.to(dtype).to(DEV).reshape(b, h, h, co), dev(rs), dev(rb))
+    assert none is None and torch.equal(out2, out) and torch.equal(mask2, mask)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cfg", [(4, 28, 64, 256, 64), (3, 14, 128, 512, 128), (2, 6, 64, 256, 128), (2, 14, 256, 1024, 256)])
+def test_y3_free_bottleneck_backward(dtype, cfg):
+    """The backward of a block whose raw conv3 output was never written.  a2 -> conv3 (1x1) -> bn3 -> + identity -> ReLU = a3 -> next
+    conv1 (1x1).  (a) the next block's fused conv1 data gradient with bn->y = NULL: the same dz as with y, sum dz in the partial rows
+    and zeros in their second half; (b) rpe_bn_backward_coeffs_t (sum dz*xhat from T = dz^T a2 and W) == the coefficients from y itself,
+    dgamma / dbeta == autograd; (c) rpe_conv1x1_wgrad_combine (T + the forward's Gram buffer) == autograd's conv3 weight gradient;
+    (d) the folded data gradient from those coefficients == autograd's gradient of a2."""
+    b, h, p, co, nxt = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    rows = b * h * h
+    a2 = q(F.relu(torch.randn(rows, p, generator=g) * 1.2 + 0.3), dtype)
+    w3 = q(torch.randn(co, p, generator=g) / p ** 0.5, dtype)
+    idn = q(F.relu(torch.randn(rows, co, generator=g)), dtype)
+    gamma, beta = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.3
+    w1n = q(torch.randn(nxt, co, generator=g) / co ** 0.5, dtype)          # the next block's conv1 [out, in]
+    dy1 = q(torch.randn(rows, nxt, generator=g), dtype)                     # gradient of its raw output
+    sc_grad = q(torch.randn(rows, co, generator=g), dtype)                 # the shortcut's gradient term
+    # GPU forward pieces
+    dev = lambda t: t.to(DEV)
+    a2d, w3d = a2.to(dtype).to(DEV).reshape(b, h, h, p), w3.to(dtype).to(DEV)
+    S, s1, buf = ops.gram(a2d)
+    scale, shift, mean, invstd = ops.bn_stats_from_gram(w3d, buf, rows, dev(gamma), dev(beta))
+    out, mask, y = ops.conv1x1_fwd_bn(a2d, w3d, scale, shift, idn.to(dtype).to(DEV).reshape(b, h, h, co), want_y=True)
+    bits = ((mask.cpu()[:, None] >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(rows, co).double()
+    # reference in double; the ReLU gate is the forward's packed mask (elements within rounding of 0 may fall on either side)
+    a2r = a2.double().requires_grad_(True)
+    w3r = w3.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y3 = a2r @ w3r.t()
+    z = F.batch_norm(y3, None, None, gr, br, True, 0.1, 1e-5)
+    pre = z + idn.double()
+    assert ((pre.detach() > 0).double() != bits).double().mean() < 2e-3
+    a3 = pre * bits
+    dA = dy1.double() @ w1n.double() + sc_grad.double()
+    da2_ref, dw_ref, dg_ref, db_ref = torch.autograd.grad(a3, (a2r, w3r, gr, br), dA)
+    dz_ref = dA * bits
+    # (a)
+    w_crsk = w1n.t().contiguous().reshape(co, 1, 1, nxt).to(dtype).to(DEV)
+    dyd, add = dy1.to(dtype).to(DEV).reshape(b, h, h, nxt), sc_grad.to(dtype).to(DEV).reshape(b, h, h, co)
+    t = {torch.bfloat16: 3e-2, torch.float16: 5e-3}[dtype]
+    dz_y, st_y = ops.conv2d_dgrad_bn(dyd, w_crsk, (b, h, h, co), 1, 0, y, mean, invstd, addend=add, a_mask=mask)
+    dz, st = ops.conv2d_dgrad_bn(dyd, w_crsk, (b, h, h, co), 1, 0, None, None, None, addend=add, a_mask=mask)
+    assert torch.equal(dz, dz_y) and float(st[:, 1].abs().max()) == 0.0
+    assert rel_err(st[:, 0].sum(0), dz.float().reshape(rows, co).sum(0)) < 1e-5          # the sum of dz AS STORED (rounded), so that it is
+    assert rel_err(st[:, 0].sum(0), st_y[:, 0].sum(0)) < t                              # consistent with T = dz^T a2 in (b)
+    assert rel_err(dz.reshape(rows, co), dz_ref.float()) < t
+    # (b)
+    T = ops.conv2d_wgrad(a2d, dz, 1, 1, 0).reshape(co, p)
+    dg, db, c1c2 = ops.bn_backward_coeffs_t(st, rows, T, w3d, mean, invstd)
+    dg_y, db_y, c1c2_y = ops.bn_backward_coeffs(st_y, rows)
+    assert rel_err(db, db_y) < t and rel_err(c1c2[0], c1c2_y[0]) < t
+    dzf = dz.float().cpu().reshape(rows, co).double()
+    y_exact = a2.double() @ w3.double().t()
+    q_exact = ((y_exact - mean.cpu().double()) * invstd.cpu().double() * dzf).sum(0)
+    assert rel_err(dg, q_exact.float()) < 1e-4                              # the T form sees the unrounded y and the stored dz
+    assert rel_err(dg, dg_ref.float()) < t and rel_err(db, db_ref.float()) < t
+    # (c)
+    w3m = w3.to(DEV).contiguous()
+    dw = ops.conv1x1_wgrad_combine(T, buf, w3m, dev(gamma), invstd, mean, c1c2)
+    assert rel_err(dw, dw_ref.float()) < t
+    assert torch.equal(dw, ops.conv1x1_wgrad_combine(T, buf, w3m, dev(gamma), invstd, mean, c1c2))
+    # (d)
+    wk, bias = ops.bn_bwd_fold_conv1x1(w3d, w3d.t().contiguous(), dev(gamma), invstd, mean, c1c2)
+    dx = ops.conv1x1_dgrad_kcat(dz, a2d, wk, bias)
+    assert rel_err(dx.reshape(rows, p), da2_ref.float()) < t
 
 
 def test_operands_above_2_gib():

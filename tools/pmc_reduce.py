@@ -85,7 +85,16 @@ def main():
                      "per_launch_MB": round((fetch_gb + write_gb) * 1e3 / lps, 2)})
     rows.sort(key=lambda r: -(r["fetch_GB_per_step"] + r["write_GB_per_step"]))
     total = sum(r["fetch_GB_per_step"] + r["write_GB_per_step"] for r in rows)
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 2 --warmup 1 "
+    # the build the counters belong to: the hash compiled into the library that the profiled command loaded (rpe_build_id, read here
+    # through ctypes without touching the GPU); bench.py withholds `roofline.traffic` when it does not match the library IT loaded
+    import ctypes
+    import os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.environ.get("RPE_LIB_PATH") or os.path.join(here, "rgb-proprioceptive-pose-estimator_amd", "librpe_hip.so")
+    h = ctypes.CDLL(so)
+    h.rpe_build_id.restype = ctypes.c_char_p
+    build_id = h.rpe_build_id().decode()
+    json.dump({"build_id": build_id, "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 2 --warmup 1 "
                        "--no-cpu-baseline`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); counter "
                        "unit KB; every figure is per train step (each pass normalised by its own number of optimizer launches); "
                        "per_launch_MB = (corrected fetch + write) / launches",
