@@ -111,6 +111,11 @@ int rpe_conv2d_dgrad_bn(const rpe_conv_desc* d, int dtype, const void* dy, const
  * mean / invstd, running statistics), from the Gram matrix and the compute-dtype weight.  rpe_conv1x1_fwd_bn: the conv with
  * out = relu(acc * scale + shift + residual [* res_scale + res_shift]) and the packed ReLU mask in its epilogue -- the raw output
  * is written only when y_out is given. */
+/* rpe_bn_apply_gram: out = relu(y * scale + shift) (bn2's apply pass) AND the Gram buffer of `out` -- same layout and values as rpe_gram(out)
+ * -- in one pass over y (C = 64 or 128, 16-bit element types; workspace = per-workgroup fp32 partials, summed in a fixed order). */
+long rpe_bn_apply_gram_workspace_bytes(int dtype, long rows, int C);
+int rpe_bn_apply_gram(int dtype, const void* y, void* out, const float* scale, const float* shift, long rows, int C, float* gram_out,
+                      void* workspace, long workspace_bytes, void* stream);
 long rpe_gram_ones_row(int C);
 long rpe_gram_workspace_bytes(int dtype, long M, int C);
 int rpe_gram(int dtype, const void* x, long M, int C, float* out, void* workspace, long workspace_bytes, void* stream);

@@ -88,6 +88,8 @@ _SPEC = {
     "rpe_bn_apply_mask": (I, [I, P, P, P, P, P, L, I, P, P]),
     "rpe_bn_backward_coeffs_t": (I, [I, P, I, I, L, P, P, I, P, P, P, P, P, P, P]),
     "rpe_conv1x1_wgrad_combine": (I, [PD, P, P, P, P, P, P, P, P, P]),
+    "rpe_bn_apply_gram_workspace_bytes": (L, [I, L, I]),
+    "rpe_bn_apply_gram": (I, [I, P, P, P, P, L, I, P, P, L, P]),
     "rpe_gram_ones_row": (L, [I]),
     "rpe_gram_workspace_bytes": (L, [I, L, I]),
     "rpe_gram": (I, [I, P, L, I, P, P, L, P]),

@@ -134,6 +134,7 @@ struct rpe_resnet50 {
     // forward but y3 still written and the round-3 backward (A/B of the two halves); RPE_Y3FREE_MAX: widest planes handled this way.
     bool y3free = false;
     bool y3_keep = false;
+    bool apply_gram = true;      // bn2's apply pass and the Gram matrix of its output in ONE launch (rpe_bn_apply_gram; RPE_NO_APPLY_GRAM=1: two)
     int y3free_max = 128;
     void* gram_ws = nullptr;     // slab of the Gram launches (caller's stream)
     long gram_ws_bytes = 0;
@@ -361,6 +362,7 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
     if (e->y3free) {
         if (getenv("RPE_Y3FREE_MAX")) e->y3free_max = atoi(getenv("RPE_Y3FREE_MAX"));
         e->y3_keep = getenv("RPE_Y3_KEEP") != nullptr;
+        e->apply_gram = getenv("RPE_NO_APPLY_GRAM") == nullptr;
         for (auto& b : e->blocks) {
             const ConvL& c3 = e->convs[b.c3];
             if (c3.d.in_c > e->y3free_max || c3.d.in_c > 256 || (c3.d.in_c % 64)) continue;
@@ -368,6 +370,8 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
             want(e, (void**)&b.dzt_a, (long)c3.d.out_c * c3.d.in_c * 4);
             const long wsb = rpe_gram_workspace_bytes(dtype, c3.rows, c3.d.in_c);
             if (wsb > e->gram_ws_bytes) e->gram_ws_bytes = wsb;
+            const long wsb2 = rpe_bn_apply_gram_workspace_bytes(dtype, c3.rows, c3.d.in_c);   // (-1: not a shape of the fused form)
+            if (wsb2 > e->gram_ws_bytes) e->gram_ws_bytes = wsb2;
             const long tb = rpe_conv2d_wgrad_workspace_bytes(&c3.d, dtype);   // dz3^T a2 runs on the caller's stream: its slab
             if (tb > y3_slab) y3_slab = tb;
         }
@@ -637,7 +641,7 @@ static int ensure_side(rpe_resnet50* e) {
 // res_bn: the residual is the RAW output of that layer (the projection shortcut) and its BatchNorm is applied inside this layer's
 // apply pass (rpe_bn_apply_res_bn); stats_only: stop after the statistics (the shortcut itself then has no apply pass).
 static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residual, int relu, void* stream, bool second_set = false,
-                   unsigned char* relu_mask = nullptr, const ConvL* res_bn = nullptr, bool stats_only = false) {
+                   unsigned char* relu_mask = nullptr, const ConvL* res_bn = nullptr, bool stats_only = false, float* gram_out = nullptr) {
     const bool train = e->train_mode != 0;
     float* stats = second_set ? e->stats_part2 : e->stats_part;
     double* dpart = second_set ? e->dpart2 : e->dpart;
@@ -667,6 +671,11 @@ static int conv_bn(rpe_resnet50* e, ConvL& c, const void* x, const void* residua
     if (res_bn) {
         PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_apply_res_bn(e->dtype, c.y, res_bn->y, res_bn->scale, res_bn->shift, c.a, c.scale, c.shift, c.rows, c.d.out_c, relu,
                                                             relu ? relu_mask : nullptr, stream));
+        return 0;
+    }
+    if (gram_out) {   // bn2 of a y3-free block: apply + ReLU and the Gram matrix / column sums of the result in one pass
+        if (residual || !relu) return rpe_set_error(RPE_ERR_STATE, "trunk engine: the fused apply + Gram pass takes no residual");
+        PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_apply_gram(e->dtype, c.y, c.a, c.scale, c.shift, c.rows, c.d.out_c, gram_out, e->gram_ws, e->gram_ws_bytes, stream));
         return 0;
     }
     if (relu_mask && relu) PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_apply_mask(e->dtype, c.y, residual, c.a, c.scale, c.shift, c.rows, c.d.out_c, relu_mask, stream));
@@ -747,16 +756,20 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
             idn = cd.a;
         }
         TRY(conv_bn(e, c1, x, nullptr, 1, stream));
-        TRY(conv_bn(e, c2, c1.a, nullptr, 1, stream));
+        const bool y3f_fwd = training && b.gram && b.relu_mask;
+        const bool fused_gram = y3f_fwd && e->apply_gram && (c2.d.out_c == 64 || c2.d.out_c == 128);
+        TRY(conv_bn(e, c2, c1.a, nullptr, 1, stream, false, nullptr, nullptr, false, fused_gram ? b.gram : nullptr));
         if (b.cd >= 0 && !ds_done) { ConvL& cd = e->convs[b.cd]; TRY(conv_bn(e, cd, x, nullptr, 0, stream, false, nullptr, nullptr, fuse_ds)); idn = cd.a; }
         if (ds_done) HIPTRY(hipStreamWaitEvent((hipStream_t)stream, ds_done, 0));
         static const bool use_mask = getenv("RPE_NO_RELU_MASK") == nullptr;
-        if (training && b.gram && b.relu_mask) {
+        if (y3f_fwd) {
             // y3-free: Gram matrix of a2 -> BN3 statistics -> conv3 with BN + identity (under the shortcut's BN) + ReLU + mask in its epilogue
             const ConvL* cdp = (b.cd >= 0 && fuse_ds) ? &e->convs[b.cd] : nullptr;
-            e->pending_flops = 2.0 * (double)c3.rows * c3.d.in_c * c3.d.in_c;
-            e->pending_bytes = conv_in_bytes(e, c3);
-            PROF(e, RPE_PROF_BN_FWD, stream, rpe_gram(e->dtype, c2.a, c3.rows, c3.d.in_c, b.gram, e->gram_ws, e->gram_ws_bytes, stream));
+            if (!fused_gram) {   // (else bn2's apply pass left the Gram matrix behind)
+                e->pending_flops = 2.0 * (double)c3.rows * c3.d.in_c * c3.d.in_c;
+                e->pending_bytes = conv_in_bytes(e, c3);
+                PROF(e, RPE_PROF_BN_FWD, stream, rpe_gram(e->dtype, c2.a, c3.rows, c3.d.in_c, b.gram, e->gram_ws, e->gram_ws_bytes, stream));
+            }
             e->pending_bytes = 0;
             PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_stats_from_gram(e->dtype, c3.wf, c3.d.out_c, c3.d.in_c, b.gram, (int)rpe_gram_ones_row(c3.d.in_c), c3.rows,
                                                                     e->params[c3.p_g], e->params[c3.p_b], e->running[2 * c3.bn_i], e->running[2 * c3.bn_i + 1],

@@ -179,28 +179,40 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
 // threads' partial sums meet in a fixed order.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_gram_stats_kernel(const T* __restrict__ w, int Ci, const float* __restrict__ gram, int ones_row, const BnFwdFin fin) {
-    __shared__ float ws[1024];
-    __shared__ double red[2][256];
-    const int c = blockIdx.x;
-    for (int i = threadIdx.x; i < Ci; i += 256) ws[i] = Elem<T>::to_f(w[(long)c * Ci + i]);
-    __syncthreads();
+    __shared__ float ws[1024], s1s[1024];
+    __shared__ double red[2][4];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* s1 = gram + (long)ones_row * Ci;
-    double q = 0.0, m = 0.0;
-    for (int i = threadIdx.x; i < Ci; i += 256) m += (double)ws[i] * (double)s1[i];
+    for (int i = threadIdx.x; i < Ci; i += 256) { ws[i] = Elem<T>::to_f(w[(long)c * Ci + i]); s1s[i] = s1[i]; }
+    __syncthreads();
     const double inv_count = 1.0 / fin.count;
-    for (int i = threadIdx.x >> 6; i < Ci; i += 4) {          // wave i-th row of S, lanes over its columns: coalesced
-        const float* row = gram + (long)i * Ci;
-        const double wi = ws[i], s1i = s1[i];
-        double r = 0.0;
-        for (int j = threadIdx.x & 63; j < Ci; j += 64) r += (double)ws[j] * ((double)row[j] - s1i * (double)s1[j] * inv_count);
-        q += wi * r;
+    double m = 0.0;
+    for (int i = threadIdx.x; i < Ci; i += 256) m += (double)ws[i] * (double)s1s[i];
+    // element idx = i * Ci + j of S: consecutive threads read consecutive floats, 8 loads in flight per thread (the block sits on the
+    // forward's critical path once per y3-free block: the one-row-per-wave walk of round 2 took 23 us for 128 x 128)
+    const int n = Ci * Ci;
+    double q0 = 0.0, q1 = 0.0;
+    for (int base = threadIdx.x; base < n; base += 256 * 8) {
+        float sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int idx = base + u * 256; sv[u] = idx < n ? gram[idx] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 256;
+            if (idx < n) {
+                const int i = idx / Ci, j = idx - i * Ci;
+                const double t = (double)ws[i] * (double)ws[j] * ((double)sv[u] - (double)s1s[i] * (double)s1s[j] * inv_count);
+                if (u & 1) q1 += t; else q0 += t;
+            }
+        }
     }
-    red[0][threadIdx.x] = m;
-    red[1][threadIdx.x] = q;
+    double q = q0 + q1;
+    m = wave_sum_d(m);
+    q = wave_sum_d(q);
+    if (lane == 0) { red[0][wave] = m; red[1][wave] = q; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double sm = 0.0, sq = 0.0;
-        for (int i = 0; i < 256; ++i) { sm += red[0][i]; sq += red[1][i]; }
+        const double sm = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), sq = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
         // fin expects (sum y, sum y^2): sum y^2 = centred form + (sum y)^2 / M
         fin(c, sm, sq + sm * sm * inv_count);
     }

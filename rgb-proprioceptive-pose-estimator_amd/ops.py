@@ -381,6 +381,19 @@ def gram(x):
     return out[:c], out[ones_row], out
 
 
+def bn_apply_gram(y, scale, shift):
+    """relu(y * scale + shift) and the Gram buffer of the result (as ops.gram) in one pass: (out, S [C, C], s1 [C], buffer)"""
+    c = y.shape[-1]
+    m = y.numel() // c
+    code = dtype_code(y)
+    ones_row = lib.rpe_gram_ones_row(c)
+    buf = torch.zeros((ones_row + 1, c), dtype=torch.float32, device=y.device)
+    out = torch.empty_like(y)
+    ws = scratch(lib.rpe_bn_apply_gram_workspace_bytes(code, m, c), y.device)
+    lib.rpe_bn_apply_gram(code, _p(_chk(y, "y")), _p(out), _p(scale), _p(shift), m, c, _p(buf), _p(ws), ws.numel(), _stream())
+    return out, buf[:c], buf[ones_row], buf
+
+
 def bn_stats_from_gram(w, gram_buf, count, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
     """BatchNorm statistics of y = x w^T from the Gram buffer of x (ops.gram): (scale, shift, mean, invstd)"""
     co, ci = w.shape

@@ -120,25 +120,67 @@ def test_model_fp32_matches_reference_and_oracle(kind, golden_dir):
     for name, p in named.items():  # parameters the reference leaves without a gradient stay untouched by Adam
         if name not in ref["grads"]:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
-    # Adam step, then compare every parameter with the oracle's post-step value
+    # Adam step 1: the UPDATE of every parameter against the oracle's.  The first Adam step is -lr g / (|g| + eps) = -lr sign(g) wherever
+    # |g| >> eps, so two implementations agree on an element to ~1e-6 or differ by 2 lr (a gradient element at the fp32 noise floor of
+    # this net -- see the gradient bars above -- with the other sign); an optimizer that did nothing scores 0 on every tensor here
+    # (round 3's check, allclose with atol 2.1e-3 > lr, could not tell).  Head / fc / aux tensors are well conditioned: every live
+    # element must agree.  Trunk tensors: measured per-tensor agreement 0.961-0.977 at worst, 0.990-0.995 median over the five families
+    # (tools/adam_parity_probe.py, profiles/r04_adam_parity.txt); elements whose reference gradient is above 5 % of the tensor's
+    # largest may disagree in fewer than 1e-4 of all cases (measured 31-169 elements of 23.5 M).
+    lr = 1e-3
     sd_after = {k: v.clone() for k, v in sd.items()}
-    po.train_step(kind, cfg, sd_after, b1c, LOSS_CFG, {}, lr=1e-3)
+    ost = {}
+    r1 = po.train_step(kind, cfg, sd_after, b1c, LOSS_CFG, ost, lr=lr)
     opt.step()
-    msd = model.state_dict()
-    bad = []
-    for k, v in sd_after.items():
-        if k.startswith("~"):
+    msd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    trunk_frac, strong_bad, strong_n = [], 0, 0
+    for k, g in r1["grads"].items():
+        if k not in msd:   # (td's unregistered aux / depth heads: no optimizer sees them, models/time_sensitive.py:102-115)
             continue
-        a = msd[k].detach().float().cpu()
-        # one Adam step moves each element by <= lr; sign flips of noise-level gradients differ by <= 2*lr
-        if not torch.allclose(a, v.float(), rtol=1e-4, atol=2.1e-3):
-            bad.append(k)
-    assert not bad, bad[:5]
+        u_ref = sd_after[k].float() - sd[k].float()
+        u_gpu = msd[k] - sd[k].float()
+        live = g.abs() > 1e-7 * g.abs().max().clamp_min(1e-30)
+        if not live.any():
+            continue
+        ok = (u_gpu - u_ref).abs() <= 1e-2 * lr
+        frac = (ok & live).sum().item() / live.sum().item()
+        strong = g.abs() > 0.05 * g.abs().max()
+        strong_bad += int((~ok & strong).sum())
+        strong_n += int(strong.sum())
+        if "feature_net" in k and ".fc." not in k:
+            trunk_frac.append(frac)
+        else:
+            assert frac >= 0.9999, "Adam step 1, %s: %.5f of the live elements moved as the reference's" % (k, frac)
+        assert float(u_gpu.abs().max()) <= lr * 1.001, k
+    assert min(trunk_frac) >= 0.95 and np.median(trunk_frac) >= 0.985, "Adam step 1, trunk tensors: agreement min %.4f median %.4f" % (min(trunk_frac), np.median(trunk_frac))
+    assert strong_bad <= 1e-4 * strong_n, "Adam step 1: %d of %d strong-gradient elements moved against the reference" % (strong_bad, strong_n)
     for k in msd:
         if k.endswith("running_mean") or k.endswith("running_var"):
             assert rel(msd[k], sd_after[k]) < 1e-4, k
         if k.endswith("num_batches_tracked"):
             assert int(msd[k]) == 1
+    # Step 2 on the reference's second batch, then the reference's own post-2-step vectors (`final::` / `final_digest` of the golden
+    # file).  From step 2 on the two runs see slightly different trunks (the sign flips above), so head gradients differ at the 1e-2
+    # level and an element may be one full step apart: every head / fc / aux element within 2.1 lr, half of them within 5e-5 (measured:
+    # max 2.4e-4 .. 1.6e-3); every tensor's l2 norm within 1 % of the reference's digest (measured <= 5.1e-3, the deep running_var's).
+    b2c = po.synth_batch(lead, dseed + 2, with_depth=cfg.get("use_depth", False))
+    model.reset_initial_state(lead[-1])
+    opt.zero_grad()
+    run_step(model, kind, to_dev(b2c), crit, val)
+    opt.step()
+    msd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    for k in gold.files:
+        if not k.startswith("final::") or k.endswith("num_batches_tracked"):
+            continue
+        name = k[7:]
+        if "feature_net" in name and ".fc." not in name:
+            continue
+        d = (msd[name] - torch.from_numpy(gold[k]).float()).abs()
+        assert float(d.max()) <= 2.1 * lr and float(d.median()) <= 5e-5, "after 2 Adam steps, %s: max %.3e median %.3e off the reference" % (name, d.max(), d.median())
+    for name, ref_d in zip(gold["keys"], gold["final_digest"]):
+        t = msd[str(name)].double()
+        if ref_d[1] > 0:
+            assert abs(t.norm().item() - ref_d[1]) <= 1e-2 * ref_d[1], "after 2 Adam steps, l2 norm of %s: %.6g vs %.6g" % (name, t.norm().item(), ref_d[1])
 
 
 @pytest.mark.parametrize("kind", ["no", "tdo"])

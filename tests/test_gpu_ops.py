@@ -853,6 +853,26 @@ def test_conv1x1_forward_with_bn_from_gram(dtype, cfg, shortcut):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,c", [(8 * 28 * 28, 64), (3 * 14 * 14, 128), (72, 64), (200, 128), (40000, 64), (70001, 128)])
+def test_bn_apply_fused_with_gram(dtype, rows, c):
+    """rpe_bn_apply_gram: bitwise the output of rpe_bn_apply (ReLU), and the Gram matrix / column sums of THAT output (what rpe_gram
+    computes from it in a second pass) -- any row count incl. ragged tails and several workgroups; repeatable bit for bit."""
+    g = torch.Generator().manual_seed(rows + c)
+    y = q(torch.randn(rows, c, generator=g) * 1.5 + 0.3, dtype)
+    sc, sh = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    yd = y.to(dtype).to(DEV)
+    out, S, s1, buf = ops.bn_apply_gram(yd, sc.to(DEV), sh.to(DEV))
+    ref = ops.bn_apply(yd, sc.to(DEV), sh.to(DEV), None, relu=True)
+    assert torch.equal(out, ref)
+    a = out.double().cpu()
+    assert rel_err(S, (a.t() @ a).float()) < 2e-5
+    assert rel_err(s1, a.sum(0).float()) < 2e-5
+    S2, s12, _ = ops.gram(out)
+    assert rel_err(S, S2) < 2e-5 and rel_err(s1, s12) < 2e-5
+    assert torch.equal(buf, ops.bn_apply_gram(yd, sc.to(DEV), sh.to(DEV))[3])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cfg", [(4, 28, 64, 256, 64), (3, 14, 128, 512, 128), (2, 6, 64, 256, 128), (2, 14, 256, 1024, 256)])
 def test_y3_free_bottleneck_backward(dtype, cfg):
     """The backward of a block whose raw conv3 output was never written.  a2 -> conv3 (1x1) -> bn3 -> + identity -> ReLU = a3 -> next

@@ -29,12 +29,26 @@ DEV = "cuda"
 # paths round every activation to 8 (bf16) or 11 (fp16) significant bits.
 # Bars ~2x what is measured at the configs[0] size (bf16 8.2e-3, fp16 1.8e-3; fp32 1.8e-6 against the north-star 1e-4).
 OUT_TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2, torch.float16: 4e-3}
-# the toy golden cases run train-mode BatchNorm over 2-4 images: the statistics of so few samples amplify the storage rounding further
-# (measured worst cases over the five families: bf16 3.4e-2, fp16 1.4e-2 -- the two-stage `n` model)
+# The toy golden cases run train-mode BatchNorm over 2-4 images: the statistics of so few samples amplify the storage rounding
+# chaotically.  Round 3 held the ONE golden seed of every family to a fixed bar (bf16 6.5e-2, fp16 2.5e-2: "2x the measured 3.4e-2 /
+# 1.4e-2").  Round 4 measured what that bar is worth (tools/y3_accuracy_probe.py, profiles/r04_y3_accuracy.txt): over six weight / data
+# seeds of the two-stage `n` case the ROUND-3 dataflow itself lands between 0.043 and 0.104 and the y3-free dataflow between 0.047 and
+# 0.135 -- while its block outputs are 1 % CLOSER to the fp32 trunk at every one of the 16 blocks (profiles/r04_y3_layer_error.txt):
+# a fixed bar on one seed is a coin flip for any correct 16-bit implementation.  The toy pose outputs are therefore graded like the
+# gradients: over TOY_SEEDS seeds, against an independent yardstick with the same storage type -- the CPU oracle with every stored
+# activation rounded to the compute dtype (pose_oracle.EMULATE) -- median error <= 1.25x the emulation's + 5e-3, worst case <= 2x its
+# worst + 1e-2.  The LOSS of the golden seed keeps the fixed bar below.
 TOY_TOL = {torch.float32: 1e-4, torch.bfloat16: 6.5e-2, torch.float16: 2.5e-2}
+TOY_SEEDS = 4
 # config-sized sequence models (32 images): the LSTM stacks -- in `td` two of them in series -- carry the trunk's storage rounding
 # further than the MLP of configs[0] does (measured: td bf16 2.1e-2 on the second output)
-SEQ_TOL = {torch.float32: 1e-4, torch.bfloat16: 4.5e-2, torch.float16: 1e-2}
+SEQ_TOL = {torch.float32: 1e-4, torch.bfloat16: 3e-2, torch.float16: 1e-2}
+# ... except the SECOND output of `td` in bf16: it sits behind two LSTM stacks in series (measured 2.1e-2 in eval mode in round 3)
+TD_OUT1_BF16_TOL = 4.5e-2
+
+
+def seq_tol(kind, dtype, i):
+    return TD_OUT1_BF16_TOL if (kind == "td" and dtype == torch.bfloat16 and i == 1) else SEQ_TOL[dtype]
 # GRADIENT bars.  At random initialisation this 50-layer train-mode-BN network amplifies rounding noise in the backward by
 # ~1e5 (every BN backward subtracts the common-mode part of the gradient, the rounding noise stays): two fp32 implementations
 # differ by 1-3e-2 per trunk tensor, and gradients computed with 16-bit activation storage are mostly noise in the early
@@ -48,12 +62,16 @@ SEQ_TOL = {torch.float32: 1e-4, torch.bfloat16: 4.5e-2, torch.float16: 1e-2}
 F32_GRAD_BAR = (0.999, 3e-2)
 
 
-def emulated_grads(kind, cfg, sd, batch, dtype):
+def emulated_step(kind, cfg, sd, batch, dtype):
     po.EMULATE = dtype
     try:
-        return po.train_step(kind, cfg, {k: v.clone() for k, v in sd.items()}, batch, LOSS_CFG, {}, lr=1e-3, val_metrics=False)["grads"]
+        return po.train_step(kind, cfg, {k: v.clone() for k, v in sd.items()}, batch, LOSS_CFG, {}, lr=1e-3, val_metrics=False)
     finally:
         po.EMULATE = None
+
+
+def emulated_grads(kind, cfg, sd, batch, dtype):
+    return emulated_step(kind, cfg, sd, batch, dtype)["grads"]
 
 
 def check_16bit_against_emulation(tag, hip, emu, truth):
@@ -194,9 +212,6 @@ def test_all_models_16bit_gradient_quality(kind, dtype, golden_dir):
         outs = (out,)
     loss.backward()
     tol = TOY_TOL[dtype]
-    print("%s[%s] toy: pose rel err %s" % (kind, dtype, ["%.3e" % rel(o, gold["out%d_s1" % i]) for i, o in enumerate(outs)]))
-    for i, o in enumerate(outs):
-        assert rel(o, gold["out%d_s1" % i]) < tol, "out%d" % i
     np.testing.assert_allclose(loss.item(), gold["loss_s1"], rtol=tol)
     scale = 1.0 if model.loss_scaler is None else model.loss_scaler.get_scale()
     named = dict(model.named_parameters())
@@ -205,8 +220,31 @@ def test_all_models_16bit_gradient_quality(kind, dtype, golden_dir):
         g = named[name].grad
         assert g is not None and torch.isfinite(g).all(), name
         hip[name] = g.detach().cpu().double() / scale
-    emu = emulated_grads(kind, cfg, sd, b1c, dtype)
-    check_16bit_against_emulation("%s[%s]" % (kind, dtype), hip, emu, ref64["grads"])
+    emu_step = emulated_step(kind, cfg, sd, b1c, dtype)
+    check_16bit_against_emulation("%s[%s]" % (kind, dtype), hip, emu_step["grads"], ref64["grads"])
+    # pose outputs over TOY_SEEDS weight / data seeds (seed 0 = the golden case, graded against the reference's own vectors; the others
+    # against the fp32 oracle, which tests/test_oracle_golden.py pins to the reference) -- HIP path vs the 16-bit-storage emulation
+    tup = lambda o: o if isinstance(o, tuple) else (o,)
+    e_hip = [max(rel(o, gold["out%d_s1" % i]) for i, o in enumerate(outs))]
+    e_emu = [max(rel(o, gold["out%d_s1" % i]) for i, o in enumerate(tup(emu_step["outputs"])))]
+    for s in range(1, TOY_SEEDS):
+        sd_s = po.make_state(kind, cfg, wseed + 100 * s)
+        b_s = po.synth_batch(lead, dseed + 1 + 10 * s, with_depth=cfg.get("use_depth", False))
+        ref_s = tup(po.train_step(kind, cfg, {k: v.clone() for k, v in sd_s.items()}, b_s, LOSS_CFG, {}, lr=1e-3, val_metrics=False)["outputs"])
+        emu_s = tup(emulated_step(kind, cfg, sd_s, b_s, dtype)["outputs"])
+        m = quiet_build(kind, cfg, dtype)
+        load_values(m, kind, sd_s)
+        m.cuda().train()
+        m.reset_initial_state(lead[-1])
+        bd = to_dev(b_s)
+        with torch.no_grad():
+            o_s = tup(m(bd["img"], bd["depth"], bd["x0bar"]))
+        e_hip.append(max(rel(o, r) for o, r in zip(o_s, ref_s)))
+        e_emu.append(max(rel(o, r) for o, r in zip(emu_s, ref_s)))
+    print("%s[%s] toy: pose rel err over %d seeds: HIP %s (median %.3e) | emulation %s (median %.3e)" % (
+        kind, dtype, TOY_SEEDS, ["%.3e" % e for e in e_hip], np.median(e_hip), ["%.3e" % e for e in e_emu], np.median(e_emu)))
+    assert np.median(e_hip) <= 1.25 * np.median(e_emu) + 5e-3, "median pose error %.4f vs emulation %.4f" % (np.median(e_hip), np.median(e_emu))
+    assert max(e_hip) <= 2.0 * max(e_emu) + 1e-2, "worst pose error %.4f vs emulation %.4f" % (max(e_hip), max(e_emu))
 
 
 def test_bs64_flat_gradient_matches_cpu_oracle():
@@ -295,8 +333,8 @@ def test_config_sized_sequence_models_match_reference(kind, dtype, golden_dir):
         out = model(b9["img"], b9["depth"], b9["x0bar"])
     for i, o in enumerate(out if isinstance(out, tuple) else (out,)):
         e = rel(o, gold["pre_eval_out%d" % i])
-        print("%s_cfg[%s]: eval out%d rel err %.3e" % (kind, dtype, i, e))
-        assert e < max(tol, 2e-4), "eval out%d %.3g" % (i, e)
+        print("%s_cfg[%s]: eval out%d rel err %.3e (bar %.1e)" % (kind, dtype, i, e, max(seq_tol(kind, dtype, i), 2e-4)))
+        assert e < max(seq_tol(kind, dtype, i), 2e-4), "eval out%d %.3g" % (i, e)
     model.train()
     model.reset_initial_state(lead[-1])
     b1 = to_dev(po.synth_batch(lead, dseed + 1, with_depth=use_depth))
@@ -310,9 +348,11 @@ def test_config_sized_sequence_models_match_reference(kind, dtype, golden_dir):
         pe, oe = val(out, b1["obj"])
         outs = (out,)
     loss.backward()
-    worst = max(rel(o, gold["out%d_s1" % i]) for i, o in enumerate(outs))
-    print("%s_cfg[%s]: pose rel err %.3e, loss rel %.3e" % (kind, dtype, worst, abs(loss.item() - gold["loss_s1"]) / gold["loss_s1"]))
-    assert worst < tol
+    errs = [rel(o, gold["out%d_s1" % i]) for i, o in enumerate(outs)]
+    print("%s_cfg[%s]: pose rel err %s (bars %s), loss rel %.3e" % (kind, dtype, ["%.3e" % e for e in errs], ["%.1e" % seq_tol(kind, dtype, i) for i in range(len(errs))],
+                                                                  abs(loss.item() - gold["loss_s1"]) / gold["loss_s1"]))
+    for i, e in enumerate(errs):
+        assert e < seq_tol(kind, dtype, i), "out%d %.3g" % (i, e)
     np.testing.assert_allclose(loss.item(), gold["loss_s1"], rtol=tol)
     np.testing.assert_allclose(float(pe), gold["pos_err_s1"], rtol=tol)
     np.testing.assert_allclose(oe, gold["ori_err_s1"], rtol=max(tol, 1e-4), atol=1e-4)
