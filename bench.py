@@ -260,7 +260,7 @@ def main():
     for i in range(args.steps):
         loss, _, _ = run_step()
         nan_flags[i] = loss != loss
-    host_issue_ms = (time.perf_counter() - t0) / args.steps * 1e3   # what the host needs to ISSUE a step (it runs ahead of the device when this is < ms_per_step)
+    host_loop_ms = (time.perf_counter() - t0) / args.steps * 1e3   # host time per step INSIDE the free-running loop (see host_issue_ms below)
     fence()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -280,6 +280,23 @@ def main():
                      "tests/golden/model_no_nanloss.npz); gradients and parameters finite" % (nan_loss_steps, args.steps))
 
     log("[bench] timed region: %.1f ms/step" % (dt / args.steps * 1e3))
+    # What the HOST needs to issue one step, measured on ISOLATED steps (outside the timed region): each starts with the device idle and
+    # is timed until its last call has returned, so the host never waits for the device.  The per-step host time inside the free-running
+    # timed loop (host_loop_ms_per_step) is NOT that: the HIP runtime lets a process run only a few steps ahead of the device (its
+    # kernel-argument / signal pools are bounded: the loop's host time follows the device time at a fixed distance -- round 4 measured
+    # 15.0 -> 14.1 ms when the DEVICE step went 19.24 -> 18.91 ms, profiles/r04_ab_t_gemm_off_chain.txt), so round 3's 12.3 ms was mostly waiting.
+    iso = []
+    for _ in range(5):
+        fence()
+        t1 = time.perf_counter()
+        run_step()
+        iso.append((time.perf_counter() - t1) * 1e3)
+    fence()
+    host_issue_ms = sorted(iso)[len(iso) // 2]
+    if world > 1:   # the slowest rank's host is the one that matters
+        th = torch.tensor([host_issue_ms, host_loop_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(th, op=dist.ReduceOp.MAX)
+        host_issue_ms, host_loop_ms = th[0].item(), th[1].item()
     # ---- profiled pass (not timed): HIP events around every launch of the trunk plan, per kernel family ----
     plan = model.trunk._active
     n_prof = 3
@@ -357,7 +374,7 @@ def main():
             # describe the state after precondition_steps + warmup + steps updates.  The timed loop's statements are `run_step()` and the
             # device-side NaN test of the loss value (two small elementwise launches per step, inside the timed region since round 3).
             "precondition_s": round(precondition_s, 2), "precondition_steps": precondition_steps,
-            "host_issue_ms_per_step": round(host_issue_ms, 2),
+            "host_issue_ms_per_step": round(host_issue_ms, 2), "host_loop_ms_per_step": round(host_loop_ms, 2),
             "config": {"workload": workloads[args.model] + (" [use_depth=True]" if dh else ""), "model": args.model,
                        "images_per_gpu": args.batch, "global_batch": args.batch * world, "resolution": 224, "latent_dim": 512,
                        "parallelism": "dp%d" % world + (" (RCCL world 1: staged joins + bucketed all-reduce on one GPU)" if args.force_dist else ""),

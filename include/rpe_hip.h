@@ -162,6 +162,13 @@ int rpe_conv1x1_wgrad_folded(const rpe_conv_desc* d, int dtype, const void* dz, 
  * rpe_bn_backward_coeffs_t = rpe_bn_backward_coeffs with that second sum (w: the compute-dtype weight [C][Ci] the forward used), and
  * rpe_conv1x1_wgrad_combine = the last step of rpe_conv1x1_wgrad_folded from T and the FORWARD's Gram buffer (rpe_gram of a_in):
  * dw = A o (T - c1 s1^T) + C' o (W S - mean s1^T).  Replaces autograd's BatchNorm2d + conv3 backward of a torchvision Bottleneck. */
+/* rpe_conv1x1_dgrad_bn_t: the fused data gradient of the NEXT block's conv1 (rpe_conv2d_dgrad_bn with bn->y = NULL: dz of the producing
+ * block, its ReLU mask applied, sum dz per tile) that ALSO leaves T = dz^T a_prev ([in_c][P] fp32, a_prev [rows][P] = the producing
+ * block's conv3 input, P = 64 or 128) behind -- from the dz tile on its way out, so the separate dz^T a launch and its re-read of dz
+ * are gone.  Persistent launch (per-workgroup partials in `workspace`, summed in workgroup order: deterministic). */
+long rpe_conv1x1_dgrad_bn_t_workspace_bytes(const rpe_conv_desc* d, int P);
+int rpe_conv1x1_dgrad_bn_t(const rpe_conv_desc* d, int dtype, const void* dy, const void* w_crsk, void* dz, const void* addend, const rpe_bn_bwd_epilogue* bn,
+                           const void* a_prev, int P, float* t_out, void* workspace, long workspace_bytes, void* stream);
 int rpe_bn_backward_coeffs_t(int dtype, const float* stats_part, int tiles, int C, long rows, const float* dzt_a, const void* w, int Ci, const float* mean,
                              const float* invstd, float* dgamma, float* dbeta, float* c1c2, double* dpart, void* stream);
 int rpe_conv1x1_wgrad_combine(const rpe_conv_desc* d, const float* dzt_a, const float* gram, const float* w_master, const float* gamma, const float* invstd,

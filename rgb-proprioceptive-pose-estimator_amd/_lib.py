@@ -86,6 +86,8 @@ _SPEC = {
     "rpe_bn_eval_affine": (I, [I, P, P, P, P, F, P, P, P]),
     "rpe_bn_apply": (I, [I, P, P, P, P, P, L, I, I, P]),
     "rpe_bn_apply_mask": (I, [I, P, P, P, P, P, L, I, P, P]),
+    "rpe_conv1x1_dgrad_bn_t_workspace_bytes": (L, [PD, I]),
+    "rpe_conv1x1_dgrad_bn_t": (I, [PD, I, P, P, P, P, POINTER(BnBwdEpilogue), P, I, P, P, L, P]),
     "rpe_bn_backward_coeffs_t": (I, [I, P, I, I, L, P, P, I, P, P, P, P, P, P, P]),
     "rpe_conv1x1_wgrad_combine": (I, [PD, P, P, P, P, P, P, P, P, P]),
     "rpe_bn_apply_gram_workspace_bytes": (L, [I, L, I]),

@@ -436,6 +436,56 @@ static int conv1x1_wgrad_folded_t(const rpe_conv_desc* d, const void* dz, const 
     return 0;
 }
 
+// ---- fused conv1 data gradient of the NEXT block + T = dz^T a of the producing (y3-free) block --------------------------------
+// sum of the persistent launch's per-workgroup partials [grid][128][P] in workgroup order: column tile t owns slabs t, t + tiles_n, ...;
+// out rows [128 t, 128 t + 128).  One block per 64 float4 groups, 8 waves over the slabs (as tn_reduce_kernel), fixed order.
+__global__ __launch_bounds__(512) void t_slab_sum_kernel(const float* __restrict__ slab, int nslabs, long stride4, int n4, float* __restrict__ out) {
+    __shared__ f32x4 sh[8][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + lane, tile = blockIdx.y;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (idx < n4) {
+        const f32x4* src = (const f32x4*)slab + (long)tile * n4 + idx;
+        int g = w;
+        for (; g + 8 < nslabs; g += 16) {
+            const f32x4 a = src[(long)g * stride4], b = src[(long)(g + 8) * stride4];
+            s0 += a; s1 += b;
+        }
+        if (g < nslabs) s0 += src[(long)g * stride4];
+    }
+    sh[w][lane] = s0 + s1;
+    __syncthreads();
+    if (w != 0 || idx >= n4) return;
+    f32x4 sum = sh[0][lane];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) sum += sh[i][lane];
+    ((f32x4*)out)[(long)tile * n4 + idx] = sum;
+}
+
+template <typename T>
+static int conv1x1_dgrad_bn_t_t(const rpe_conv_desc* d, const void* dy, const void* w_crsk, void* dz, const void* addend, const rpe_bn_bwd_epilogue* bn,
+                                const void* a_prev, int P, float* t_out, void* ws, long ws_bytes, hipStream_t s) {
+    NTArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.A = (const T*)dy; a.Bw = (const T*)w_crsk; a.C = (T*)dz;
+    a.M = d->batch * d->in_h * d->in_w; a.N = d->in_c; a.K = d->out_c;
+    a.lda = d->out_c; a.ldb = a.K; a.ldc = d->in_c;
+    a.addend = (const T*)addend; a.ld_add = d->in_c;
+    a.role = 1;
+    a.bn_mode = P == 64 ? 6 : 7;
+    a.bn_mask = bn->a_mask; a.stats_part = bn->stats_part;
+    a.t_a = (const T*)a_prev; a.t_slab = (float*)ws;
+    a.tiles_per_wg = nt_tfuse_tiles_per_wg(a.M, a.N);
+    const long grid = nt_tfuse_grid(a.M, a.N);
+    if (ws_bytes < grid * 128L * P * 4) return rpe_set_error(RPE_ERR_WORKSPACE, "conv1x1_dgrad_bn_t: workspace smaller than rpe_conv1x1_dgrad_bn_t_workspace_bytes()");
+    if (int e = launch_nt<T>(a, MODE_DENSE, s)) return e;
+    prof_split(s, "t_slab_sum_kernel");
+    const int tiles_n = a.N / 128, n4 = 128 * P / 4;
+    hipLaunchKernelGGL(t_slab_sum_kernel, dim3((n4 + 63) / 64, tiles_n), dim3(512), 0, s, (const float*)ws, (int)(grid / tiles_n), (long)tiles_n * n4, n4, t_out);
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
 // Gram matrix and column sums of x [M][C] in one TN launch (P = Q = x plus the all-ones tile): out [ones_row + 1][C] fp32 with
 // x^T x in rows [0, C) and colsum(x) in row ones_row = roundup(C, 128).  ws: the launch's slab (deterministic fixed-order sum).
 static inline int gram_ones_row(int C) { return (C + 127) / 128 * 128; }
@@ -908,6 +958,24 @@ int rpe_conv1x1_wgrad_combine(const rpe_conv_desc* d, const float* dzt_a, const 
                        w_master, gamma, invstd, mean, c1c2, c1c2 + Co, Co, Ci);
     RPE_CHECK_LAUNCH();
     return 0;
+}
+
+long rpe_conv1x1_dgrad_bn_t_workspace_bytes(const rpe_conv_desc* d, int P) {
+    if (check_desc(d) || !is_dense(d) || (d->in_c % 128) || (P != 64 && P != 128)) return -1;
+    return nt_tfuse_grid((long)d->batch * d->in_h * d->in_w, d->in_c) * 128L * P * 4;
+}
+
+int rpe_conv1x1_dgrad_bn_t(const rpe_conv_desc* d, int dtype, const void* dy, const void* w_crsk, void* dz, const void* addend, const rpe_bn_bwd_epilogue* bn,
+                           const void* a_prev, int P, float* t_out, void* workspace, long workspace_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    if (!is_dense(d) || (d->in_c % 128) || (d->out_c % 8)) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_dgrad_bn_t: 1x1 / stride 1, in_c % 128 == 0");
+    if (P != 64 && P != 128) return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_dgrad_bn_t: the second operand has 64 or 128 channels");
+    if (!dy || !w_crsk || !dz || !bn || !bn->a_mask || !bn->stats_part || bn->y || !a_prev || !t_out || !workspace)
+        return rpe_set_error(RPE_ERR_SHAPE, "conv1x1_dgrad_bn_t: dy, w, dz, bn (a_mask + stats_part, y = NULL), a_prev, t_out and the workspace are required");
+    if ((((uintptr_t)a_prev) | ((uintptr_t)t_out) | ((uintptr_t)workspace)) & 15) return rpe_set_error(RPE_ERR_ALIGN, "conv1x1_dgrad_bn_t: 16-byte aligned operands");
+    if (dtype == RPE_BF16) return conv1x1_dgrad_bn_t_t<bf16>(d, dy, w_crsk, dz, addend, bn, a_prev, P, t_out, workspace, workspace_bytes, (hipStream_t)stream);
+    if (dtype == RPE_F16) return conv1x1_dgrad_bn_t_t<f16>(d, dy, w_crsk, dz, addend, bn, a_prev, P, t_out, workspace, workspace_bytes, (hipStream_t)stream);
+    return rpe_set_error(RPE_ERR_DTYPE, "conv1x1_dgrad_bn_t: 16-bit element types only");
 }
 
 long rpe_gram_ones_row(int C) { return gram_ones_row(C); }

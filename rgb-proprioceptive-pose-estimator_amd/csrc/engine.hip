@@ -42,6 +42,7 @@ struct Block {
     // (BN3 statistics without y3) and read again by the backward's weight-gradient combine; dzt_a: fp32 [4 planes][planes] = dz3^T a2
     float* gram = nullptr;
     float* dzt_a = nullptr;
+    bool t_ready = false;   // backward: dzt_a was already left behind by the next block's fused conv1 data gradient (rpe_conv1x1_dgrad_bn_t)
     unsigned char* relu_mask = nullptr;  // 16-bit element types: packed ReLU mask of the block output (1 bit per element), written by its bn_apply
 };
 
@@ -134,6 +135,12 @@ struct rpe_resnet50 {
     // forward but y3 still written and the round-3 backward (A/B of the two halves); RPE_Y3FREE_MAX: widest planes handled this way.
     bool y3free = false;
     bool y3_keep = false;
+    // dz3^T a2 as a side product of the NEXT block's fused conv1 data gradient (rpe_conv1x1_dgrad_bn_t: persistent over row tiles, the partial
+    // in registers).  Built, bit-exact against the separate launch, and SLOWER in the step: 19.47-19.50 vs 19.16-19.18 ms (profiles/
+    // r04_ab_t_fused.txt).  Per kernel: the fused launch streams at 2.2 TB/s where the plain one reaches 3.5-3.7 (251 VGPRs + 68 KB of LDS = two
+    // workgroups per CU instead of three, and three more barriers per tile), 467 us against 272 + 146 us for layer1's blocks -- the side
+    // product costs the HBM-bound epilogue more than the separate dz^T a2 launch and its re-read of dz.  OFF by default; RPE_T_FUSE=1 enables it.
+    bool t_fused = false;
     bool apply_gram = true;      // bn2's apply pass and the Gram matrix of its output in ONE launch (rpe_bn_apply_gram; RPE_NO_APPLY_GRAM=1: two)
     int y3free_max = 128;
     void* gram_ws = nullptr;     // slab of the Gram launches (caller's stream)
@@ -363,6 +370,7 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
         if (getenv("RPE_Y3FREE_MAX")) e->y3free_max = atoi(getenv("RPE_Y3FREE_MAX"));
         e->y3_keep = getenv("RPE_Y3_KEEP") != nullptr;
         e->apply_gram = getenv("RPE_NO_APPLY_GRAM") == nullptr;
+        e->t_fused = getenv("RPE_T_FUSE") != nullptr;
         for (auto& b : e->blocks) {
             const ConvL& c3 = e->convs[b.c3];
             if (c3.d.in_c > e->y3free_max || c3.d.in_c > 256 || (c3.d.in_c % 64)) continue;
@@ -374,6 +382,10 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
             if (wsb2 > e->gram_ws_bytes) e->gram_ws_bytes = wsb2;
             const long tb = rpe_conv2d_wgrad_workspace_bytes(&c3.d, dtype);   // dz3^T a2 runs on the caller's stream: its slab
             if (tb > y3_slab) y3_slab = tb;
+            // ... or rides on the next block's fused conv1 data gradient, whose row space and columns are this block's output
+            rpe_conv_desc dn = c3.d; dn.in_c = c3.d.out_c; dn.out_c = c3.d.in_c;
+            const long tb2 = rpe_conv1x1_dgrad_bn_t_workspace_bytes(&dn, c3.d.in_c);
+            if (tb2 > y3_slab) y3_slab = tb2;
         }
         if (e->gram_ws_bytes > 0) want(e, &e->gram_ws, e->gram_ws_bytes);
     }
@@ -823,7 +835,7 @@ static int bn_back(rpe_resnet50* e, ConvL& c, const void* dA, int relu, void* dy
 // data gradient of conv `c` with the BN-backward reduction of layer `bnl` (the layer producing c's input) fused in.
 // mask_mode 1: ReLU mask from bnl.a (residual block output); 2: mask recomputed from bnl.y, scale, shift.
 static int dgrad_fused(rpe_resnet50* e, ConvL& c, const void* dy, void* dz, const void* addend, ConvL* bnl, int mask_mode, void* stream,
-                       const unsigned char* relu_mask = nullptr, bool no_y = false) {
+                       const unsigned char* relu_mask = nullptr, bool no_y = false, const void* t_a = nullptr, int t_p = 0, float* t_out = nullptr) {
     rpe_bn_bwd_epilogue ep;
     ep.y = no_y ? nullptr : bnl->y;                      // (y3-free block: sum dz only, rpe_conv2d_dgrad_bn)
     ep.a_mask = mask_mode == 1 ? relu_mask : nullptr;   // block outputs: 1 bit per element instead of re-reading a_out
@@ -836,6 +848,12 @@ static int dgrad_fused(rpe_resnet50* e, ConvL& c, const void* dy, void* dz, cons
     // reads dy; writes dz; the fused epilogue also reads y (and a_out for residual outputs) and the shortcut addend
     e->pending_bytes = conv_out_bytes(e, c) + conv_in_bytes(e, c) * ((no_y ? 1.0 : 2.0) + (mask_mode == 1 ? (ep.a_mask ? 1.0 / 16 : 1.0) : 0.0) + (addend ? 1.0 : 0.0));
     e->fused_tiles = (int)rpe_conv2d_dgrad_stats_tiles(&c.d, e->dtype);  // partial-sum rows this launch leaves behind
+    if (t_out) {   // ... and T = dz^T a2 of the producing block from the tile on its way out (persistent launch)
+        e->pending_flops += 2.0 * (double)c.rows * c.d.in_c * t_p;
+        e->pending_bytes += conv_in_bytes(e, c) * (double)t_p / c.d.in_c;
+        PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv1x1_dgrad_bn_t(&c.d, e->dtype, dy, c.wd, dz, addend, &ep, t_a, t_p, t_out, e->main_slab, e->main_slab_bytes, stream));
+        return 0;
+    }
     PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad_bn(&c.d, e->dtype, dy, c.wd, dz, addend, &ep, stream));
     return 0;
 }
@@ -888,6 +906,16 @@ static int conv1x1_backward_folded(rpe_resnet50* e, ConvL& c, const void* dz, Co
         // y3-free block: T = dz^T a2 first (caller's stream: the coefficients need it), then sum dz (partials) + rowdot(T, W) -> c1, c2
         e->pending_flops = conv_flops(c);
         e->pending_bytes = conv_in_bytes(e, c) + conv_out_bytes(e, c);
+        static const bool exp_t_side = getenv("RPE_EXP_T_SIDE") != nullptr;   // TIMING EXPERIMENT ONLY (wrong coefficients): dz^T a2 off the data-gradient chain
+        if (y3f->t_ready) {
+            // (the next block's fused conv1 data gradient left dz^T a2 behind)
+        } else
+        if (exp_t_side) {
+            ConvL* cp = &c; const Block* bp = y3f;
+            TRY(to_side(e, stream, [e, cp, x, dz, bp](hipStream_t run) -> int {
+                PROF(e, RPE_PROF_CONV_WGRAD, run, rpe_conv2d_wgrad_det(&cp->d, e->dtype, x, dz, bp->dzt_a, e->wg_slab, e->wg_slab_bytes, run));
+                return 0; }));
+        } else
         PROF(e, RPE_PROF_CONV_WGRAD, stream, rpe_conv2d_wgrad_det(&c.d, e->dtype, x, dz, y3f->dzt_a, e->main_slab, e->main_slab_bytes, stream));
         e->pending_bytes = 0;
         PROF(e, RPE_PROF_BN_BWD, stream, rpe_bn_backward_coeffs_t(e->dtype, e->stats_part, e->fused_tiles, c.d.out_c, c.rows, y3f->dzt_a, c.wf, c.d.in_c, c.mean, c.invstd,
@@ -1104,8 +1132,12 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
         } else
         if (bi > 0) {
             const Block& pb = e->blocks[bi - 1];
-            TRY(dgrad_fused(e, c1, c1.dy, gD, shortcut, &e->convs[pb.c3], 1, stream, use_mask ? pb.relu_mask : nullptr,
-                            pb.gram && pb.relu_mask && !e->y3_keep));             // dz3 of the previous block
+            const bool pb_y3f = pb.gram && pb.relu_mask && !e->y3_keep;
+            const ConvL& p3 = e->convs[pb.c3];
+            const bool t_here = pb_y3f && e->t_fused && (p3.d.in_c == 64 || p3.d.in_c == 128) && (c1.d.in_c % 128) == 0 && c1.d.kh == 1 && c1.d.stride == 1;
+            e->blocks[bi - 1].t_ready = t_here;
+            TRY(dgrad_fused(e, c1, c1.dy, gD, shortcut, &e->convs[pb.c3], 1, stream, use_mask ? pb.relu_mask : nullptr, pb_y3f,
+                            t_here ? e->convs[pb.c2].a : nullptr, p3.d.in_c, t_here ? pb.dzt_a : nullptr));   // dz3 of the previous block (+ its dz3^T a2)
         } else {
             PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&c1.d, e->dtype, c1.dy, c1.wd, gD, shortcut, stream));
         }

@@ -112,6 +112,14 @@ template <typename T> struct NTArgs {
     const float *fwd_scale, *fwd_shift, *res_scale, *res_shift;
     unsigned char* mask_out;
     T* y_out;
+    // bn_mode 6 / 7 (dense data-gradient role, 16-bit types): mode 5 plus the SIDE PRODUCT  Tm[n][k] = sum_m C[m][n] * t_a[m][k]  of the
+    // tile on its way out (C = dz as stored) with a second row-major tensor t_a [M][64 (mode 6) | 128 (mode 7)] -- the weight gradient's
+    // first product dz^T a of the PRODUCING block (rpe_conv1x1_dgrad_bn_t).  The launch is persistent: workgroup g walks row tiles
+    // g / tiles_n + it * (grid / tiles_n) of column tile g % tiles_n (tiles_per_wg iterations), keeps its 128 x 64|128 partial in
+    // registers and stores it once to t_slab [grid][128][64|128] fp32; the launcher's slab sum adds them in workgroup order.
+    const T* t_a;
+    float* t_slab;
+    int tiles_per_wg;
     // Split-K form of the inference forward (few output tiles, long K: one rollout frame).  role 3 with `slab` set and
     // splits > 1 runs as role 4: grid.y = splits, workgroup (tile, z) walks K steps [z * split_steps, (z+1) * split_steps)
     // and stores its raw fp32 accumulators (fragment order) into slab[z][tile]; nt_split_epilogue_kernel then adds the
@@ -137,6 +145,19 @@ static inline int nt_split_plan(long M, int N, int K, int bk, int* steps_per_spl
     const int steps = (nk + (int)S - 1) / (int)S;
     if (steps_per_split) *steps_per_split = steps;
     return (nk + steps - 1) / steps;
+}
+// grid of the persistent data-gradient launch with the T side product (NTArgs::t_a): two workgroups per CU (68 KB of LDS, ~200 VGPRs), a
+// multiple of the column tiles, never more than the tiles there are
+static inline long nt_tfuse_grid(long M, int N) {
+    const long tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
+    long per = 512 / tiles_n;
+    if (per > tiles_m) per = tiles_m;
+    if (per < 1) per = 1;
+    return per * tiles_n;
+}
+static inline int nt_tfuse_tiles_per_wg(long M, int N) {
+    const long tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128, per = nt_tfuse_grid(M, N) / tiles_n;
+    return (int)((tiles_m + per - 1) / per);
 }
 static inline long nt_split_slab_bytes(long M, int N, int splits) { return ((M + 63) / 64) * ((N + 63) / 64) * (long)splits * 64 * 64 * 4; }
 

@@ -105,12 +105,39 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
     constexpr int NSTAGE = DMA ? NST : 2;              // DMA path: ring of NST slots, NST-1 tiles in flight
     static_assert(DMA || (WAVES_M == 2 && KCH == 4), "register staging is only wired for the 128-row / 64-B-row config");
     static_assert(NST >= 2 && NST <= (MODE == MODE_HALO ? 4 : 3), "ring depth 2..3 (halo form: ..4)");
-    __shared__ u32x4 lds[(NSTAGE * STAGE + PATCH16 > EPI16) ? NSTAGE * STAGE + PATCH16 : EPI16];
+    // T side product (NTArgs::t_a; BNM 6 / 7): behind the epilogue's staging rows the LDS holds the dz tile as stored (16-bit, [row][16
+    // chunks], swizzled for the transposing reads) and 128 x 64 / 64 x 128 rows of the second operand; both alias the (dead) ring.
+    constexpr bool TFUSE = ROLE == 1 && MODE == MODE_DENSE && (BNM == 6 || BNM == 7);
+    constexpr int TP = BNM == 7 ? 128 : 64;                    // channels of t_a
+    constexpr int T_DZ0 = 1280, T_A0 = T_DZ0 + 128 * 128 / 8, T_END = T_A0 + 1024;
+    static_assert(!TFUSE || (BM == 128 && BN == 128 && CE == 8 && EPI16 <= T_DZ0), "T side product: 128 x 128 tiles of a 16-bit type");
+    static_assert(!TFUSE || NSTAGE * STAGE <= T_A0, "T side product: the second operand's LDS image must lie behind the operand ring (it is filled while the ring runs)");
+    constexpr int LDS16 = (NSTAGE * STAGE + PATCH16 > EPI16) ? NSTAGE * STAGE + PATCH16 : EPI16;
+    __shared__ u32x4 lds[(TFUSE && T_END > LDS16) ? T_END : LDS16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
-    const int lb = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int tile_n = lb % p.tiles_n, tile_m = lb / p.tiles_n;
+    f32x4 tacc[TFUSE ? 2 : 1][TFUSE ? TP / 16 : 1];   // T partial of this workgroup: rows (2 wave + a) * 16.., all TP columns
+    if constexpr (TFUSE) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < TP / 16; ++b) tacc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int n_iter = TFUSE ? p.tiles_per_wg : 1;   // (persistent only with the side product: its partial lives in registers across tiles)
+    for (int it = 0; it < n_iter; ++it) {
+    int lb_, tn_, tm_;
+    if constexpr (TFUSE) {
+        const int per = (int)gridDim.x / p.tiles_n;
+        tn_ = (int)blockIdx.x % p.tiles_n;
+        tm_ = (int)blockIdx.x / p.tiles_n + it * per;
+        if (tm_ >= p.tiles_m) break;
+        lb_ = tm_ * p.tiles_n + tn_;
+    } else {
+        lb_ = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+        tn_ = lb_ % p.tiles_n; tm_ = lb_ / p.tiles_n;
+    }
+    const int lb = lb_, tile_n = tn_, tile_m = tm_;
     const int n0 = tile_n * BN;
     const Gather& g = p.g;
     // Row space.  Normal: row m = m0 + local.  Parity mode (stride-2 dgrad): tile_m = tq * 4 + cls (classes interleaved:
@@ -279,6 +306,25 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
     const __amdgpu_buffer_rsrc_t rs_a2 = (KCAT && p.A2) ? __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 + tile_a2), 0, clamp31(((long)p.M * p.lda2 - tile_a2) * ES), 0x00020000) : rs_a;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // provably uniform: the LDS base of a DMA goes through M0
     const bool ktail = (p.K % BK) != 0;                        // dense only (conv: C % BK == 0, checked by the launcher)
+    // ---- T side product: operand staging --------------------------------------------------------
+    constexpr int T_CPR = TP / 8, T_ROWS = TP == 64 ? 128 : 64;   // 16-byte chunks per row of t_a; rows per staged pass (16 KB)
+    auto t_swz16 = [](int row) -> int { return ((row & 3) | ((row >> 1) & 4)) << 1; };
+    auto t_swz = [&](int row) -> int { return T_CPR >= 16 ? t_swz16(row) : ((((row >> 1) & 1) | ((row >> 2) & 2)) << 1); };
+    const __amdgpu_buffer_rsrc_t rs_t = TFUSE ? __builtin_amdgcn_make_buffer_rsrc((void*)(p.t_a + (long)m0 * TP), 0, clamp31(((long)p.M - m0) * TP * ES), 0x00020000) : rs_a;
+    auto t_stage = [&](int row_base) {   // rows row_base .. row_base + T_ROWS of this tile's t_a rows -> LDS [row][T_CPR chunks], 4 LDS-DMA instructions per wave
+        if constexpr (TFUSE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sl = (wave_u * 4 + i) * 64 + lane, row = sl / T_CPR, slot = sl % T_CPR;
+                const unsigned vo = (unsigned)(((row_base + row) * TP + (slot ^ t_swz(row)) * 8) * ES);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t, (lds_void*)((lds_char*)lds + T_A0 * 16 + (wave_u * 4 + i) * 1024), 16, (int)vo, 0, 0, 0);
+            }
+        }
+    };
+    // requested BEFORE the operand ring's first tiles (its region lies behind the ring): vmcnt completes in issue order, so the ring's
+    // counted waits cover it and it has landed when the K loop ends -- no wait on the epilogue's stores later (rows past M lie outside
+    // the descriptor: zeros)
+    if constexpr (TFUSE) t_stage(0);
     auto dma_tile = [&](int st) {
         lds_char* base = (lds_char*)lds + st * (STAGE * 16);
         if (MODE == MODE_CONV && tap_dirty) { tap_offsets(); tap_dirty = false; }
@@ -348,7 +394,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
     const bool vec_c = VEC_ONLY ? ncol_ok : nfull && (p.ldc % CE == 0) && (((uintptr_t)p.C) & 15) == 0;
     const T* const e_addend = HAS_ADDEND ? p.addend : nullptr;
     const bool vec_add = VEC_ONLY ? (ncol_ok && e_addend != nullptr) : nfull && e_addend && (p.ld_add % CE == 0) && (((uintptr_t)e_addend) & 15) == 0;
-    constexpr int bn_mode = HAS_BN ? BNM : 0;
+    constexpr int bn_mode = HAS_BN ? (TFUSE ? 5 : BNM) : 0;   // (the side-product modes run mode 5's epilogue)
     const float* const e_bias = (HAS_AFFINE || ROLE == 1) ? p.bias : nullptr;   // (role 1: the constant term of a folded BN backward)
     const int e_relu = HAS_AFFINE ? p.relu : 0;
     // Data-gradient launches with short K are bound by the epilogue's operand stream (residual gradient, y, a_out: up to
@@ -708,8 +754,58 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) if (n + j < p.N) cp[j] = Elem<T>::from_f(v[j]);
                 }
+                if constexpr (TFUSE) {   // the same 16 bytes into the LDS image of the tile
+                    const int lrow = wave_m * WM + qf * 16 + r;
+                    lds[T_DZ0 + lrow * 16 + ((wave_n * (WN / 8) + echk) ^ t_swz16(lrow))] = f_to_chunk<T>(v);
+                }
+            } else if constexpr (TFUSE) {    // rows past M contribute zeros
+                const int lrow = wave_m * WM + qf * 16 + r;
+                lds[T_DZ0 + lrow * 16 + ((wave_n * (WN / 8) + echk) ^ t_swz16(lrow))] = zero16();
             }
             if (PIPE && t + DEPTH < NSTEP) issue(t + DEPTH);   // recycle this step's operand registers
+        }
+    }
+    if constexpr (TFUSE) {
+        // ---- T side product: tacc[c][k] += sum over the tile's rows of dz[row][c] * t_a[row][k] ----------------------------
+        // operands by ds_read_b64_tr_b16 as in tn_kernel: lane (g = l>>4, q = (l&15)>>2, pp = l&3) addresses row 8g + 4h + q, columns
+        // base + 4pp.., and receives column base + (l&15) for rows 8g + 4h + 0..3.  Wave w owns c = 32 w .. 32 w + 31 (two fragments).
+        const int tg = lane >> 4, tq = (lane & 15) >> 2, tpp = lane & 3;
+        auto t_frag = [&](const char* tile, int cpr, int row0, int col0) -> u32x4 {
+            const int col = col0 + 4 * tpp;
+            unsigned w[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = row0 + 8 * tg + 4 * h + tq;
+                const int ch = (col >> 3) ^ (cpr >= 16 ? t_swz16(row) : ((((row >> 1) & 1) | ((row >> 2) & 2)) << 1));
+                const char* ad = tile + (row * cpr + ch) * 16 + (col & 7) * 2;
+                s16x4 tt = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ad));
+                u32x2 t2 = __builtin_bit_cast(u32x2, tt);
+                w[2 * h] = t2.x; w[2 * h + 1] = t2.y;
+            }
+            return u32x4{w[0], w[1], w[2], w[3]};
+        };
+        const char* dz_tile = (const char*)(lds + T_DZ0);
+        const char* a_tile = (const char*)(lds + T_A0);
+#pragma unroll
+        for (int pass = 0; pass < 128 / T_ROWS; ++pass) {
+            if (pass > 0) {
+                __syncthreads();                 // every wave is done with the first half of t_a
+                t_stage(pass * T_ROWS);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (128-channel operand only: this one also waits for the epilogue's stores)
+            }
+            __syncthreads();                     // dz tile complete (pass 0), t_a rows landed
+#pragma unroll
+            for (int ks = 0; ks < T_ROWS / 32; ++ks) {
+                u32x4 pf[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) pf[a] = t_frag(dz_tile, 16, pass * T_ROWS + ks * 32, (2 * wave + a) * 16);
+#pragma unroll
+                for (int b = 0; b < TP / 16; ++b) {
+                    const u32x4 qf2 = t_frag(a_tile, T_CPR, ks * 32, b * 16);
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) Mma<T>::run(pf[a], qf2, tacc[a][b]);
+                }
+            }
         }
     }
     if ((HAS_FWD_STATS || HAS_BN) && p.stats_part) {
@@ -736,6 +832,18 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
                 p.stats_part[(t128 * 2 + which) * p.N + n0 + c] = t;
             }
         }
+    }
+    if constexpr (TFUSE) __syncthreads();   // the next tile's operand ring overwrites the LDS images and the reduction scratch
+    }   // tile loop
+    if constexpr (TFUSE) {
+        // this workgroup's partial of T, row-major [128 c][TP k]: element e of lane l of fragment (a, b) is (c = 16 (2 wave + a) + 4 (l>>4) + e, k = 16 b + (l&15))
+        float* mine = p.t_slab + (long)blockIdx.x * (128 * TP);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < TP / 16; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mine[((2 * wave + a) * 16 + 4 * (lane >> 4) + e) * TP + b * 16 + (lane & 15)] = tacc[a][b][e];
     }
 }
 
@@ -1198,6 +1306,12 @@ template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST, int ROLE>
             case 5:   // (the fused conv1 data gradients of the y3-free bottleneck blocks: dense launches of a 16-bit type only)
                 if constexpr (MODE == MODE_DENSE && sizeof(T) == 2 && WAVES_M == 2) { hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 5 : 0>), grid, block, 0, s, a); break; }
                 else return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: BN-backward mode 5 is a dense 128-row launch of a 16-bit element type");
+            case 6: case 7:   // mode 5 + the T side product (persistent: grid = the workgroups chosen by the caller, launch_nt_mode)
+                if constexpr (MODE == MODE_DENSE && sizeof(T) == 2 && WAVES_M == 2 && BN == 128 && KCH == 4) {
+                    if (a.bn_mode == 6) hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 6 : 0>), grid, block, 0, s, a);
+                    else hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, ROLE == 1 ? 7 : 0>), grid, block, 0, s, a);
+                    break;
+                } else return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: the T side product is a dense 128 x 128-tile launch of a 16-bit element type");
             default: hipLaunchKernelGGL((nt_kernel<T, WAVES_M, BN, KCH, MODE, NST, ROLE, 0>), grid, block, 0, s, a); break;
         }
     } else {
@@ -1233,6 +1347,18 @@ template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s) 
         return wide ? launch_nt_cfg<T, 2, 128, 8, MODE_HALO, 2>(a, s) : launch_nt_cfg<T, 2, 64, 8, MODE_HALO, 2>(a, s);
     } else {
         if ((a.role == 3 || (a.role == 2 && MODE == MODE_DENSE)) && a.slab && a.splits > 1) return launch_nt_split<T, MODE>(a, s);
+        if (a.role == 1 && (a.bn_mode == 6 || a.bn_mode == 7)) {   // fused conv1 data gradient + T side product (rpe_conv1x1_dgrad_bn_t): persistent
+            if constexpr (MODE == MODE_DENSE && sizeof(T) == 2) {
+                a.tiles_m = ceil_div(a.M, 128); a.tiles_n = ceil_div(a.N, 128);
+                if ((a.N % 128) || !a.t_a || !a.t_slab || a.tiles_per_wg <= 0) return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: T side product needs N % 128 == 0, t_a, t_slab and a plan");
+                const long nwg = nt_tfuse_grid(a.M, a.N);
+                if ((long)a.tiles_per_wg * (nwg / a.tiles_n) < a.tiles_m) return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: T side product: tiles_per_wg does not cover the row tiles");
+                if (a.K <= 8 * CE && a.M >= 4096) return launch_nt_role<T, 2, 128, 4, MODE_DENSE, 2, 1>(a, s, nwg);
+                return launch_nt_role<T, 2, 128, 4, MODE_DENSE, 3, 1>(a, s, nwg);
+            } else {
+                return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: the T side product is a dense launch of a 16-bit element type");
+            }
+        }
         if (a.role == 5) {   // 1x1 training forward with the BatchNorm apply fused (rpe_conv1x1_fwd_bn): 16-bit element types, dense
             if constexpr (MODE == MODE_DENSE && sizeof(T) == 2) {
                 a.tiles_m = ceil_div(a.M, 128); a.tiles_n = ceil_div(a.N, 128);

@@ -113,6 +113,23 @@ def conv2d_dgrad_bn(dy, w_crsk, x_shape, stride, pad, y, mean, invstd, a_out=Non
     return dz, st
 
 
+def conv1x1_dgrad_bn_t(dy, w_crsk, x_shape, a_prev, a_mask, addend=None):
+    """The fused 1x1 data gradient with the producing layer's packed ReLU mask (sum dz only) that also leaves T = dz^T a_prev behind.
+    Returns (dz [B,H,W,Ci], stats partials [tiles,2,Ci], T [Ci, P] fp32)."""
+    _chk(dy, "dy"), _chk(w_crsk, "w"), _chk(a_prev, "a_prev")
+    ci, co = w_crsk.shape[0], w_crsk.shape[3]
+    pch = a_prev.shape[-1]
+    d = conv_desc(x_shape, co, 1, 1, 0)
+    dz = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device)
+    st = torch.empty((lib.rpe_conv2d_dgrad_stats_tiles(ctypes.byref(d), dtype_code(dy)), 2, ci), dtype=torch.float32, device=dy.device)
+    t_out = torch.empty((ci, pch), dtype=torch.float32, device=dy.device)
+    ws = scratch(lib.rpe_conv1x1_dgrad_bn_t_workspace_bytes(ctypes.byref(d), pch), dy.device)
+    ep = BnBwdEpilogue(*(None if t is None else t.data_ptr() for t in (None, None, None, None, None, None, st, a_mask)))
+    lib.rpe_conv1x1_dgrad_bn_t(ctypes.byref(d), dtype_code(dy), _p(dy), _p(w_crsk), _p(dz), _p(addend), ctypes.byref(ep), _p(a_prev), pch, _p(t_out),
+                               _p(ws), ws.numel(), _stream())
+    return dz, st, t_out
+
+
 def bn_backward_from_dz(dz, y, mean, invstd, gamma, stats_part):
     c = y.shape[-1]
     dev = y.device

@@ -873,7 +873,8 @@ def test_bn_apply_fused_with_gram(dtype, rows, c):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("cfg", [(4, 28, 64, 256, 64), (3, 14, 128, 512, 128), (2, 6, 64, 256, 128), (2, 14, 256, 1024, 256)])
+@pytest.mark.parametrize("cfg", [(4, 28, 64, 256, 64), (3, 14, 128, 512, 128), (2, 6, 64, 256, 128), (2, 14, 256, 1024, 256), (40, 56, 64, 256, 64),
+                                 (37, 15, 128, 512, 256)])
 def test_y3_free_bottleneck_backward(dtype, cfg):
     """The backward of a block whose raw conv3 output was never written.  a2 -> conv3 (1x1) -> bn3 -> + identity -> ReLU = a3 -> next
     conv1 (1x1).  (a) the next block's fused conv1 data gradient with bn->y = NULL: the same dz as with y, sum dz in the partial rows
@@ -919,6 +920,14 @@ def test_y3_free_bottleneck_backward(dtype, cfg):
     assert rel_err(st[:, 0].sum(0), dz.float().reshape(rows, co).sum(0)) < 1e-5          # the sum of dz AS STORED (rounded), so that it is
     assert rel_err(st[:, 0].sum(0), st_y[:, 0].sum(0)) < t                              # consistent with T = dz^T a2 in (b)
     assert rel_err(dz.reshape(rows, co), dz_ref.float()) < t
+    # (a') the same launch with the T side product: identical dz and partial sums, T == the separate dz^T a2 launch (up to the fp32
+    # summation order), repeatable bit for bit
+    if p in (64, 128):
+        dz_t, st_t, T_t = ops.conv1x1_dgrad_bn_t(dyd, w_crsk, (b, h, h, co), a2d, mask, addend=add)
+        assert torch.equal(dz_t, dz) and torch.equal(st_t, st)
+        assert rel_err(T_t, ops.conv2d_wgrad(a2d, dz, 1, 1, 0).reshape(co, p)) < 2e-5
+        assert rel_err(T_t, (dz.double().cpu().reshape(rows, co).t() @ a2.double()).float()) < 2e-5
+        assert torch.equal(T_t, ops.conv1x1_dgrad_bn_t(dyd, w_crsk, (b, h, h, co), a2d, mask, addend=add)[2])
     # (b)
     T = ops.conv2d_wgrad(a2d, dz, 1, 1, 0).reshape(co, p)
     dg, db, c1c2 = ops.bn_backward_coeffs_t(st, rows, T, w3d, mean, invstd)

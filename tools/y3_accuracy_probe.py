@@ -21,6 +21,9 @@ dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[sys.argv[1] if len(sys.ar
 nseeds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 cases = dict(CASES)
 cases["c1"] = C1
+cases["bs64"] = (C1[0], (64,), 31, 300)    # tests/test_gpu_parity_sizes.py::test_bs64_flat_gradient_matches_cpu_oracle at seed index 0
+if len(sys.argv) > 3:
+    cases = {k: v for k, v in cases.items() if k in sys.argv[3].split(",")}
 
 
 def run(kind, cfg, lead, sd, batch, env):
@@ -28,7 +31,7 @@ def run(kind, cfg, lead, sd, batch, env):
         os.environ.pop(k, None)
     if env:
         os.environ[env] = "1"
-    k2 = "no" if kind == "c1" else kind
+    k2 = "no" if kind in ("c1", "bs64") else kind
     with contextlib.redirect_stdout(sys.stderr):
         model = build(k2, cfg, dtype)
     load_values(model, k2, sd)
@@ -46,14 +49,23 @@ def run(kind, cfg, lead, sd, batch, env):
 
 
 for kind, (cfg, lead, wseed, dseed) in cases.items():
-    k2 = "no" if kind == "c1" else kind
-    res = {"y3free": [], "round3": []}
-    gres = {"y3free": [], "round3": []}
+    k2 = "no" if kind in ("c1", "bs64") else kind
+    res = {"y3free": [], "round3": [], "emulation": []}
+    gres = {"y3free": [], "round3": [], "emulation": []}
     for s in range(nseeds):
         sd = po.make_state(k2, cfg, wseed + 100 * s)
         batch = po.synth_batch(lead, dseed + 1 + 10 * s, with_depth=cfg.get("use_depth", False))
         ref = po.train_step(k2, cfg, {k: v.clone() for k, v in sd.items()}, batch, LOSS_CFG, {}, lr=1e-3, val_metrics=False)
         ro = ref["outputs"] if isinstance(ref["outputs"], tuple) else (ref["outputs"],)
+        po.EMULATE = dtype     # the CPU oracle with every stored activation rounded to the compute dtype: the independent yardstick
+        try:
+            emu = po.train_step(k2, cfg, {k: v.clone() for k, v in sd.items()}, batch, LOSS_CFG, {}, lr=1e-3, val_metrics=False)
+        finally:
+            po.EMULATE = None
+        eo = emu["outputs"] if isinstance(emu["outputs"], tuple) else (emu["outputs"],)
+        res["emulation"].append(max(((o - r).abs().max() / r.abs().max().clamp_min(1e-12)).item() for o, r in zip(eo, ro)))
+        gres["emulation"].append(float(np.median([((emu["grads"][n].double() - g.double()).norm() / g.double().norm()).item()
+                                                  for n, g in ref["grads"].items() if float(g.abs().max()) > 0])))
         for tag, env in (("y3free", None), ("round3", "RPE_NO_Y3FREE")):
             outs, grads = run(kind, cfg, lead, sd, batch, env)
             e = max(((o - r).abs().max() / r.abs().max().clamp_min(1e-12)).item() for o, r in zip(outs, ro))
@@ -63,6 +75,6 @@ for kind, (cfg, lead, wseed, dseed) in cases.items():
                 if n in grads and float(g.abs().max()) > 0:
                     ge.append(((grads[n].double() - g.double()).norm() / g.double().norm()).item())
             gres[tag].append(float(np.median(ge)))
-    for tag in ("y3free", "round3"):
+    for tag in ("y3free", "round3", "emulation"):
         print("%-6s %-7s output rel err: mean %.4f max %.4f  [%s]   median gradient rel err: mean %.3f" % (
             kind, tag, np.mean(res[tag]), np.max(res[tag]), " ".join("%.4f" % e for e in res[tag]), np.mean(gres[tag])))
