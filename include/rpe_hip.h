@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RPE_ABI_VERSION 2   /* 2: BN partial-sum row counts depend on the element type (halo form of the 3x3 convs) */
+#define RPE_ABI_VERSION 3   /* 2: BN partial-sum row counts depend on the element type (halo form of the 3x3 convs); 3: the staged image x4 is zero-bordered */
 
 enum { RPE_F32 = 0, RPE_BF16 = 1, RPE_F16 = 2 };   /* RPE_F16: IEEE half activations / weight copies (BASELINE config C5), fp32 accumulate */
 enum {
@@ -186,8 +186,14 @@ long rpe_conv2d_wgrad_workspace_bytes(const rpe_conv_desc* d, int dtype);
 int rpe_conv2d_wgrad_det(const rpe_conv_desc* d, int dtype, const void* x, const void* dy, float* dw_krsc, void* workspace, long workspace_bytes,
                          void* stream);
 
-/* ResNet stem conv1 (3->64, 7x7 / 2, pad 3) on the NHWC4 image produced by
- * rpe_stage_image_nhwc4; w_packed = [64][8][8][4] from rpe_pack_stem_weight. */
+/* ResNet stem conv1 (3->64, 7x7 / 2, pad 3) on the staged image x4; w_packed = [64][8][8][4] from rpe_pack_stem_weight.
+ * x4 is ZERO-BORDERED NHWC4: [B][H + 2 RPE_STEM_PAD][W + 2 RPE_STEM_PAD][4] in the compute dtype, the image at rows / columns
+ * [RPE_STEM_PAD, RPE_STEM_PAD + H) x [.., + W), channel 3 = 0, and ZEROS around it (conv1's padding made explicit: every 16-byte
+ * piece of an im2col row is then an in-bounds aligned read, so the conv and its weight gradient stage through LDS-DMA -- round 4; the
+ * unpadded layout of rounds 1-3 forced register staging at 1.8-2.1 TB/s).  rpe_stage_image_nhwc4 / rpe_stage_frames_u8[_resized] write
+ * the interior only: zero the buffer once before its first use (rpe_x4_bytes() bytes).  H, W even. */
+#define RPE_STEM_PAD 3
+long rpe_x4_bytes(int dtype, int B, int H, int W);
 int rpe_stem_conv_fwd(int dtype, const void* x4, const void* w_packed, void* y, float* stats_part, int B, int H, int W, void* stream);
 int rpe_stem_conv_fwd_affine(int dtype, const void* x4, const void* w_packed, void* out, const float* bias, int relu, int B, int H, int W,
                              void* stream);
@@ -215,7 +221,7 @@ int rpe_pack_stem_weight(int dtype, const float* w_oihw, const float* scale, voi
 int rpe_unpack_stem_grad(const float* d_packed, float* dw_oihw, void* stream);
 
 /* replaces: the per-tensor .cuda() staging of util/learn_utils.py:130-138 for `img`
- * ((B,3,H,W) fp32 NCHW, util/data_utils.py:62-73) -> NHWC4 in the compute dtype. */
+ * ((B,3,H,W) fp32 NCHW, util/data_utils.py:62-73) -> the interior of the zero-bordered NHWC4 image x4 (see rpe_stem_conv_fwd). */
 int rpe_stage_image_nhwc4(int dtype, const float* img_nchw, void* out, int B, int H, int W, void* stream);
 
 /* replaces: the CPU image transform ToPILImage -> Resize(256) -> CenterCrop(224) -> ToTensor -> Normalize

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RPE_LIB_PATH") or os.path.join(_HERE, "librpe_hip.so")
 
 RPE_F32, RPE_BF16, RPE_F16 = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class RpeError(RuntimeError):
@@ -44,6 +44,7 @@ _SPEC = {
     "rpe_abi_version": (I, []),
     "rpe_last_error": (c_char_p, []),
     "rpe_build_id": (c_char_p, []),
+    "rpe_x4_bytes": (L, [I, I, I, I]),
     "rpe_conv_out_hw": (I, [PD, POINTER(c_int), POINTER(c_int)]),
     "rpe_conv_stats_tiles": (L, [L]),
     "rpe_conv2d_fwd": (I, [PD, I, P, P, P, P, P]),

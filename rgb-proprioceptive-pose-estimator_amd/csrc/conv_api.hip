@@ -667,12 +667,15 @@ static int conv1x1_wgrad_folded_y_t(const rpe_conv_desc* d, const void* dz, cons
     return 0;
 }
 
+// The stem's image operand is ZERO-BORDERED: x4 [B][H + 6][W + 6][4] with the image at rows / columns [3, 3 + H) x [3, 3 + W) and zeros
+// around it (RPE_STEM_PAD = 3 = conv1's padding).  Over it the 7x7 / stride 2 / pad 3 conv is an 8 x 8 / stride 2 / pad 0 conv whose 8th
+// tap row / column meets zero weights (rpe_pack_stem_weight): every 16-byte chunk of an im2col row is in bounds and aligned.
 static void stem_gather(Gather& g, int H, int W) {
     const int Ho = out_dim(H, 7, 2, 3), Wo = out_dim(W, 7, 2, 3);
-    g.H = H; g.W = W; g.C = 4; g.Ho = Ho; g.Wo = Wo; g.R = 8; g.S = 8;
-    g.sn = 2; g.sd_shift = 0; g.base_h = -3; g.base_w = -3; g.tap_sign = 1;
+    g.H = H + 2 * RPE_STEM_PAD; g.W = W + 2 * RPE_STEM_PAD; g.C = 4; g.Ho = Ho; g.Wo = Wo; g.R = 8; g.S = 8;
+    g.sn = 2; g.sd_shift = 0; g.base_h = 0; g.base_w = 0; g.tap_sign = 1;
     g.div_hw = make_fastdiv(Ho * Wo); g.div_w = make_fastdiv(Wo);
-    g.img_stride = (long)H * W * 4;
+    g.img_stride = (long)g.H * g.W * 4;
 }
 
 template <typename T>
@@ -683,9 +686,11 @@ static int stem_fwd_t(const void* x4, const void* w, void* y, float* stats, cons
     a.A = (const T*)x4; a.Bw = (const T*)w; a.C = (T*)y;
     a.M = B * a.g.Ho * a.g.Wo; a.N = 64; a.K = 224;   // 7 real kernel rows x (8 taps x 4 channels); the 8th, all-zero row of the packed weight is skipped
     a.lda = 4; a.ldb = 256; a.ldc = 64;
+    a.a_elems = (long)B * a.g.img_stride;
     a.stats_part = stats;
     a.bias = bias; a.relu = relu;
     if (bias || relu) { a.role = 3; a.stats_part = nullptr; }
+    if (H % 2 || W % 2) return rpe_set_error(RPE_ERR_SHAPE, "stem conv: even image dims");
     return launch_nt<T>(a, MODE_STEM, s);
 }
 
@@ -696,8 +701,10 @@ static int stem_wgrad_t(const void* x4, const void* dy, float* dw_packed, int B,
     stem_gather(a.g, H, W);
     a.P = (const T*)dy; a.Q = (const T*)x4; a.D = dw_packed;
     a.slab = (float*)slab; a.slab_bytes = slab_bytes;
-    a.M = B * a.g.Ho * a.g.Wo; a.I = 64; a.J = 224;   // (the 8th kernel row of the packed layout stays zero)
+    a.M = B * a.g.Ho * a.g.Wo; a.I = 64; a.J = 256;   // (all 8 x 8 packed taps: rows / columns 7 of dw_packed are not gradients -- rpe_unpack_stem_grad skips them)
     a.ldp = 64; a.ldq = 4; a.ldd = 256;
+    a.q_elems = (long)B * a.g.img_stride;
+    if (H % 2 || W % 2) return rpe_set_error(RPE_ERR_SHAPE, "stem conv: even image dims");
     return launch_tn<T>(a, MODE_STEM, s, slab_query);
 }
 
@@ -1039,6 +1046,11 @@ int rpe_conv2d_wgrad_det(const rpe_conv_desc* d, int dtype, const void* x, const
     if (int e = wgrad_ws_query(d, dtype, &need)) return e;
     if (workspace_bytes < need) return rpe_set_error(RPE_ERR_WORKSPACE, "conv2d_wgrad_det: workspace smaller than rpe_conv2d_wgrad_workspace_bytes()");
     DISPATCH(dtype, conv_wgrad_t, d, x, dy, dw_krsc, workspace, workspace_bytes, nullptr, (hipStream_t)stream);
+}
+
+long rpe_x4_bytes(int dtype, int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return -1;
+    return (long)B * (H + 2 * RPE_STEM_PAD) * (W + 2 * RPE_STEM_PAD) * 4 * (dtype == RPE_F32 ? 4 : 2);
 }
 
 int rpe_stem_conv_fwd(int dtype, const void* x4, const void* w_packed, void* y, float* stats_part, int B, int H, int W, void* stream) {

@@ -71,7 +71,7 @@ struct rpe_resnet50 {
     char* ws = nullptr;
     struct Slot { void** dst; long bytes; };
     std::vector<Slot> slots;
-    void* x4 = nullptr;          // staged NHWC4 image
+    void* x4 = nullptr;          // staged image: zero-bordered NHWC4 [B][H + 6][W + 6][4] (the border is zeroed once, at bind time)
     void* pool = nullptr;        // maxpool output
     unsigned char* pool_idx = nullptr;
     float* pooled = nullptr;     // avgpool output [B][2048]
@@ -280,7 +280,7 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
 
     // ---- workspace plan ----
     const size_t es = e->esz;
-    want(e, &e->x4, (long)batch * height * width * 4 * es);
+    want(e, &e->x4, rpe_x4_bytes(dtype, batch, height, width));   // zero-bordered NHWC4 image (RPE_STEM_PAD)
     long max_act = 0;
     for (auto& c : e->convs) {
         const long n = c.rows * c.d.out_c;
@@ -513,7 +513,7 @@ extern "C" int rpe_resnet50_bind(rpe_resnet50_t* e, void* workspace, long worksp
         e->named.push_back({c.name + ".a", c.a, c.rows, c.d.out_c});
     }
     e->named.push_back({"pool", e->pool, (long)e->B * (e->convs[0].Ho / 2) * (e->convs[0].Wo / 2), 64});
-    e->named.push_back({"x4", e->x4, (long)e->B * e->H * e->W, 4});
+    e->named.push_back({"x4", e->x4, (long)e->B * (e->H + 2 * RPE_STEM_PAD) * (e->W + 2 * RPE_STEM_PAD), 4});
     for (int i = 0; i < 2; ++i) e->named.push_back({"G" + std::to_string(i), e->G[i], 0, 0});
     {   // descriptor table of the per-step weight packing (bind is a setup call: one small synchronous upload)
         std::vector<rpe_pack_desc> tab;
@@ -542,6 +542,8 @@ extern "C" int rpe_resnet50_bind(rpe_resnet50_t* e, void* workspace, long worksp
         if (hipError_t he = hipMemcpy(e->pack_tab_fold, tab.data(), tab.size() * sizeof(rpe_pack_desc), hipMemcpyHostToDevice))
             return rpe_set_error_hip(he, __FILE__, __LINE__);
         e->pack_state = 0;
+        // the staged image's zero border (the staging kernels only ever write its interior)
+        if (hipError_t he = hipMemset(e->x4, 0, (size_t)rpe_x4_bytes(e->dtype, e->B, e->H, e->W))) return rpe_set_error_hip(he, __FILE__, __LINE__);
         // arrival counters of the fused BN reduce+finalize launches start at zero (and are left at zero by every launch)
         if (hipError_t he = hipMemset(e->dpart, 0, 64 * sizeof(double))) return rpe_set_error_hip(he, __FILE__, __LINE__);
         if (hipError_t he = hipMemset(e->dpart2, 0, 64 * sizeof(double))) return rpe_set_error_hip(he, __FILE__, __LINE__);

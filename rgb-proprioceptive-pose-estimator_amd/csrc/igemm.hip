@@ -27,7 +27,7 @@ template <typename T> int launch_nt(NTArgs<T>& a, int mode, hipStream_t s) {
             (g.base_h != -1 && g.base_h != 1) || g.base_h != g.base_w || g.tap_sign != -g.base_h || a.K != 9 * g.C || (a.slab && a.splits > 1))
             return rpe_set_error(RPE_ERR_SHAPE, "igemm_nt: the halo form is for 3x3 / stride 1 / pad 1 convs of 16-bit types");
     }
-    if (mode != MODE_STEM) {
+    {
         // buffer-descriptor extents of the two DMA operands; rows that must read as zero use offset 2^31, so both stay below it
         // the activation operand may be of any size: the kernel's descriptors start at each tile's first row (dense) / first image
         // (conv), so only ONE tile's span has to stay below 2 GiB; the weights use one descriptor

@@ -19,6 +19,7 @@
 #pragma once
 #include "igemm.h"
 
+constexpr int kEpiDepthLean = 8;   // ... of the epilogues without the y operand (role 5, BN-backward mode 5)
 constexpr int kEpiDepth = 4;   // epilogue operand prefetch distance of the fused data gradients, in steps (see nt_kernel, PIPE); 8 measured level
 
 namespace rpe {
@@ -101,9 +102,10 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
     constexpr int STAGE = HALO ? BN * KCH : (BM + BN) * KCH;   // 16-byte units (halo: the ring carries the weight tile only)
     constexpr int PATCH16 = HALO ? kHaloPatchPx * 8 : 0;       // halo patch region behind the ring
     constexpr int EPI16 = NW * 16 * (WN + 4) / 4;      // epilogue staging (NW waves x 16 rows x (WN+4) floats)
-    constexpr bool DMA = MODE != MODE_STEM;
+    // (MODE_STEM staged its operand through registers until round 4: two 8-byte pixels per chunk with separate bounds.  Over the
+    // zero-bordered image every chunk is an in-bounds, aligned 16-byte read and the stem rides the LDS-DMA ring like the others.)
+    constexpr bool DMA = true;
     constexpr int NSTAGE = DMA ? NST : 2;              // DMA path: ring of NST slots, NST-1 tiles in flight
-    static_assert(DMA || (WAVES_M == 2 && KCH == 4), "register staging is only wired for the 128-row / 64-B-row config");
     static_assert(NST >= 2 && NST <= (MODE == MODE_HALO ? 4 : 3), "ring depth 2..3 (halo form: ..4)");
     // T side product (NTArgs::t_a; BNM 6 / 7): behind the epilogue's staging rows the LDS holds the dz tile as stored (16-bit, [row][16
     // chunks], swizzled for the transposing reads) and 128 x 64 / 64 x 128 rows of the second operand; both alias the (dead) ring.
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
     // The A descriptors start at THIS tile's first row (dense) / first image (conv), so the 32-bit offsets span one tile and a
     // tensor may be of any size (round 1 capped a tensor at 2 GiB = ~1300 images in bf16); num_records = the bytes from there to
     // the end of the tensor, clamped below 2^31 (a tile never reaches that far, and rows past M are masked by a_ok anyway).
-    const unsigned tile_b0 = (MODE == MODE_CONV) ? (unsigned)__builtin_amdgcn_readfirstlane((int)fd_div((unsigned)(m0 < row_lim ? m0 : 0), g.div_hw))
+    const unsigned tile_b0 = (MODE == MODE_CONV || MODE == MODE_STEM) ? (unsigned)__builtin_amdgcn_readfirstlane((int)fd_div((unsigned)(m0 < row_lim ? m0 : 0), g.div_hw))
                              : HALO ? (unsigned)__builtin_amdgcn_readfirstlane((int)fd_div((unsigned)(tile_m * g.halo_rt), g.div_h)) : 0u;
     const long tile_a = (MODE == MODE_DENSE) ? (long)m0 * p.lda : (long)tile_b0 * g.img_stride;     // elements
     unsigned a_voff[AR], b_voff[BR], a_vbase[AR];
@@ -217,6 +219,9 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
             a_vbase[i] = (unsigned)(((long)(b - tile_b0) * g.img_stride + a_chunk[i] * CE) * ES);   // relative to the tile's first image
             a_hb[i] = (int)oh * g.sn + g.base_h;
             a_wb[i] = (int)ow * g.sn + g.base_w;
+            // stem over the zero-bordered NHWC4 image (g.H, g.W = the padded dims): row m's K row r is the 8 pixels (2 oh + r, 2 ow ..+7) --
+            // 32 contiguous elements; the tap row advances through the SGPR offset (dma_tile)
+            if (MODE == MODE_STEM && a_ok[i]) a_voff[i] = a_vbase[i] + (unsigned)((((long)oh * 2 * g.W + (long)ow * 2) * 4) * ES);
         }
     }
     constexpr bool KCAT = MODE == MODE_DENSE && ROLE == 1;   // a second A tensor for k >= K1 (NTArgs::A2)
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
     auto dma_tile = [&](int st) {
         lds_char* base = (lds_char*)lds + st * (STAGE * 16);
         if (MODE == MODE_CONV && tap_dirty) { tap_offsets(); tap_dirty = false; }
-        const int so_a = (MODE == MODE_CONV ? c0 : kbase) * ES, so_b = kbase * ES;
+        const int so_a = (MODE == MODE_CONV ? c0 : MODE == MODE_STEM ? (kbase >> 5) * g.W * 4 + (kbase & 31) : kbase) * ES, so_b = kbase * ES;
         if (KCAT && p.A2 && kbase >= p.K1) {   // (uniform: the K step lies in the second tensor)
             const int so_a2 = (kbase - p.K1) * ES;
 #pragma unroll
@@ -402,7 +407,10 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
     // keeps ~1-3 KB per wave in flight; here the operands of the next DEPTH steps are requested ahead (the first DEPTH
     // before the K loop even starts), 16 B per lane and operand, into registers that are recycled step by step.
     constexpr bool PIPE = (ROLE == 1 || ROLE == 5) && CE == 8;
-    constexpr int DEPTH = PIPE ? (NSTEP < kEpiDepth ? NSTEP : kEpiDepth) : 1;
+    // the y3-free epilogues -- role 5 and BN-backward mode 5 -- read one operand stream less and have the registers for a deeper prefetch
+    // (8 steps: 154 / 141 VGPRs, still three workgroups per CU; 18.96-19.09 vs 19.00-19.14 ms/step on one box, profiles/r04_ab_epi_depth.txt)
+    constexpr int kDepthHere = (ROLE == 5 || (ROLE == 1 && BNM == 5)) ? kEpiDepthLean : kEpiDepth;
+    constexpr int DEPTH = PIPE ? (NSTEP < kDepthHere ? NSTEP : kDepthHere) : 1;
     u32x4 qd[DEPTH], qy[DEPTH], qa[DEPTH];
     auto step_row = [&](int t) -> long { return out_row(wave_m * WM + (t / NPASS) * 16 + (t % NPASS) * RPP + erow); };
     auto issue = [&](int t) {
@@ -1447,6 +1455,9 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
     const bool dma = MODE != MODE_STEM;
     int ksub = 1, nslot = 2;
     if (dma) tn_ring(a.M, ksub, nslot);
+    // the stem's 64 x 256 tile is 40 KB per slot: two slots = two workgroups per CU (0.191 ms), three = one (0.306 ms; the register-staged
+    // form of rounds 1-3: 0.286 ms) -- profiles/r04_ab_stem_dma.txt
+    if (BJ == 256) nslot = 2;
     const int BMK = (dma ? 4 * ksub : 4) * Elem<T>::kChunk;
     // (the register-staged stem kernel is bound by the latency of its load -> LDS -> barrier steps, not by bytes: 2x / 4x the
     // workgroups measured level, as did reading dy once instead of four times)
@@ -1506,7 +1517,14 @@ template <typename T> int launch_tn(TNArgs<T>& a, int mode, hipStream_t s, long*
     }
     // stem (7x7, J = 224 of 256 packed columns): ONE 64 x 256 tile, so the 411-MB dy operand is read once (round 2 walked it once
     // per 64-column tile: four times, 0.35 ms at the end of the step with nothing beside it)
-    if (mode == MODE_STEM) return launch_tn_cfg<T, 64, 256, MODE_STEM>(a, s, slab_query);
+    // round 4: the operand is the zero-bordered image, over which the stem is an 8 x 8 / stride 2 / pad 0 conv of 4 channels (taps 7 meet
+    // zero weights): every 16-byte chunk of its im2col row (two pixels of one tap row) is in bounds and aligned, so it takes the
+    // LDS-DMA path of the conv mode (the register-staged form it replaces ran at 1.8 TB/s)
+    if (mode == MODE_STEM) {
+        if (a.g.C != 4 || a.g.R != 8 || a.g.S != 8 || a.g.sn != 2 || a.g.base_h || a.g.base_w || a.J != 256 || a.g.img_stride >= (1L << 24))
+            return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: the stem operand is the zero-bordered NHWC4 image (8 x 8 taps, stride 2, no padding, 256 packed columns)");
+        return launch_tn_cfg<T, 64, 256, MODE_CONV>(a, s, slab_query);
+    }
     const bool wide_i = a.I > 64;
     if (mode == MODE_DENSE) {
         const bool wide_j = a.J > 64;

@@ -801,18 +801,26 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------
 // Device staging: NCHW fp32 image batch -> NHWC4 (channel 3 = 0) in the compute type
 // ---------------------------------------------------------------------------------------------
+// The staged image is ZERO-BORDERED (include/rpe_hip.h, RPE_STEM_PAD): [B][H + 6][W + 6][4], the image in the middle.  The staging
+// kernels write the interior only; the border is zeroed once by whoever owns the buffer (the engine at bind time).
+__device__ __forceinline__ long x4_index(long b, int h, int w, int H, int W) {
+    return ((b * (H + 2 * RPE_STEM_PAD) + h + RPE_STEM_PAD) * (long)(W + 2 * RPE_STEM_PAD) + w + RPE_STEM_PAD) * 4;
+}
 template <typename T>
-__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int HW) {
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int H, int W) {
+    const int HW = H * W;
     const long total = (long)B * HW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long b = i / HW, p = i - b * HW;
         const float* src = img + b * 3 * HW + p;
         const float r = src[0], g = src[HW], bl = src[2 * (long)HW];
+        const int h = (int)(p / W), w = (int)(p - (long)h * W);
+        T* dst = out + x4_index(b, h, w, H, W);
         if (sizeof(T) == 4) {
-            *(f32x4*)(out + i * 4) = f32x4{r, g, bl, 0.f};
+            *(f32x4*)dst = f32x4{r, g, bl, 0.f};
         } else {
             u32x2 t; t.x = pack2<T>(r, g); t.y = pack2<T>(bl, 0.f);
-            *(u32x2*)(out + i * 4) = t;
+            *(u32x2*)dst = t;
         }
     }
 }
@@ -832,11 +840,12 @@ __global__ __launch_bounds__(256) void frames_u8_to_nhwc4_kernel(const unsigned 
         const long b = t / H;
         const unsigned char* p = fr + ((b * Hs + (top + h)) * Ws + (left + w)) * 3;
         const float r = ((float)p[0] * (1.f / 255.f) - m0) * i0, g = ((float)p[1] * (1.f / 255.f) - m1) * i1, bl = ((float)p[2] * (1.f / 255.f) - m2) * i2;
+        T* dst = out + x4_index(b, h, w, H, W);
         if (sizeof(T) == 4) {
-            *(f32x4*)(out + i * 4) = f32x4{r, g, bl, 0.f};
+            *(f32x4*)dst = f32x4{r, g, bl, 0.f};
         } else {
             u32x2 v; v.x = pack2<T>(r, g); v.y = pack2<T>(bl, 0.f);
-            *(u32x2*)(out + i * 4) = v;
+            *(u32x2*)dst = v;
         }
     }
 }
@@ -888,11 +897,12 @@ __global__ __launch_bounds__(256) void resize_v_crop_norm_kernel(const unsigned 
             c0 = p[0]; c1 = p[1]; c2 = p[2];
         }
         const float r = ((float)c0 * (1.f / 255.f) - m0) * i0, g = ((float)c1 * (1.f / 255.f) - m1) * i1, bl = ((float)c2 * (1.f / 255.f) - m2) * i2;
+        T* dst = out + x4_index(b, h, w, H, W);
         if (sizeof(T) == 4) {
-            *(f32x4*)(out + i * 4) = f32x4{r, g, bl, 0.f};
+            *(f32x4*)dst = f32x4{r, g, bl, 0.f};
         } else {
             u32x2 v; v.x = pack2<T>(r, g); v.y = pack2<T>(bl, 0.f);
-            *(u32x2*)(out + i * 4) = v;
+            *(u32x2*)dst = v;
         }
     }
 }
@@ -1287,9 +1297,9 @@ int rpe_avgpool_bwd(int dtype, const float* dout, void* dx, int B, int HW, int C
 int rpe_stage_image_nhwc4(int dtype, const float* img_nchw, void* out, int B, int H, int W, void* stream) {
     note_kernel("nchw_to_nhwc4_kernel");
     const long n = (long)B * H * W;
-    if (dtype == RPE_F32) hipLaunchKernelGGL((nchw_to_nhwc4_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, img_nchw, (float*)out, B, H * W);
-    else if (dtype == RPE_BF16) hipLaunchKernelGGL((nchw_to_nhwc4_kernel<bf16>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, img_nchw, (bf16*)out, B, H * W);
-    else if (dtype == RPE_F16) hipLaunchKernelGGL((nchw_to_nhwc4_kernel<f16>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, img_nchw, (f16*)out, B, H * W);
+    if (dtype == RPE_F32) hipLaunchKernelGGL((nchw_to_nhwc4_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, img_nchw, (float*)out, B, H, W);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((nchw_to_nhwc4_kernel<bf16>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, img_nchw, (bf16*)out, B, H, W);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((nchw_to_nhwc4_kernel<f16>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, img_nchw, (f16*)out, B, H, W);
     else return rpe_set_error(RPE_ERR_DTYPE, "stage_image: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;

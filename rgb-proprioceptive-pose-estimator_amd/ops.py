@@ -316,10 +316,14 @@ def pack_conv_weight(w_krsc_f32, dtype):
     return wf, wd
 
 
+STEM_PAD = 3   # RPE_STEM_PAD: the staged image is zero-bordered, [B, H + 6, W + 6, 4]
+
+
 def stage_image(img_nchw, dtype):
+    """(B, 3, H, W) fp32 -> the zero-bordered NHWC4 image [B, H + 6, W + 6, 4] the stem kernels read (interior written by the kernel)"""
     b, c, h, w = img_nchw.shape
     assert c == 3 and img_nchw.dtype == torch.float32
-    out = torch.empty((b, h, w, 4), dtype=dtype, device=img_nchw.device)
+    out = torch.zeros((b, h + 2 * STEM_PAD, w + 2 * STEM_PAD, 4), dtype=dtype, device=img_nchw.device)
     lib.rpe_stage_image_nhwc4(dtype_code(dtype), _p(_chk(img_nchw, "img")), _p(out), b, h, w, _stream())
     return out
 
@@ -332,6 +336,7 @@ def pack_stem_weight(w_oihw, dtype):
 
 def stem_conv_fwd(x4, w_packed, want_stats=False):
     b, h, w, _ = x4.shape
+    h, w = h - 2 * STEM_PAD, w - 2 * STEM_PAD
     ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
     y = torch.empty((b, ho, wo, 64), dtype=x4.dtype, device=x4.device)
     st = torch.empty((stats_tiles(b * ho * wo), 2, 64), dtype=torch.float32, device=x4.device) if want_stats else None
@@ -341,6 +346,7 @@ def stem_conv_fwd(x4, w_packed, want_stats=False):
 
 def stem_conv_wgrad(x4, dy):
     b, h, w, _ = x4.shape
+    h, w = h - 2 * STEM_PAD, w - 2 * STEM_PAD
     dwp = torch.zeros((64, 8, 8, 4), dtype=torch.float32, device=x4.device)
     ws = scratch(lib.rpe_stem_conv_wgrad_workspace_bytes(dtype_code(x4), b, h, w), x4.device)
     lib.rpe_stem_conv_wgrad_det(dtype_code(x4), _p(x4), _p(dy), _p(dwp), b, h, w, _p(ws), ws.numel(), _stream())

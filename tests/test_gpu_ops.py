@@ -412,8 +412,13 @@ def test_stem_conv(dtype):
     img = q(torch.randn(b, 3, h, h, generator=g), dtype)
     w = q(torch.randn(64, 3, 7, 7, generator=g) / 12.0, dtype).requires_grad_(True)
     ref = F.conv2d(img, w, None, 2, 3)
-    x4 = ops.stage_image(img.to(DEV), dtype)
-    assert torch.equal(x4[..., :3].float().cpu(), nhwc(img)) and (x4[..., 3] == 0).all()
+    x4 = ops.stage_image(img.to(DEV), dtype)          # zero-bordered: [B, H + 6, W + 6, 4], the image at [3, 3 + H) x [3, 3 + W)
+    assert x4.shape == (b, h + 6, h + 6, 4)
+    inner = x4[:, 3:3 + h, 3:3 + h]
+    assert torch.equal(inner[..., :3].float().cpu(), nhwc(img)) and (x4[..., 3] == 0).all()
+    border = x4.clone()
+    border[:, 3:3 + h, 3:3 + h] = 0
+    assert not border.float().abs().max().item() > 0.0                         # nothing but zeros around it
     wp = ops.pack_stem_weight(w.detach().to(DEV), dtype)
     y, st = ops.stem_conv_fwd(x4, wp, want_stats=True)
     assert rel_err(nchw(y), ref) < tol(dtype)

@@ -341,7 +341,11 @@ def test_uint8_frames_resized_like_pillow(golden_dir):
             b = model(torch.from_numpy(frames).cuda(), None, x0bar.cuda())
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), (i, (a - b).abs().max().item())
         # and the staged image itself (NHWC4 in the trunk's workspace) against the host transform
-        x4 = model.trunk._active.tensor("x4").float().reshape(2, 224, 224, 4)[..., :3].permute(0, 3, 1, 2).cpu()
+        x4 = model.trunk._active.tensor("x4").float().reshape(2, 230, 230, 4)   # zero-bordered (RPE_STEM_PAD = 3)
+        border = x4.clone()
+        border[:, 3:227, 3:227] = 0
+        assert float(border.abs().max()) == 0.0
+        x4 = x4[:, 3:227, 3:227, :3].permute(0, 3, 1, 2).cpu()
         assert torch.allclose(x4, img, rtol=0, atol=2e-6), (i, (x4 - img).abs().max().item())
 
 
