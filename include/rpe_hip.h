@@ -424,6 +424,12 @@ int rpe_resnet50_pack_weights(rpe_resnet50_t* e, void* stream);
  * copy -- the compute-dtype training copies and the BN-folded inference copies -- is rebuilt by the next forward.
  * replaces: nothing in the reference (torch modules read their parameters in place, util/model_utils.py:136-141). */
 int rpe_resnet50_weights_changed(rpe_resnet50_t* e);
+/* The engine's second stream (weight gradients in the backward, the projection shortcuts in the training forward) is PROBED when it is
+ * created (first training pass): does a kernel on it run while a kernel of the caller's stream executes?  HIP deals streams to a few
+ * hardware queues in creation order, and a stream that shares a queue (or, at low priority, a pipe) with the caller's serialises or
+ * starves (Schedule).  candidates: streams created until one overlapped (1..4, 0 before the first training pass);
+ * concurrent: 1 the stream in use overlapped, 0 none of four did, -1 not probed (RPE_NO_SIDE_PROBE=1, or created under capture). */
+int rpe_resnet50_side_stream_info(const rpe_resnet50_t* e, int* candidates, int* concurrent);
 /* img: (B,3,H,W) fp32 NCHW.  features: fp32 [B][ld_features] (first latent_dim columns written).
  * training != 0: batch statistics + running-stat update and everything backward needs is kept. */
 int rpe_resnet50_forward(rpe_resnet50_t* e, const float* img_nchw, float* features, long ld_features, int training, void* stream);

@@ -165,6 +165,12 @@ struct rpe_resnet50 {
     // weight-gradient GEMMs run on a second stream, overlapping the data-gradient / BN chain (they only feed Adam)
     hipStream_t side = nullptr;
     bool overlap = true;
+    // how the second stream was chosen (ensure_side / rpe_resnet50_side_stream_info): candidates created, whether the one in use ran a
+    // kernel WHILE a kernel of the caller's stream was executing, and the rejected candidates (kept until the engine goes: destroying
+    // one would hand its hardware queue to the next stream created)
+    int side_tries = 0;
+    int side_concurrent = -1;    // -1 not probed (RPE_NO_SIDE_PROBE / capture), 0 no candidate overlapped, 1 yes
+    std::vector<hipStream_t> side_rejects;
     bool capturing = false;              // the caller's stream is being captured into a hipGraph (capture_guard)
     std::vector<hipEvent_t> sync_pool;
     size_t sync_next = 0;
@@ -481,6 +487,7 @@ extern "C" void rpe_resnet50_destroy(rpe_resnet50_t* e) {
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     for (auto ev : e->sync_pool) (void)hipEventDestroy(ev);
     if (e->side) (void)hipStreamDestroy(e->side);
+    for (auto st : e->side_rejects) (void)hipStreamDestroy(st);
     delete e;
 }
 extern "C" long rpe_resnet50_workspace_bytes(const rpe_resnet50_t* e) { return e ? e->ws_bytes : 0; }
@@ -628,9 +635,49 @@ static int fold_for_eval(rpe_resnet50* e, void* stream) {
     return 0;
 }
 
+// ---- which hardware queue the second stream lands on ---------------------------------------------------------------------------
+// HIP multiplexes a process's streams onto at most GPU_MAX_HW_QUEUES (4) hardware queues PER PRIORITY LEVEL, in creation order: a new
+// queue while that level's pool has fewer than four, then the least-referenced existing one; the hardware queues are dealt to the
+// command processor's pipes round-robin, again in creation order.  Round 3's two findings are the two ways this can go wrong for a
+// stream that forks from / joins the caller's:
+//   (1) a LOW-priority queue that is the 5th, 9th .. hardware queue of the process sits on the pipe of the caller's queue, which
+//       always has a packet ready (the host runs ahead): it is never scheduled -- 28 ms/step for every RPE_TEST_STREAM_SKIP >= 3 and
+//       only for those (profiles/r03_ab_stream_priority.txt: three extra normal-priority queues + the caller's fill the first round);
+//   (2) a stream that SHARES a hardware queue with the stream it waits on (the pool was full: the 5th .. stream of its level) cannot
+//       have its cross-stream waits resolved by barrier packets inside one in-order queue: the runtime resolves them on the host
+//       (hipGraphLaunch 2.6 ms, 3-4 ms frames: profiles/r03_rollout_latency.txt) or the two streams simply serialise (21.5 ms/step at
+//       RPE_TEST_STREAM_SKIP = 6, normal priority).
+// So the engine does not trust the position it is created at: every candidate is PROBED once -- a spin kernel of ~200 us on the
+// caller's stream, an empty kernel on the candidate, and the question whether the candidate's kernel finished while the spin was
+// still running -- and the first candidate that overlaps is kept (up to four: one full round of the pool).  Normal priority (finding 1).
+__global__ void side_probe_spin_kernel(long ticks) {
+    const long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+__global__ void side_probe_empty_kernel() {}
+// 1: a kernel on `cand` completed while a kernel on `caller` was still executing; 0: it did not; -1: could not tell
+static int side_probe(hipStream_t caller, hipStream_t cand) {
+    hipEvent_t spin_done = nullptr, cand_done = nullptr;
+    if (hipEventCreateWithFlags(&spin_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&cand_done, hipEventDisableTiming) != hipSuccess) return -1;
+    int res = -1;
+    hipLaunchKernelGGL(side_probe_spin_kernel, dim3(1), dim3(64), 0, caller, 20000L);   // wall_clock64 ticks at 100 MHz: 200 us
+    if (hipEventRecord(spin_done, caller) == hipSuccess) {
+        hipLaunchKernelGGL(side_probe_empty_kernel, dim3(1), dim3(64), 0, cand);
+        if (hipEventRecord(cand_done, cand) == hipSuccess && hipEventSynchronize(cand_done) == hipSuccess) {
+            const hipError_t q = hipEventQuery(spin_done);
+            res = q == hipErrorNotReady ? 1 : (q == hipSuccess ? 0 : -1);
+        }
+    }
+    (void)hipEventSynchronize(spin_done);
+    (void)hipGetLastError();
+    (void)hipEventDestroy(spin_done);
+    (void)hipEventDestroy(cand_done);
+    return res;
+}
+
 // conv -> batch statistics -> BN apply (+residual) (+relu)
 // the second HIP stream (weight gradients in the backward, the projection-shortcut branch in the forward), created on first use
-static int ensure_side(rpe_resnet50* e) {
+static int ensure_side(rpe_resnet50* e, hipStream_t caller = nullptr) {
     if (e->overlap && !e->side) {
         if (getenv("RPE_NO_OVERLAP")) e->overlap = false;
         else {
@@ -646,7 +693,15 @@ static int ensure_side(rpe_resnet50* e) {
             // RPE_TEST_STREAM_SKIP=n: n streams created first, as another component of the host process might (A/B of the above)
             const int skip = getenv("RPE_TEST_STREAM_SKIP") ? atoi(getenv("RPE_TEST_STREAM_SKIP")) : 0;
             for (int i = 0; i < skip; ++i) { hipStream_t d; HIPTRY(hipStreamCreateWithFlags(&d, hipStreamNonBlocking)); }
-            HIPTRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, low ? least : 0));
+            static const bool no_probe = getenv("RPE_NO_SIDE_PROBE") != nullptr;
+            for (int t = 0; t < 4 && !e->side; ++t) {
+                hipStream_t cand = nullptr;
+                HIPTRY(hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, low ? least : 0));
+                e->side_tries = t + 1;
+                const int r = (no_probe || e->capturing) ? -1 : side_probe(caller, cand);
+                if (r != 0 || t == 3) { e->side = cand; e->side_concurrent = r; }   // (the fourth candidate is kept whatever it showed)
+                else e->side_rejects.push_back(cand);
+            }
         }
     }
     return 0;
@@ -730,7 +785,7 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
     else if (frames) PROF(e, RPE_PROF_OTHER, stream, rpe_stage_frames_u8(e->dtype, frames, e->x4, e->B, Hs, Ws, e->H, e->W, mean3, std3, stream));
     else PROF(e, RPE_PROF_OTHER, stream, rpe_stage_image_nhwc4(e->dtype, img_nchw, e->x4, e->B, e->H, e->W, stream));
     ConvL& st = e->convs[0];
-    TRY(ensure_side(e));
+    TRY(ensure_side(e, (hipStream_t)stream));
     e->sync_next = 0;
     static const bool pool_fuse_ok = getenv("RPE_NO_POOL_FUSE") == nullptr;
     if (training && pool_fuse_ok && !((st.Ho | st.Wo) & 1)) {
@@ -908,15 +963,11 @@ static int conv1x1_backward_folded(rpe_resnet50* e, ConvL& c, const void* dz, Co
         // y3-free block: T = dz^T a2 first (caller's stream: the coefficients need it), then sum dz (partials) + rowdot(T, W) -> c1, c2
         e->pending_flops = conv_flops(c);
         e->pending_bytes = conv_in_bytes(e, c) + conv_out_bytes(e, c);
-        static const bool exp_t_side = getenv("RPE_EXP_T_SIDE") != nullptr;   // TIMING EXPERIMENT ONLY (wrong coefficients): dz^T a2 off the data-gradient chain
+        // (timing experiment of round 4, code removed: with this launch on the second stream -- wrong coefficients, the chain not waiting
+        // for it -- the step ran 18.91 vs 19.24 ms, profiles/r04_ab_t_gemm_off_chain.txt: the upper bound of what taking dz^T a2 off the
+        // data-gradient chain could return)
         if (y3f->t_ready) {
-            // (the next block's fused conv1 data gradient left dz^T a2 behind)
-        } else
-        if (exp_t_side) {
-            ConvL* cp = &c; const Block* bp = y3f;
-            TRY(to_side(e, stream, [e, cp, x, dz, bp](hipStream_t run) -> int {
-                PROF(e, RPE_PROF_CONV_WGRAD, run, rpe_conv2d_wgrad_det(&cp->d, e->dtype, x, dz, bp->dzt_a, e->wg_slab, e->wg_slab_bytes, run));
-                return 0; }));
+            // (the next block's fused conv1 data gradient left dz^T a2 behind: RPE_T_FUSE=1)
         } else
         PROF(e, RPE_PROF_CONV_WGRAD, stream, rpe_conv2d_wgrad_det(&c.d, e->dtype, x, dz, y3f->dzt_a, e->main_slab, e->main_slab_bytes, stream));
         e->pending_bytes = 0;
@@ -989,7 +1040,7 @@ extern "C" int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_fea
         if (!e->grads[i]) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward: gradient tensors were not bound");
     hipStream_t s = (hipStream_t)stream;
     TRY(capture_guard(e, stream, "resnet50_backward"));
-    TRY(ensure_side(e));
+    TRY(ensure_side(e, s));
     e->sync_next = 0;
     if (e->gspan_lo) HIPTRY(hipMemsetAsync(e->gspan_lo, 0, e->gspan_bytes, s));
     // fc
@@ -1178,6 +1229,12 @@ extern "C" int rpe_resnet50_backward_end(rpe_resnet50_t* e, int use_d_early, voi
     TRY(rpe_unpack_stem_grad(e->stem_dw, e->grads[st.p_w], stream));
     TRY(join_side(e, s));
     e->bwd_next = -2;
+    return 0;
+}
+
+extern "C" int rpe_resnet50_side_stream_info(const rpe_resnet50_t* e, int* candidates, int* concurrent) {
+    if (!e || !candidates || !concurrent) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_side_stream_info: null argument");
+    *candidates = e->side_tries; *concurrent = e->side_concurrent;
     return 0;
 }
 

@@ -29,7 +29,7 @@ def main(argv=None):
     p.add_argument("--n_episodes", type=int, default=10)
     p.add_argument("--out", type=str, default="model_outputs.npy")
     p.add_argument("--no_graph", action="store_true", help="launch every frame eagerly instead of replaying one captured hipGraph "
-                   "(a frame is ~75 launches; replay: 0.58 ms, eager: 1.26 ms at batch 1)")
+                   "(a frame is ~90 launches on one stream; replay: 0.45 ms, eager: 1.05-1.27 ms at batch 1 -- profiles/r03_rollout_latency.txt)")
     args = p.parse_args(argv)
     from rgb_proprioceptive_pose_estimator_amd.models import PoseDistanceLoss
     from rgb_proprioceptive_pose_estimator_amd.util.data_utils import synthetic_batch

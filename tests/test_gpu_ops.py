@@ -136,7 +136,7 @@ CONVS = [  # (B, H, Cin, Cout, k, stride, pad)
     (2, 10, 64, 128, 3, 2, 1),  # Ho*Wo not a multiple of anything convenient
     (2, 9, 64, 64, 3, 2, 1),    # odd input size: stride-2 data gradient without the parity-class decomposition
     (3, 12, 64, 128, 1, 2, 0),
-    # M >= 4096 rows and K >= 1024: the 256-row / 8-wave tile configuration
+    # M >= 1024 rows and K >= 1024: the 128-B-K-row / 2-slot-ring configuration (the 256-row / 8-wave tiles of round 1 were removed in round 3)
     (8, 24, 128, 128, 3, 1, 1),
     (8, 24, 1024, 64, 1, 1, 0),
     (6, 30, 128, 256, 3, 2, 1),

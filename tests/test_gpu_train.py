@@ -579,3 +579,41 @@ def test_fp16_resume_applies_the_checkpointed_loss_scale_to_the_first_backward(t
     # identical kernels on identical state: bitwise, up to the aux head's atomically accumulated gradients (lr-sized sign flips)
     assert d <= 2.1e-3 and ((m1._arena.flat - m2._arena.flat).abs() > 1e-7).float().mean().item() < 1e-3, d
     assert torch.allclose(o1._m, o2._m, rtol=1e-3, atol=1e-6) and torch.allclose(o1._v, o2._v, rtol=1e-3, atol=1e-9)
+
+
+def test_second_stream_is_probed_for_concurrency():
+    """Round 3 found the engine's second stream starved (low priority) or serialised with the caller's stream depending on HOW MANY streams
+    the process had created before it: HIP deals streams to four hardware queues per priority level in creation order, and a stream that
+    shares a hardware queue -- or, at low priority, a command-processor pipe -- with the caller's does not overlap with it.  The engine now
+    probes every candidate (a spin kernel on the caller's stream, an empty kernel on the candidate: did it finish first?) and keeps the
+    first that overlaps.  Here five streams are created in front of it (RPE_TEST_STREAM_SKIP = 5: the position where normal-priority
+    streams begin to share hardware queues): the stream the engine ends up with must have overlapped in the probe, and a train step on
+    it must leave the gradients it leaves on one stream."""
+    import ctypes
+    from rgb_proprioceptive_pose_estimator_amd import models as M
+    from rgb_proprioceptive_pose_estimator_amd._lib import lib
+    from rgb_proprioceptive_pose_estimator_amd.util.data_utils import synthetic_batch
+    torch.manual_seed(0)
+    b = synthetic_batch((4,), 9)
+    crit = M.PoseDistanceLoss("combined", 1.0, 0.5, 1e-4, "pose")
+    grads = {}
+    for tag, env in (("skip5", {"RPE_TEST_STREAM_SKIP": "5"}), ("one_stream", {"RPE_NO_OVERLAP": "1"})):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            torch.manual_seed(1)
+            model = M.NaiveObjectStateEstimator("cube", [32], 50, 32, False, (9,), False, False, False, compute_dtype=torch.bfloat16).cuda().train()
+            crit(model(b["img"], None, b["x0bar"]), b["obj"]).backward()
+            torch.cuda.synchronize()
+            grads[tag] = model._arena.grad.clone()
+            if tag == "skip5":
+                cand, conc = ctypes.c_int(), ctypes.c_int()
+                lib.rpe_resnet50_side_stream_info(model.trunk._active.handle, ctypes.byref(cand), ctypes.byref(conc))
+                assert 1 <= cand.value <= 4 and conc.value == 1, (cand.value, conc.value)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    assert torch.equal(grads["skip5"], grads["one_stream"])    # fixed-order sums: the schedule does not change a bit
