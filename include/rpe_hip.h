@@ -287,6 +287,10 @@ int rpe_maxpool3x3s2_fwd(int dtype, const void* x, void* out, unsigned char* idx
  * rpe_maxpool3x3s2_fwd give (replaces bn1 -> relu -> maxpool of torchvision's ResNet stem, util/model_utils.py:136). */
 int rpe_bn_apply_maxpool3x3s2(int dtype, const void* y, const float* scale, const float* shift, void* a, void* out, unsigned char* idx, int B, int H,
                               int W, int C, void* stream);
+/* the same pass with the bn1 aux head riding along (see rpe_resnet50_set_aux_head); 64 channels; `a` may be NULL (not written) */
+int rpe_bn_apply_maxpool3x3s2_aux(int dtype, const void* y, const float* scale, const float* shift, void* a, void* out, unsigned char* idx, int B, int H,
+                                  int W, const float* aux_w, const float* aux_bias, const float* depth_feat, float* aux_out, long ld_aux_out, float* aux_raw,
+                                  unsigned char* aux_idx, void* stream);
 int rpe_maxpool3x3s2_bwd(int dtype, const void* dout, const unsigned char* idx, const void* addend, void* dx, int B, int H, int W, int C,
                          void* stream);
 /* Stem backward in two passes over y (fused form of rpe_maxpool3x3s2_bwd + the aux head's scatter + rpe_bn_backward for the
@@ -320,6 +324,10 @@ long rpe_aux_head_bwd_workspace_floats(int dtype, int B, int H, int W);
 int rpe_aux_head_bwd_det(int dtype, const float* dout, long ld_dout, const void* a1, const float* w, const float* depth_feat, const float* raw,
                          const unsigned char* idx, void* d_a1, float* dw, float* dbias, float* d_depth_feat, int B, int H, int W, float* workspace,
                          long workspace_floats, void* stream);
+/* ... and from the RAW stem conv output y with bn1's scale / shift (the activated tensor was not written: rpe_bn_apply_maxpool3x3s2_aux) */
+int rpe_aux_head_bwd_det_y(int dtype, const float* dout, long ld_dout, const void* y, const float* bn_scale, const float* bn_shift, const float* w,
+                           const float* depth_feat, const float* raw, const unsigned char* idx, float* dw, float* dbias, float* d_depth_feat, int B, int H,
+                           int W, float* workspace, long workspace_floats, void* stream);
 /* replaces: depth_nets[i] = AvgPool2d(2) x2 -> InstanceNorm2d(1, affine) -> Flatten (models/naive.py:233-240) */
 int rpe_depth_head_fwd(const float* depth, const float* w, const float* b, float* feat, float* xhat, int B, int H, int W, void* stream);
 int rpe_depth_head_bwd(const float* d_feat, const float* xhat, long n, float* dw, float* db, void* stream);
@@ -430,6 +438,18 @@ int rpe_resnet50_weights_changed(rpe_resnet50_t* e);
  * starves (Schedule).  candidates: streams created until one overlapped (1..4, 0 before the first training pass);
  * concurrent: 1 the stream in use overlapped, 0 none of four did, -1 not probed (RPE_NO_SIDE_PROBE=1, or created under capture). */
 int rpe_resnet50_side_stream_info(const rpe_resnet50_t* e, int* candidates, int* concurrent);
+/* The bn1 aux head (aux_nets[0]: Conv2d(64 -> 1, 1x1) + MaxPool2d(2) + Flatten [x the depth feature], models/naive.py:223-231,318-330)
+ * computed BY the next training forward, inside the stem's BatchNorm-apply + ReLU + max-pool pass (rpe_bn_apply_maxpool3x3s2_aux): the
+ * activated tensor relu(bn1(conv1 x)) is then never written (rpe_resnet50_early_feature returns NULL after such a forward) and the
+ * separate aux launch with its re-read disappears.  out: the aux columns of the fused feature rows (row pitch ld_out floats); raw / idx:
+ * [B][(H/4)(W/4)] window maxima and winner taps for the backward.  The setting is consumed by ONE forward; w = NULL clears it.
+ * rpe_resnet50_aux_head_bwd: the head's parameter gradients (dw [64], dbias, d_depth_feat) from the raw stem output, as
+ * rpe_aux_head_bwd_det computes them from a1 (workspace: rpe_aux_head_bwd_workspace_floats); its gradient towards the stem still
+ * travels in compact form through rpe_resnet50_set_aux_grad. */
+int rpe_resnet50_set_aux_head(rpe_resnet50_t* e, const float* w, const float* bias, const float* depth_feat, float* out, long ld_out, float* raw,
+                              unsigned char* idx);
+int rpe_resnet50_aux_head_bwd(rpe_resnet50_t* e, const float* dout, long ld_dout, const float* w, const float* depth_feat, const float* raw,
+                              const unsigned char* idx, float* dw, float* dbias, float* d_depth_feat, float* workspace, long workspace_floats, void* stream);
 /* img: (B,3,H,W) fp32 NCHW.  features: fp32 [B][ld_features] (first latent_dim columns written).
  * training != 0: batch statistics + running-stat update and everything backward needs is kept. */
 int rpe_resnet50_forward(rpe_resnet50_t* e, const float* img_nchw, float* features, long ld_features, int training, void* stream);

@@ -153,6 +153,10 @@ _SPEC = {
     "rpe_resnet50_set_aux_grad": (I, [P, P, L, P, P, P]),
     "rpe_resnet50_profile_kernels": (L, [P, P, L]),
     "rpe_last_kernel_name": (c_char_p, []),
+    "rpe_resnet50_set_aux_head": (I, [P, P, P, P, P, L, P, P]),
+    "rpe_resnet50_aux_head_bwd": (I, [P, P, L, P, P, P, P, P, P, P, P, L, P]),
+    "rpe_aux_head_bwd_det_y": (I, [I, P, L, P, P, P, P, P, P, P, P, P, P, I, I, I, P, L, P]),
+    "rpe_bn_apply_maxpool3x3s2_aux": (I, [I, P, P, P, P, P, P, I, I, I, P, P, P, P, L, P, P, P]),
     "rpe_resnet50_side_stream_info": (I, [P, POINTER(c_int), POINTER(c_int)]),
     "rpe_resnet50_tensor": (I, [P, c_char_p, POINTER(c_void_p), POINTER(c_long), POINTER(c_int)]),
     "rpe_resnet50_set_hook_grad": (I, [P, I, P]),

@@ -91,6 +91,10 @@ struct rpe_resnet50 {
     double* dpart2 = nullptr;    // ... of the projection-shortcut branch
     // aux-head gradient in compact form for the fused stem backward (rpe_resnet50_set_aux_grad)
     const float* aux_dout = nullptr; long aux_ld = 0; const float* aux_df = nullptr; const unsigned char* aux_idx = nullptr; const float* aux_w = nullptr;
+    // the bn1 aux head's FORWARD riding on the stem's apply + pool pass (rpe_resnet50_set_aux_head, consumed by the next training forward):
+    // a1 = relu(bn1(conv1 x)) is then not written at all (a1_valid: what rpe_resnet50_early_feature may hand out)
+    struct { const float *w = nullptr, *bias = nullptr, *depth_feat = nullptr; float* out = nullptr; long ld = 0; float* raw = nullptr; unsigned char* idx = nullptr; } aux_fwd;
+    bool a1_valid = false;
     float* stem_dw = nullptr;    // [64][8][8][4]
     // BN backward folded into the conv3 data gradients (rpe_bn_bwd_fold_conv1x1): main-stream-only scratch, rebuilt per block
     bool fold = true;
@@ -788,16 +792,31 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
     TRY(ensure_side(e, (hipStream_t)stream));
     e->sync_next = 0;
     static const bool pool_fuse_ok = getenv("RPE_NO_POOL_FUSE") == nullptr;
+    const bool aux_here = e->aux_fwd.w != nullptr;
+    e->a1_valid = true;
     if (training && pool_fuse_ok && !((st.Ho | st.Wo) & 1)) {
         // conv + statistics, then BatchNorm apply + ReLU + max pool in one pass over y (the separate pool pass re-read all of a1)
         TRY(conv_bn(e, st, e->x4, nullptr, 1, stream, false, nullptr, nullptr, true));
+        if (aux_here) {
+            // ... and the bn1 aux head (1x1 conv 64 -> 1 + 2x2 max pool [x depth feature]) in the same pass; a1 itself is not written
+            e->pending_bytes = conv_out_bytes(e, st) * 1.25 + (double)e->B * (st.Ho / 2) * (st.Wo / 2) * (64 + 9);
+            PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_apply_maxpool3x3s2_aux(e->dtype, st.y, st.scale, st.shift, nullptr, e->pool, e->pool_idx, e->B, st.Ho, st.Wo,
+                                                                          e->aux_fwd.w, e->aux_fwd.bias, e->aux_fwd.depth_feat, e->aux_fwd.out, e->aux_fwd.ld,
+                                                                          e->aux_fwd.raw, e->aux_fwd.idx, stream));
+            e->a1_valid = false;
+        } else {
         e->pending_bytes = conv_out_bytes(e, st) * 2.25 + (double)e->B * (st.Ho / 2) * (st.Wo / 2) * 64;   // y -> a1, pool + winner index
         PROF(e, RPE_PROF_BN_FWD, stream, rpe_bn_apply_maxpool3x3s2(e->dtype, st.y, st.scale, st.shift, st.a, e->pool, e->pool_idx, e->B, st.Ho, st.Wo, 64, stream));
+        }
     } else {
         TRY(conv_bn(e, st, e->x4, nullptr, 1, stream));
         e->pending_bytes = conv_out_bytes(e, st) * 1.25 + (double)e->B * (st.Ho / 2) * (st.Wo / 2) * 64;   // a1 -> pool + winner index
         PROF(e, RPE_PROF_OTHER, stream, rpe_maxpool3x3s2_fwd(e->dtype, st.a, e->pool, e->pool_idx, e->B, st.Ho, st.Wo, 64, stream));
+        if (aux_here)   // (a forward that cannot take the fused pass still owes the caller the aux head it was handed)
+            TRY(rpe_aux_head_fwd(e->dtype, st.a, e->aux_fwd.w, e->aux_fwd.bias, e->aux_fwd.depth_feat, e->aux_fwd.out, e->aux_fwd.ld, e->aux_fwd.raw, e->aux_fwd.idx,
+                                 e->B, st.Ho, st.Wo, stream));
     }
+    e->aux_fwd.w = nullptr;   // one forward only
     const void* x = e->pool;
     static const bool fwd_overlap = getenv("RPE_NO_FWD_OVERLAP") == nullptr;
     // training: the projection shortcut's BatchNorm is applied inside conv3's apply pass (no pass / normalised copy of its own);
@@ -878,7 +897,7 @@ extern "C" int rpe_resnet50_forward_u8_resized(rpe_resnet50_t* e, const unsigned
     return forward_impl(e, nullptr, frames, Hs, Ws, mean3_host, std3_host, features, ld_features, training, stream, rs);
 }
 
-extern "C" const void* rpe_resnet50_early_feature(const rpe_resnet50_t* e) { return e ? e->convs[0].a : nullptr; }
+extern "C" const void* rpe_resnet50_early_feature(const rpe_resnet50_t* e) { return (e && e->a1_valid) ? e->convs[0].a : nullptr; }
 extern "C" void* rpe_resnet50_early_grad(rpe_resnet50_t* e) { return e ? e->early_grad : nullptr; }
 
 // BN backward of layer c: dA (grad wrt c.a) -> dy (may alias dA); dz_out optional
@@ -1230,6 +1249,24 @@ extern "C" int rpe_resnet50_backward_end(rpe_resnet50_t* e, int use_d_early, voi
     TRY(join_side(e, s));
     e->bwd_next = -2;
     return 0;
+}
+
+extern "C" int rpe_resnet50_set_aux_head(rpe_resnet50_t* e, const float* w, const float* bias, const float* depth_feat, float* out, long ld_out, float* raw,
+                                         unsigned char* idx) {
+    if (!e) return rpe_set_error(RPE_ERR_STATE, "resnet50_set_aux_head: null engine");
+    if (w && (!bias || !out || !raw || !idx || ld_out < (long)(e->convs[0].Ho / 2) * (e->convs[0].Wo / 2)))
+        return rpe_set_error(RPE_ERR_SHAPE, "resnet50_set_aux_head: bias, the output columns (row pitch >= (H/4)(W/4)), raw and idx are required");
+    e->aux_fwd.w = w; e->aux_fwd.bias = bias; e->aux_fwd.depth_feat = depth_feat; e->aux_fwd.out = out; e->aux_fwd.ld = ld_out; e->aux_fwd.raw = raw; e->aux_fwd.idx = idx;
+    return 0;
+}
+
+extern "C" int rpe_resnet50_aux_head_bwd(rpe_resnet50_t* e, const float* dout, long ld_dout, const float* w, const float* depth_feat, const float* raw,
+                                         const unsigned char* idx, float* dw, float* dbias, float* d_depth_feat, float* workspace, long workspace_floats,
+                                         void* stream) {
+    if (!e || !e->bound || !e->fwd_done) return rpe_set_error(RPE_ERR_STATE, "resnet50_aux_head_bwd: no training-mode forward to differentiate");
+    const ConvL& st = e->convs[0];
+    return rpe_aux_head_bwd_det_y(e->dtype, dout, ld_dout, st.y, st.scale, st.shift, w, depth_feat, raw, idx, dw, dbias, d_depth_feat, e->B, st.Ho, st.Wo, workspace,
+                                  workspace_floats, stream);
 }
 
 extern "C" int rpe_resnet50_side_stream_info(const rpe_resnet50_t* e, int* candidates, int* concurrent) {

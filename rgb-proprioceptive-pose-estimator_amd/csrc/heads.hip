@@ -59,7 +59,10 @@ __global__ __launch_bounds__(256) void aux_bwd_kernel(const float* __restrict__ 
                                                      const float* __restrict__ w, const float* __restrict__ depth_feat,
                                                      const float* __restrict__ raw, const unsigned char* __restrict__ idx,
                                                      T* __restrict__ d_a1, float* __restrict__ dw, float* __restrict__ dbias,
-                                                     float* __restrict__ d_depth_feat, int B, int H, int W, float* __restrict__ part) {
+                                                     float* __restrict__ d_depth_feat, int B, int H, int W, float* __restrict__ part,
+                                                     const float* __restrict__ bn_scale, const float* __restrict__ bn_shift) {
+    // bn_scale / bn_shift (round 4): `a1` is the RAW stem conv output y and the activated value is recomputed at the winner pixel,
+    // a1 = round_T(relu(y * scale + shift)) -- the tensor itself is not written when the aux head rides on the stem's apply + pool pass
     constexpr int CE = Elem<T>::kChunk, LPP = 64 / CE;
     __shared__ float sh_dw[64];
     __shared__ float sh_db;
@@ -69,9 +72,9 @@ __global__ __launch_bounds__(256) void aux_bwd_kernel(const float* __restrict__ 
     const int Ho = H / 2, Wo = W / 2;
     const long total = (long)B * Ho * Wo;
     const int sub = threadIdx.x % LPP;
-    float wv[CE], gw[CE];
+    float wv[CE], gw[CE], bsc[CE], bsh[CE];
 #pragma unroll
-    for (int e = 0; e < CE; ++e) { wv[e] = w[sub * CE + e]; gw[e] = 0.f; }
+    for (int e = 0; e < CE; ++e) { wv[e] = w[sub * CE + e]; gw[e] = 0.f; bsc[e] = bn_scale ? bn_scale[sub * CE + e] : 1.f; bsh[e] = bn_scale ? bn_shift[sub * CE + e] : 0.f; }
     float gb = 0.f;
     const int groups = blockDim.x / LPP;
     for (long o = (long)blockIdx.x * groups + threadIdx.x / LPP; o < total; o += (long)gridDim.x * groups) {
@@ -95,6 +98,11 @@ __global__ __launch_bounds__(256) void aux_bwd_kernel(const float* __restrict__ 
             if (k == bi) {
                 float v[CE];
                 chunk_to_f<T>(*(const u32x4*)(a1 + off), v);
+                if (bn_scale) {
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) v[e] = fmaxf(fmaf(v[e], bsc[e], bsh[e]), 0.f);
+                    chunk_to_f<T>(f_to_chunk<T>(v), v);   // as the forward rounded it
+                }
 #pragma unroll
                 for (int e = 0; e < CE; ++e) { g[e] = d * wv[e]; gw[e] += d * v[e]; }
             } else {
@@ -750,7 +758,7 @@ int rpe_aux_head_fwd(int dtype, const void* a1, const float* w, const float* bia
 
 static int aux_bwd_launch(int dtype, const float* dout, long ld_dout, const void* a1, const float* w, const float* depth_feat, const float* raw,
                           const unsigned char* idx, void* d_a1, float* dw, float* dbias, float* d_depth_feat, int B, int H, int W, float* part,
-                          long part_floats, void* stream);
+                          long part_floats, void* stream, const float* bn_scale = nullptr, const float* bn_shift = nullptr);
 
 long rpe_aux_head_bwd_workspace_floats(int dtype, int B, int H, int W) {
     const long total = (long)B * (H / 2) * (W / 2);
@@ -771,17 +779,28 @@ int rpe_aux_head_bwd(int dtype, const float* dout, long ld_dout, const void* a1,
     return aux_bwd_launch(dtype, dout, ld_dout, a1, w, depth_feat, raw, idx, d_a1, dw, dbias, d_depth_feat, B, H, W, nullptr, 0, stream);
 }
 
+/* the same from the RAW stem conv output y and bn1's scale / shift: the activated tensor a1 was never written (rpe_bn_apply_maxpool3x3s2_aux
+ * with a = NULL); compact form only (the stem backward gathers the a1 gradient itself: rpe_stem_bwd) */
+int rpe_aux_head_bwd_det_y(int dtype, const float* dout, long ld_dout, const void* y, const float* bn_scale, const float* bn_shift, const float* w,
+                           const float* depth_feat, const float* raw, const unsigned char* idx, float* dw, float* dbias, float* d_depth_feat, int B, int H,
+                           int W, float* workspace, long workspace_floats, void* stream) {
+    if (!y || !bn_scale || !bn_shift) return rpe_set_error(RPE_ERR_SHAPE, "aux_head_bwd_det_y: y, scale and shift are required");
+    if (!workspace || workspace_floats < rpe_aux_head_bwd_workspace_floats(dtype, B, H, W))
+        return rpe_set_error(RPE_ERR_WORKSPACE, "aux_head_bwd_det_y: workspace smaller than rpe_aux_head_bwd_workspace_floats()");
+    return aux_bwd_launch(dtype, dout, ld_dout, y, w, depth_feat, raw, idx, nullptr, dw, dbias, d_depth_feat, B, H, W, workspace, workspace_floats, stream, bn_scale, bn_shift);
+}
+
 static int aux_bwd_launch(int dtype, const float* dout, long ld_dout, const void* a1, const float* w, const float* depth_feat, const float* raw,
                           const unsigned char* idx, void* d_a1, float* dw, float* dbias, float* d_depth_feat, int B, int H, int W, float* part,
-                          long part_floats, void* stream) {
+                          long part_floats, void* stream, const float* bn_scale, const float* bn_shift) {
     const long total = (long)B * (H / 2) * (W / 2);
     // the gather is latency-bound (winner index -> winner pixel): many short blocks when their sums leave as plain stores (part);
     // with global atomics every block ends in 65 adds on the same 65 addresses, which is what then bounds the launch: fewer blocks
     int g = ew_grid(total, (dtype == RPE_F32 ? 16 : 32) * 4);
     if (!part && g > 1024) g = 1024;
-    if (dtype == RPE_F32) hipLaunchKernelGGL((aux_bwd_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, (const float*)a1, w, depth_feat, raw, idx, (float*)d_a1, dw, dbias, d_depth_feat, B, H, W, part);
-    else if (dtype == RPE_BF16) hipLaunchKernelGGL((aux_bwd_kernel<bf16>), dim3(g), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, (const bf16*)a1, w, depth_feat, raw, idx, (bf16*)d_a1, dw, dbias, d_depth_feat, B, H, W, part);
-    else if (dtype == RPE_F16) hipLaunchKernelGGL((aux_bwd_kernel<f16>), dim3(g), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, (const f16*)a1, w, depth_feat, raw, idx, (f16*)d_a1, dw, dbias, d_depth_feat, B, H, W, part);
+    if (dtype == RPE_F32) hipLaunchKernelGGL((aux_bwd_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, (const float*)a1, w, depth_feat, raw, idx, (float*)d_a1, dw, dbias, d_depth_feat, B, H, W, part, bn_scale, bn_shift);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((aux_bwd_kernel<bf16>), dim3(g), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, (const bf16*)a1, w, depth_feat, raw, idx, (bf16*)d_a1, dw, dbias, d_depth_feat, B, H, W, part, bn_scale, bn_shift);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((aux_bwd_kernel<f16>), dim3(g), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, (const f16*)a1, w, depth_feat, raw, idx, (f16*)d_a1, dw, dbias, d_depth_feat, B, H, W, part, bn_scale, bn_shift);
     else return rpe_set_error(RPE_ERR_DTYPE, "aux_head: unsupported dtype");
     RPE_CHECK_LAUNCH();
     if (part) {

@@ -477,22 +477,36 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 // hits), writes the four a pixels of its own 2 x 2 block (taps (1..2, 1..2): every input pixel has exactly one owner; H and W even)
 // and the pooled chunk with its winner taps.  Values are compared AFTER rounding to T, ties / NaN exactly as maxpool_fwd_kernel on the
 // stored a: the results are bitwise those of bn_apply_kernel followed by maxpool_fwd_kernel.
-template <typename T>
+// AUX (round 4): the bn1 aux head -- Conv2d(64 -> 1, 1x1) + MaxPool2d(2) (x the depth feature), models/naive.py:223-231,318-330 -- rides
+// along: a thread's own 2 x 2 block of a IS the aux head's pooling window, and the 8 (4 in fp32) threads of a pooled pixel hold all 64
+// channels of it, so the 1x1 conv is 8 multiply-adds per pixel and thread plus a shuffle sum over the group; the first thread writes
+// the feature, the raw maximum and the winner tap exactly as aux_fwd_kernel does (same products of the ROUNDED a, same tie rule).
+// With `a` null the activated tensor is not written at all: nobody else reads it (the stem backward works from y), which saves its
+// 411-MB write here and the 411-MB read of the separate aux launch.
+struct StemAuxFwd {
+    const float *w, *bias, *depth_feat;   // [64], [1], [B][Ho*Wo] or null
+    float* out; long ld_out;              // feature columns of the fused feature rows
+    float* raw; unsigned char* idx;       // [B][Ho*Wo]: the window maximum before the depth product, its winner tap
+};
+template <typename T, bool AUX>
 __global__ __launch_bounds__(256) void bn_apply_maxpool_kernel(const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
                                                               T* __restrict__ a, T* __restrict__ out, unsigned char* __restrict__ idx,
-                                                              int B, int H, int W, int C, int Ho, int Wo) {
+                                                              int B, int H, int W, int C, int Ho, int Wo, const StemAuxFwd aux) {
     constexpr int CE = Elem<T>::kChunk;
     const int cpr = C / CE;
     const long total = (long)B * Ho * Wo * cpr;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long span = (long)gridDim.x * blockDim.x;
+    // (AUX: every thread of a pooled pixel's group takes part in the shuffles, so the loop bound is rounded up to whole groups -- total is a
+    // multiple of cpr, and cpr divides the wave: a group is either all in or all out)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += span) {
         const int cc = (int)(i % cpr);
         long pix = i / cpr;
         const int ow = (int)(pix % Wo); pix /= Wo;
         const int oh = (int)(pix % Ho);
         const int b = (int)(pix / Ho);
-        float sc[CE], sh[CE];
+        float sc[CE], sh[CE], aw[CE], ad[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < CE; ++e) { sc[e] = scale[cc * CE + e]; sh[e] = shift[cc * CE + e]; }
+        for (int e = 0; e < CE; ++e) { sc[e] = scale[cc * CE + e]; sh[e] = shift[cc * CE + e]; aw[e] = AUX ? aux.w[cc * CE + e] : 0.f; }
         u32x4 raw[9];
         bool ok[9];
 #pragma unroll
@@ -513,17 +527,42 @@ __global__ __launch_bounds__(256) void bn_apply_maxpool_kernel(const T* __restri
 #pragma unroll
             for (int e = 0; e < CE; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);   // bn_apply_kernel's expression
             const u32x4 packed = f_to_chunk<T>(v);
-            if (k / 3 >= 1 && k % 3 >= 1) {   // this thread's own 2 x 2 block
+            if (k / 3 >= 1 && k % 3 >= 1 && a) {   // this thread's own 2 x 2 block
                 const int ih = oh * 2 - 1 + k / 3, iw = ow * 2 - 1 + k % 3;
                 *(u32x4*)(a + (((long)b * H + ih) * W + iw) * C + cc * CE) = packed;
             }
             chunk_to_f<T>(packed, v);               // compare what the pool pass would have read back
+            if (AUX && k / 3 >= 1 && k % 3 >= 1) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < CE; ++e) d += v[e] * aw[e];
+                ad[(k / 3 - 1) * 2 + (k % 3 - 1)] = d;
+            }
 #pragma unroll
             for (int e = 0; e < CE; ++e)
                 if (v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = (unsigned char)k; }
         }
         *(u32x4*)(out + i * CE) = f_to_chunk<T>(best);
         store_winners<CE>(idx + i * CE, bi);
+        if (AUX) {
+            const float bv = aux.bias[0];
+            float bestd = -INFINITY;
+            int bk = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float d = ad[k];
+                for (int o = 1; o < cpr; o <<= 1) d += __shfl_xor(d, o);   // the group's lanes are consecutive and aligned (cpr divides 64)
+                d += bv;
+                if (d > bestd || d != d) { bestd = d; bk = k; }
+            }
+            if (cc == 0) {
+                const long pos = (long)oh * Wo + ow, flat = (long)b * Ho * Wo + pos;
+                const float df = aux.depth_feat ? aux.depth_feat[flat] : 1.f;
+                aux.out[(long)b * aux.ld_out + pos] = bestd * df;
+                aux.raw[flat] = bestd;
+                aux.idx[flat] = (unsigned char)bk;
+            }
+        }
     }
 }
 
@@ -1243,13 +1282,34 @@ int rpe_bn_apply_maxpool3x3s2(int dtype, const void* y, const float* scale, cons
                               int W, int C, void* stream) {
     note_kernel("bn_apply_maxpool_kernel");
     if (B <= 0 || H <= 0 || W <= 0 || ((H | W) & 1) || C <= 0 || (C % 8)) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply_maxpool: H and W even, C % 8 == 0");
+    if (!a) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply_maxpool: the activated output is required (rpe_bn_apply_maxpool3x3s2_aux may omit it)");
     const int Ho = H / 2, Wo = W / 2;
     const long n = (long)B * Ho * Wo * C;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == RPE_F32) hipLaunchKernelGGL((bn_apply_maxpool_kernel<float>), dim3(ew_grid(n / 4)), dim3(256), 0, s, (const float*)y, scale, shift, (float*)a, (float*)out, idx, B, H, W, C, Ho, Wo);
-    else if (dtype == RPE_BF16) hipLaunchKernelGGL((bn_apply_maxpool_kernel<bf16>), dim3(ew_grid(n / 8)), dim3(256), 0, s, (const bf16*)y, scale, shift, (bf16*)a, (bf16*)out, idx, B, H, W, C, Ho, Wo);
-    else if (dtype == RPE_F16) hipLaunchKernelGGL((bn_apply_maxpool_kernel<f16>), dim3(ew_grid(n / 8)), dim3(256), 0, s, (const f16*)y, scale, shift, (f16*)a, (f16*)out, idx, B, H, W, C, Ho, Wo);
+    const StemAuxFwd none{};
+    if (dtype == RPE_F32) hipLaunchKernelGGL((bn_apply_maxpool_kernel<float, false>), dim3(ew_grid(n / 4)), dim3(256), 0, s, (const float*)y, scale, shift, (float*)a, (float*)out, idx, B, H, W, C, Ho, Wo, none);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((bn_apply_maxpool_kernel<bf16, false>), dim3(ew_grid(n / 8)), dim3(256), 0, s, (const bf16*)y, scale, shift, (bf16*)a, (bf16*)out, idx, B, H, W, C, Ho, Wo, none);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((bn_apply_maxpool_kernel<f16, false>), dim3(ew_grid(n / 8)), dim3(256), 0, s, (const f16*)y, scale, shift, (f16*)a, (f16*)out, idx, B, H, W, C, Ho, Wo, none);
     else return rpe_set_error(RPE_ERR_DTYPE, "bn_apply_maxpool: unsupported dtype");
+    RPE_CHECK_LAUNCH();
+    return 0;
+}
+
+int rpe_bn_apply_maxpool3x3s2_aux(int dtype, const void* y, const float* scale, const float* shift, void* a, void* out, unsigned char* idx, int B, int H,
+                                  int W, const float* aux_w, const float* aux_bias, const float* depth_feat, float* aux_out, long ld_aux_out, float* aux_raw,
+                                  unsigned char* aux_idx, void* stream) {
+    note_kernel("bn_apply_maxpool_kernel<aux>");
+    if (B <= 0 || H <= 0 || W <= 0 || ((H | W) & 1)) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply_maxpool_aux: H and W even (64 channels)");
+    if (!aux_w || !aux_bias || !aux_out || !aux_raw || !aux_idx || ld_aux_out < (long)(H / 2) * (W / 2)) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply_maxpool_aux: aux head weight, bias and outputs are required");
+    const int Ho = H / 2, Wo = W / 2, C = 64;
+    const long n = (long)B * Ho * Wo * C;
+    hipStream_t s = (hipStream_t)stream;
+    const StemAuxFwd aux{aux_w, aux_bias, depth_feat, aux_out, ld_aux_out, aux_raw, aux_idx};
+    // whole blocks of whole groups: the grid covers every chunk exactly once (no grid-stride tail splits a group)
+    if (dtype == RPE_F32) hipLaunchKernelGGL((bn_apply_maxpool_kernel<float, true>), dim3(ew_grid(n / 4)), dim3(256), 0, s, (const float*)y, scale, shift, (float*)a, (float*)out, idx, B, H, W, C, Ho, Wo, aux);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((bn_apply_maxpool_kernel<bf16, true>), dim3(ew_grid(n / 8)), dim3(256), 0, s, (const bf16*)y, scale, shift, (bf16*)a, (bf16*)out, idx, B, H, W, C, Ho, Wo, aux);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((bn_apply_maxpool_kernel<f16, true>), dim3(ew_grid(n / 8)), dim3(256), 0, s, (const f16*)y, scale, shift, (f16*)a, (f16*)out, idx, B, H, W, C, Ho, Wo, aux);
+    else return rpe_set_error(RPE_ERR_DTYPE, "bn_apply_maxpool_aux: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;
 }

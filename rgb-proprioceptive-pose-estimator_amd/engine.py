@@ -132,9 +132,11 @@ class ResNet50Trunk(nn.Module):
         self._wver += 1
 
     # -- compute ----------------------------------------------------------------------------------
-    def run(self, img, features, training):
+    def run(self, img, features, training, pre_forward=None):
         """img (B,3,H,W) fp32 device tensor; features: fp32 2-D device tensor whose first `latent`
-        columns receive the ResNet output.  Returns the plan (early feature / backward handle)."""
+        columns receive the ResNet output.  Returns the plan (early feature / backward handle).
+        pre_forward(plan): called once the plan is chosen and before the engine's forward is enqueued (the bn1 aux head hands the
+        engine its parameters and output columns there: headops.AuxHeadOp.bind_fused)."""
         if not img.is_cuda:
             raise RuntimeError("ResNet50Trunk needs device tensors: the HIP path has no CPU fallback")
         frames = img.dtype == torch.uint8  # raw simulator frames (B, Hs, Ws, 3): cropped + normalised on the device
@@ -157,6 +159,8 @@ class ResNet50Trunk(nn.Module):
             lib.rpe_resnet50_weights_changed(plan.handle)
         plan.wver = self._wver
         lib.rpe_resnet50_set_stem_raw(plan.handle, int(self.keep_stem_raw))
+        if pre_forward is not None:
+            pre_forward(plan)
         if frames:
             F3 = ctypes.c_float * 3
             hr, wr = resized_hw(hs, ws, self.resize_to)
@@ -254,6 +258,9 @@ class _Plan:
     # early feature relu(bn1(conv1 x)) as an NHWC tensor aliasing the workspace
     def early_feature(self):
         ptr = lib.rpe_resnet50_early_feature(self.handle)
+        if not ptr:
+            raise RuntimeError("the last forward computed the bn1 aux head inside the stem's apply + pool pass and did not write relu(bn1(conv1 x)) "
+                               "(rpe_resnet50_set_aux_head); set RPE_NO_AUX_FUSE=1 to keep the tensor")
         return self._alias(ptr, (self.batch, self.h // 2, self.w // 2, 64))
 
     def hooked_feature(self, layer):

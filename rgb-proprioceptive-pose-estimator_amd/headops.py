@@ -172,25 +172,53 @@ class AuxHeadOp:
         self.trainable = trainable
         self.layer, self.pools, self.dense = layer, pools, dense
 
-    def fwd(self, plan, depth, out_cols, use_depth, save=True):
-        """out_cols: [B, (H/2)*(W/2)] column slice of the fused feature rows."""
-        if self.layer != 9:
-            return self._fwd_general(plan, depth, out_cols, use_depth, save)
-        a1 = plan.early_feature()
-        b, h, w, _ = a1.shape
-        n = (h // 2) * (w // 2)
-        dev = a1.device
-        raw = torch.empty((b, n), dtype=torch.float32, device=dev)
-        idx = torch.empty((b, n), dtype=torch.uint8, device=dev)
+    def can_fuse(self, training):
+        """The bn1 head of a TRAINING forward can ride on the stem's apply + pool pass (round 4): the engine computes it and never
+        writes relu(bn1(conv1 x)).  Not in dense mode (a conv1 hook / RPE_STEM_UNFUSED need the tensor), not in inference."""
+        return (training and self.layer == 9 and not self.dense and os.environ.get("RPE_STEM_UNFUSED") is None
+                and os.environ.get("RPE_NO_AUX_FUSE") is None)
+
+    def _depth_feature(self, depth, b, h, w, n, dev, use_depth):
         feat = xhat = None
-        s = ops._stream()
         if use_depth:
             if depth is None or depth.shape[-2:] != (2 * h, 2 * w):
                 raise ValueError("use_depth=True needs a (B,1,H,W) depth batch matching the image size")
             depth = depth.reshape(b, 2 * h, 2 * w).contiguous()
             feat = torch.empty((b, n), dtype=torch.float32, device=dev)
             xhat = torch.empty((b, n), dtype=torch.float32, device=dev)
-            lib.rpe_depth_head_fwd(ops._p(depth), ops._p(self.in_w.data), ops._p(self.in_b.data), ops._p(feat), ops._p(xhat), b, 2 * h, 2 * w, s)
+            lib.rpe_depth_head_fwd(ops._p(depth), ops._p(self.in_w.data), ops._p(self.in_b.data), ops._p(feat), ops._p(xhat), b, 2 * h, 2 * w, ops._stream())
+        return feat, xhat
+
+    def bind_fused(self, plan, depth, out_cols, use_depth, save=True):
+        """Called BEFORE the trunk's forward (ResNet50Trunk.run(pre_forward=...)): the depth feature is computed here, the engine is
+        handed the head's parameters and output columns and computes the head inside its stem pass (rpe_resnet50_set_aux_head)."""
+        b, h, w = plan.batch, plan.h // 2, plan.w // 2
+        n = (h // 2) * (w // 2)
+        dev = out_cols.device
+        raw = torch.empty((b, n), dtype=torch.float32, device=dev)
+        idx = torch.empty((b, n), dtype=torch.uint8, device=dev)
+        feat, xhat = self._depth_feature(depth, b, h, w, n, dev, use_depth)
+        lib.rpe_resnet50_set_aux_head(plan.handle, ops._p(self.conv_w.data), ops._p(self.conv_b.data), ops._p(feat), ops._p(out_cols), out_cols.stride(0),
+                                      ops._p(raw), ops._p(idx))
+        self._bound = (raw, idx, feat)   # alive until the forward has been enqueued
+        if save:
+            self.saved = (plan, raw, idx, feat, xhat, b, h, w, n)
+        self.fused = True
+        return out_cols
+
+    def fwd(self, plan, depth, out_cols, use_depth, save=True):
+        """out_cols: [B, (H/2)*(W/2)] column slice of the fused feature rows."""
+        if self.layer != 9:
+            return self._fwd_general(plan, depth, out_cols, use_depth, save)
+        self.fused = False
+        a1 = plan.early_feature()
+        b, h, w, _ = a1.shape
+        n = (h // 2) * (w // 2)
+        dev = a1.device
+        raw = torch.empty((b, n), dtype=torch.float32, device=dev)
+        idx = torch.empty((b, n), dtype=torch.uint8, device=dev)
+        s = ops._stream()
+        feat, xhat = self._depth_feature(depth, b, h, w, n, dev, use_depth)
         lib.rpe_aux_head_fwd(ops.dtype_code(a1), ops._p(a1), ops._p(self.conv_w.data), ops._p(self.conv_b.data), ops._p(feat), ops._p(out_cols),
                              out_cols.stride(0), ops._p(raw), ops._p(idx), b, h, w, s)
         if save:
@@ -251,12 +279,13 @@ class AuxHeadOp:
         if self.layer != 9:
             return self._bwd_general(d_cols)
         plan, raw, idx, feat, xhat, b, h, w, n = self.saved
-        a1 = plan.early_feature()
+        fused = getattr(self, "fused", False)   # the forward rode on the stem pass: a1 does not exist, the engine recomputes it from y
+        a1 = None if fused else plan.early_feature()
         # The gradient of a1 is NOT materialised (a 411 MB tensor at 256 images, zero in 3 of 4 pixels): the trunk's fused stem
         # backward gathers it from (d_cols, depth feature, winner index, conv weight).  RPE_STEM_UNFUSED=1: dense form.
         dense = self.dense or os.environ.get("RPE_STEM_UNFUSED") is not None
         d_a1 = plan.early_grad() if dense else None
-        dev = a1.device
+        dev = d_cols.device
         if self.trainable:
             gw, gb = _grad_of(self.conv_w), _grad_of(self.conv_b)
             gw.zero_(), gb.zero_()
@@ -267,12 +296,18 @@ class AuxHeadOp:
         s = ops._stream()
         # parameter gradients through per-block partial sums added in a fixed order (bitwise reproducible, and faster than 65 global
         # atomics per block on the same 65 addresses)
-        code = ops.dtype_code(a1)
+        code = ops.dtype_code(plan.dtype)
         nws = lib.rpe_aux_head_bwd_workspace_floats(code, b, h, w)
         if getattr(self, "_part", None) is None or self._part.numel() < nws or self._part.device != dev:
             self._part = torch.empty(nws, dtype=torch.float32, device=dev)
-        lib.rpe_aux_head_bwd_det(code, ops._p(d_cols), d_cols.stride(0), ops._p(a1), ops._p(self.conv_w.data), ops._p(feat), ops._p(raw),
-                                 ops._p(idx), ops._p(d_a1), ops._p(gw), ops._p(gb), ops._p(d_feat), b, h, w, ops._p(self._part), self._part.numel(), s)
+        if fused:
+            if dense:
+                raise RuntimeError("AuxHeadOp: a fused forward cannot be followed by the dense backward")
+            lib.rpe_resnet50_aux_head_bwd(plan.handle, ops._p(d_cols), d_cols.stride(0), ops._p(self.conv_w.data), ops._p(feat), ops._p(raw), ops._p(idx),
+                                          ops._p(gw), ops._p(gb), ops._p(d_feat), ops._p(self._part), self._part.numel(), s)
+        else:
+            lib.rpe_aux_head_bwd_det(code, ops._p(d_cols), d_cols.stride(0), ops._p(a1), ops._p(self.conv_w.data), ops._p(feat), ops._p(raw),
+                                     ops._p(idx), ops._p(d_a1), ops._p(gw), ops._p(gb), ops._p(d_feat), b, h, w, ops._p(self._part), self._part.numel(), s)
         if not dense:
             self._keep = (d_cols, feat, idx)   # alive until the trunk backward has been enqueued
             plan.set_aux_grad(d_cols, feat, idx, self.conv_w.data)

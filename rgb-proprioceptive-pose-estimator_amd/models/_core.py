@@ -224,16 +224,27 @@ class PoseModelBase(nn.Module):
 
     def _features_fwd(self, img, depth, rows, save):
         """img (B,3,H,W); rows [B, ld] fp32: columns [0,L) <- ResNet latent, [L, L+aux) <- aux head."""
-        plan = self.trunk.run(img, rows, self.training)
+        # the bn1 head of a training forward rides on the engine's stem pass (headops.AuxHeadOp.bind_fused): it is bound before the run
+        cols, fused, off = {}, set(), self.latent_dim
         if self.aux_nets is not None:
-            off = self.latent_dim
             for op in self._aux_ops:
                 c, h, w = self.HOOK_SHAPES[op.layer]
+                cols[id(op)] = rows[:, off:off + h * w // 4]
+                off += h * w // 4
+
+        def pre_forward(plan):
+            for op in (self._aux_ops or ()) if self.aux_nets is not None else ():
+                if op.can_fuse(self.training):
+                    op.bind_fused(plan, depth if self.use_depth else None, cols[id(op)], self.use_depth, save=save)
+                    fused.add(id(op))
+
+        plan = self.trunk.run(img, rows, self.training, pre_forward=pre_forward)
+        if self.aux_nets is not None:
+            for op in self._aux_ops:
                 if (plan.h, plan.w) != (224, 224) and op.layer != 9:
                     raise ValueError("hooks other than bn1 are sized for 224x224 inputs (as the reference's dummy forward is)")
-                n = h * w // 4
-                op.fwd(plan, depth if self.use_depth else None, rows[:, off:off + n], self.use_depth, save=save)
-                off += n
+                if id(op) not in fused:
+                    op.fwd(plan, depth if self.use_depth else None, cols[id(op)], self.use_depth, save=save)
         self._plan = plan
         return plan
 

@@ -30,7 +30,7 @@ ENGINE_VARIANTS = [
     # (the golden case's eval / rollout outputs run at 2-4 images: the default takes the split-K kernels there)
     {"RPE_NO_SPLITK": "1", "RPE_NO_DS_FUSE": "1", "RPE_WGRAD_FOLD_MAX": "128", "RPE_NO_LINEAR_SPLITK": "1", "RPE_NO_DS_FOLD": "1"},
     # round 4: the round-3 bottleneck dataflow (y3 written, BN3 statistics from the conv epilogue, apply pass); the second stream unprobed
-    {"RPE_NO_Y3FREE": "1", "RPE_NO_SIDE_PROBE": "1"},
+    {"RPE_NO_Y3FREE": "1", "RPE_NO_SIDE_PROBE": "1", "RPE_NO_AUX_FUSE": "1"},   # (+ the bn1 aux head as its own launch on a written a1)
     # the new forward (Gram statistics, fused conv3 epilogue) with y3 still written and the round-3 backward; Gram matrix as its own launch
     {"RPE_Y3_KEEP": "1", "RPE_NO_APPLY_GRAM": "1"},
     # y3-free with dz3^T a2 as the side product of the next block's fused conv1 data gradient (measured slower, off by default);

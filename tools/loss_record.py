@@ -44,28 +44,35 @@ def dev_batch(i):
     bb = po.synth_batch((B,), 1234 + i) if FRESH else batch
     return tuple(None if t is None else t.cuda() for t in (bb["img"], None, bb["x0bar"], bb["x0"], None, bb["obj"]))
 
-for name, dtype in (("f32", torch.float32), ("bf16", torch.bfloat16), ("f16", torch.float16)):
+DTYPES = (("f32", torch.float32), ("bf16", torch.bfloat16), ("f16", torch.float16))
+models, opts, crits, hist = {}, {}, {}, {}
+for name, dtype in DTYPES:
     with contextlib.redirect_stdout(sys.stderr):
         m = M.NaiveObjectStateEstimator("cube", [1024, 256, 64], 50, 512, False, (9,), False, False, False, compute_dtype=dtype)
     m.load_state_dict({k: v.clone() for k, v in sd0.items()})
     m.cuda().train()
-    crit = {"obj_loss": M.PoseDistanceLoss(distance_metric="combined", scale_factor=1.0, alpha=0.5, mode="pose"), "val_loss": M.PoseDistanceLoss(mode="val")}
-    opt = FusedAdam(m.parameters(), lr=1e-3)
-    b = dev_batch(0)
-    ls, pos = [], []
-    for i in range(STEPS):
-        if FRESH and i:
-            b = dev_batch(i)
-        loss, pe, oe = train_step(m, b, crit, opt, True, "train", None)
-        ls.append(clean(float(loss.item())))
-        pos.append(round(float(pe.item()) / B, 5))
+    models[name], opts[name] = m, FusedAdam(m.parameters(), lr=1e-3)
+    crits[name] = {"obj_loss": M.PoseDistanceLoss(distance_metric="combined", scale_factor=1.0, alpha=0.5, mode="pose"), "val_loss": M.PoseDistanceLoss(mode="val")}
+    hist[name] = ([], [])
+b = dev_batch(0)
+for i in range(STEPS):          # steps outside, compute types inside: every type sees the same batch, generated once
+    if FRESH and i:
+        b = dev_batch(i)
+    for name, _ in DTYPES:
+        loss, pe, oe = train_step(models[name], b, crits[name], opts[name], True, "train", None)
+        hist[name][0].append(clean(float(loss.item())))
+        hist[name][1].append(round(float(pe.item()) / B, 5))
+    if i % 25 == 0:
+        print("[loss_record] step %d: %s" % (i, {n: hist[n][0][-1] for n, _ in DTYPES}), file=sys.stderr, flush=True)
+for name, _ in DTYPES:
+    ls, pos = hist[name]
     tail = [x for x in ls[-50:] if x is not None]
     out[name] = {"loss": ls, "mean_pos_err_m": pos, "nan_loss_steps": sum(1 for x in ls if x is None),
                  "mean_loss_last_50": round(sum(tail) / max(1, len(tail)), 4), "mean_pos_err_m_last_50": round(sum(pos[-50:]) / len(pos[-50:]), 5),
-                 "params_finite": bool(torch.isfinite(m._arena.flat).all().item())}
+                 "params_finite": bool(torch.isfinite(models[name]._arena.flat).all().item())}
     print("[loss_record] %s: first %.4f last %s min %s" % (name, ls[0], ls[-1], min(x for x in ls if x is not None)), file=sys.stderr)
-    del m, opt
-    torch.cuda.empty_cache()
+del models, opts
+torch.cuda.empty_cache()
 if ORACLE:
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     sd, opt, ls = {k: v.clone() for k, v in sd0.items()}, {}, []
