@@ -146,6 +146,13 @@ __global__ __launch_bounds__(512) void gram_reduce_kernel(const float* __restric
     if (idx < n4) {
         const f32x4* src = (const f32x4*)slab + idx;
         int g = w;
+        for (; g + 56 < G; g += 64) {   // 8 loads in flight per lane (the launch sits on the forward's critical path)
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(long)(g + 8 * u) * n4];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { s0 += v[u]; s1 += v[u + 1]; }
+        }
         for (; g + 8 < G; g += 16) {
             const f32x4 a = src[(long)g * n4], b = src[(long)(g + 8) * n4];
             s0 += a; s1 += b;

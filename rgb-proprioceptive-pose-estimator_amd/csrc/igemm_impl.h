@@ -9,8 +9,9 @@
 //
 // Layout: activations NHWC (channels contiguous), weights [N][K] with K = (r, s, c) contiguous.
 // Operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds through raw buffer descriptors: 32-bit lane offsets, the
-// hardware range check supplies the zeros of padding taps and tails) into a 2..3-slot ring, one raw s_barrier per K step;
-// only the 7x7 stem (two 8-byte pixels per chunk with separate bounds) stages through registers.
+// hardware range check supplies the zeros of padding taps and tails) into a 2..3-slot ring, one raw s_barrier per K step --
+// since round 4 the 7x7 stem too, over a zero-bordered image (rounds 1-3 staged its two-pixel chunks through registers; what is
+// left of that form in tn_kernel -- USE_DMA = false, stem_chunk -- is no longer instantiated).
 // The weight tile is the MFMA "A" operand and the activation tile the "B" operand, so the accumulator registers of a lane run
 // along N (channels); the epilogue passes them once through LDS so that every lane owns 8 consecutive channels of one row.
 #include <stdio.h>
@@ -174,13 +175,11 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
     int a_row[AR], a_chunk[AR], b_row[BR], b_chunk[BR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        if (DMA) { a_row[i] = (wave * AR + i) * RPI + lane / KCH; a_chunk[i] = nt_swz<KCH>(a_row[i], lane % KCH); }
-        else { a_row[i] = (tid >> 2) + 64 * i; a_chunk[i] = tid & 3; }
+        a_row[i] = (wave * AR + i) * RPI + lane / KCH; a_chunk[i] = nt_swz<KCH>(a_row[i], lane % KCH);
     }
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-        if (DMA) { b_row[i] = (wave * BR + i) * RPI + lane / KCH; b_chunk[i] = nt_swz<KCH>(b_row[i], lane % KCH); }
-        else { b_row[i] = (tid >> 2) + 64 * i; b_chunk[i] = tid & 3; }
+        b_row[i] = (wave * BR + i) * RPI + lane / KCH; b_chunk[i] = nt_swz<KCH>(b_row[i], lane % KCH);
     }
 
     // DMA path addressing: buffer_load ... lds through two raw buffer descriptors (A, weights).  Per lane and chunk a 32-bit
@@ -262,20 +261,6 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
         }
     }
 
-    // source address of A chunk i for the current K-step, or nullptr for zero fill
-    auto a_src = [&](int i) -> const T* {
-        const bool kok = (kbase + a_chunk[i] * CE) < p.K;
-        if (MODE == MODE_DENSE) return (a_ok[i] && kok) ? p.A + a_base[i] + kbase : nullptr;
-        const int nh = a_hb[i] + g.tap_sign * tr, nw = a_wb[i] + g.tap_sign * ts;
-        const int msk = (1 << g.sd_shift) - 1;
-        const int ih = nh >> g.sd_shift, iw = nw >> g.sd_shift;
-        const bool ok = a_ok[i] && nh >= 0 && nw >= 0 && ((nh | nw) & msk) == 0 && ih < g.H && iw < g.W;
-        return ok ? p.A + a_base[i] + ((long)ih * g.W + iw) * g.C + c0 + a_chunk[i] * CE : nullptr;
-    };
-    auto b_src = [&](int i) -> const T* {
-        const bool kok = (kbase + b_chunk[i] * CE) < p.K;
-        return (b_ok[i] && kok) ? p.Bw + b_off[i] + kbase : nullptr;
-    };
     // conv: voffsets of the A chunks for the current tap (tr, ts); refreshed only when the tap changes
     auto tap_offsets = [&]() {
         const int msk = (1 << g.sd_shift) - 1;
@@ -357,24 +342,6 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(base + BM * KCH * 16 + (wave_u * BR + i) * 1024), 16, (int)vo, so_b, 0, 0);
         }
     };
-    u32x4 ra[AR], rb[BR];
-    auto load_tile = [&]() {  // register staging (stem)
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            if (MODE == MODE_STEM) ra[i] = stem_chunk<T>(p.A, a_base[i], a_hb[i], a_wb[i], g.H, g.W, kbase + a_chunk[i] * CE, a_ok[i]);
-            else { const T* src = a_src(i); ra[i] = src ? ld16(src) : zero16(); }
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) { const T* src = b_src(i); rb[i] = src ? ld16(src) : zero16(); }
-    };
-    auto store_tile = [&](int st) {
-        u32x4* base = lds + st * STAGE;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) base[a_row[i] * KCH + nt_swz<KCH>(a_row[i], a_chunk[i])] = ra[i];
-#pragma unroll
-        for (int i = 0; i < BR; ++i) base[BM * KCH + b_row[i] * KCH + nt_swz<KCH>(b_row[i], b_chunk[i])] = rb[i];
-    };
-
     // ---- epilogue lane geometry (needed early: the data-gradient form prefetches its epilogue operands) ----
     constexpr int LDW = WN + 4;     // staged row pitch in floats (+4: conflict-free float4 writes)
     constexpr int CPW = WN / 8;     // 8-channel chunks per staged row
@@ -563,7 +530,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
         };
         k_step(0, TagFirst{});
         for (int kt = 1; kt < nk; ++kt) k_step(kt, TagNext{});
-    } else if (DMA) {
+    } else {
         // 3-slot ring, tiles kt+1 and kt+2 in flight while tile kt is multiplied.  A tile is NI LDS-DMA instructions per
         // wave; vmcnt counts them in issue order, so "all but the newest NI landed" == tile kt+1 is complete.  The raw
         // s_barrier (not __syncthreads, which would drain vmcnt to 0) then publishes it to the other waves; slot (kt+2)%3
@@ -596,20 +563,6 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
             if (newer >= 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             if (++st == NSTAGE) st = 0;
-        };
-        if (nk > 0) k_step(0, TagFirst{});
-        for (int kt = 1; kt < nk; ++kt) k_step(kt, TagNext{});
-    } else {
-        load_tile();
-        store_tile(0);
-        __syncthreads();
-        auto k_step = [&](int kt, auto first_tag) {
-            const int cur = kt & 1;
-            const bool more = kt + 1 < nk;
-            if (more) { advance_k(); load_tile(); }
-            compute(cur, first_tag);
-            if (more) store_tile(cur ^ 1);
-            __syncthreads();
         };
         if (nk > 0) k_step(0, TagFirst{});
         for (int kt = 1; kt < nk; ++kt) k_step(kt, TagNext{});
@@ -1215,6 +1168,13 @@ __global__ __launch_bounds__(512) void tn_reduce_kernel(const float* __restrict_
     const f32x4* src = (const f32x4*)slab + idx;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
     int sp = w;
+    for (; sp + 56 < splits; sp += 64) {   // 8 loads in flight per lane (same order of additions as the two-at-a-time loop below)
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(long)(sp + 8 * u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) { s0 += v[u]; s1 += v[u + 1]; }
+    }
     for (; sp + 8 < splits; sp += 16) {
         const f32x4 a = src[(long)sp * stride], b = src[(long)(sp + 8) * stride];
         s0 += a; s1 += b;

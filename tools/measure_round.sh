@@ -2,7 +2,7 @@
 # cycles, one step's timeline, the other model families, the data-parallel path on one GPU, the fp16 line, the loss record.
 # usage: bash tools/measure_round.sh <tag>     outputs under gpurun_out/measure_<tag>/
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/measure_$tag
 mkdir -p $out
@@ -28,7 +28,9 @@ python bench.py --dtype f16 --steps 30 --warmup 8 --no-cpu-baseline --preconditi
 python bench.py --force-dist --steps 30 --warmup 8 --precondition-min 2 2>> $out/dist.err | tail -1 > $out/bench_force_dist.json
 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --precondition-min 2 2>> $out/dist.err | tail -1 > $out/bench_plain_same_box.json
 echo "dist done" >> $out/progress.txt
+if [ "${RPE_MEASURE_LOSS:-0}" = "1" ]; then   # (the convergence records take minutes of host time: tools/loss_record.py 256 300 0 fresh, run on their own)
 python tools/loss_record.py 32 200 20 > $out/loss_trace.json 2> $out/loss.err
 echo "loss done" >> $out/progress.txt
+fi
 rm -rf $out/pmc $out/mfma $out/stats/*.db 2>/dev/null || true   # (the raw counter tables are tens of MB; gpurun merges at most 64 MiB back)
 ls -la $out | tail -30
