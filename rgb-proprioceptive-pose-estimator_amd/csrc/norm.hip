@@ -102,17 +102,19 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
         // 4 independent row loads in flight per thread (the loop is latency-, not bandwidth-bound)
         const int st = 8 * NS;
         int t = blockIdx.y + rl * NS;
+        // (a functor with the row-dot form ignores the second sum: its half of every partial row -- zeros -- is not even read)
+        constexpr bool NOQ = FinHasDot<Fin>::value;
         for (; t + 3 * st < tiles; t += 4 * st) {
-            const float a0 = part[((long)t * 2 + 0) * C + c], b0 = part[((long)t * 2 + 1) * C + c];
-            const float a1 = part[((long)(t + st) * 2 + 0) * C + c], b1 = part[((long)(t + st) * 2 + 1) * C + c];
-            const float a2 = part[((long)(t + 2 * st) * 2 + 0) * C + c], b2 = part[((long)(t + 2 * st) * 2 + 1) * C + c];
-            const float a3 = part[((long)(t + 3 * st) * 2 + 0) * C + c], b3 = part[((long)(t + 3 * st) * 2 + 1) * C + c];
+            const float a0 = part[((long)t * 2 + 0) * C + c], b0 = NOQ ? 0.f : part[((long)t * 2 + 1) * C + c];
+            const float a1 = part[((long)(t + st) * 2 + 0) * C + c], b1 = NOQ ? 0.f : part[((long)(t + st) * 2 + 1) * C + c];
+            const float a2 = part[((long)(t + 2 * st) * 2 + 0) * C + c], b2 = NOQ ? 0.f : part[((long)(t + 2 * st) * 2 + 1) * C + c];
+            const float a3 = part[((long)(t + 3 * st) * 2 + 0) * C + c], b3 = NOQ ? 0.f : part[((long)(t + 3 * st) * 2 + 1) * C + c];
             s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
             q += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
         }
         for (; t < tiles; t += st) {
             s += (double)part[((long)t * 2 + 0) * C + c];
-            q += (double)part[((long)t * 2 + 1) * C + c];
+            if (!NOQ) q += (double)part[((long)t * 2 + 1) * C + c];
         }
     }
     sh[0][rl][cl] = s;
@@ -172,14 +174,15 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
         }
     }
     if constexpr (FinHasDot<Fin>::value) {
-        double d = c < C ? fin.dot(c, rl, 8) : 0.0;
+        // row dot products: 8 CONSECUTIVE lanes share a channel and walk its row together (coalesced 32-byte runs; with the channel on the
+        // fast lane index every load touched 32 lines), their partial sums meet by xor shuffles in a fixed order
+        const int dc = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+        double d = dc < C ? fin.dot(dc, part, 8) : 0.0;
+        d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
         __syncthreads();   // (sh was read by the row-0 lanes above)
-        sh[0][rl][cl] = d;
+        if (part == 0) sh[0][0][threadIdx.x >> 3] = d;
         __syncthreads();
-        if (rl == 0 && c < C) {
-            for (int i = 1; i < 8; ++i) d += sh[0][i][cl];
-            fin(c, s, d);
-        }
+        if (rl == 0 && c < C) fin(c, s, sh[0][0][cl]);
         return;
     }
     if (rl == 0 && c < C) fin(c, s, q);
