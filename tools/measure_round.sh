@@ -10,6 +10,14 @@ cd $root
 python bench.py > $out/bench.json 2> $out/bench.err
 echo "bench done" > $out/progress.txt
 cd /tmp && export TMPDIR=/tmp
+# a heartbeat file: the counter passes print nothing for minutes, and a gpurun call that writes nothing for 7 minutes is taken to be hung
+( while sleep 45; do date >> $out/heartbeat.txt; done ) &
+hb=$!
+trap "kill $hb 2>/dev/null" EXIT
+# Under rocprofv3's counter collection every kernel is serialised, so the engine's second-stream probe (does a kernel on the candidate
+# overlap with one on the caller's stream?) can only fail and would create all four candidates; the first PMC pass of round 4 aborted with
+# HSA_STATUS_ERROR_INVALID_PACKET_FORMAT in that configuration (gpurun_out/measure_r04/fetch.err).  The profiled passes take the first stream.
+export RPE_NO_SIDE_PROBE=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o st -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --precondition-min 2 > $out/bench_under_rocprof.json 2> $out/stats.err
 echo "stats done" >> $out/progress.txt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc -o fetch -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --precondition-min 2 > /dev/null 2> $out/fetch.err
@@ -18,6 +26,7 @@ echo "pmc done" >> $out/progress.txt
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/mfma -o m -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --precondition-min 2 > /dev/null 2> $out/mfma.err
 echo "mfma done" >> $out/progress.txt
 cd $root
+unset RPE_NO_SIDE_PROBE
 python tools/pmc_reduce.py $out/pmc/fetch_counter_collection.csv $out/pmc/write_counter_collection.csv > $out/hbm_traffic_pmc.json
 python tools/mfma_reduce.py $out/mfma/m_counter_collection.csv > $out/mfma_busy_pmc.json
 python tools/timeline.py $out/stats/st_kernel_trace.csv -5 > $out/timeline.txt
