@@ -96,10 +96,19 @@ class GradSync:
                 dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group)
         self._pending = True
 
+    def defer_add(self, carry):
+        """Gradient accumulation across backward() calls (torch semantics: .grad accumulates until zero_grad()): `carry` -- the flat
+        gradient as it stood before this backward, already reduced -- is added to the buffer once this backward's staged reduction has
+        finished (finish()); adding it earlier would race with the collectives in flight."""
+        self._carry = carry if getattr(self, "_carry", None) is None else self._carry + carry
+
     def finish(self):
         if self._pending:
             torch.cuda.current_stream(self.flat.device).wait_stream(self._comm)
             self._pending = False
+        if getattr(self, "_carry", None) is not None:
+            self.flat.add_(self._carry)
+            self._carry = None
         if self._slices is not None and self._seen is not None:
             if (self.world > 1 or self.reduce_single) and self._seen != set(self._slices):
                 raise RuntimeError("GradSync: stages %s were never reduced" % sorted(set(self._slices) - self._seen))

@@ -86,12 +86,15 @@ class _ModelFn(torch.autograd.Function):
             d_outs = [None if d is None else d * sc for d in d_outs]
         arena = model._arena
         carry = arena.grad.clone() if arena.accumulating() else None   # a second backward() without zero_grad(): torch adds
-        if carry is not None and getattr(model, "_grad_sync", None) is not None:
-            raise RuntimeError("gradient accumulation across backward() calls is not supported under the staged data-parallel "
-                               "reduction (GradSync.attach): call optimizer.zero_grad() every step, as the reference loop does")
+        sync = getattr(model, "_grad_sync", None)
         model._backward_impl(list(d_outs))
         if carry is not None:
-            arena.grad.add_(carry)
+            if sync is not None:
+                # staged data-parallel reduction: the slices of THIS backward are still being summed across replicas on the communication
+                # stream; the carried gradients (already reduced by their own backward) are added once that is done -- GradSync.finish()
+                sync.defer_add(carry)
+            else:
+                arena.grad.add_(carry)
         arena._dirty = True
         arena.publish_grads()
         return None, None, None, None, None

@@ -63,7 +63,17 @@ def _worker(rank, world, port, q):
     crit(model(other["img"], None, other["x0bar"]), other["obj"]).backward()
     both = local + model._arena.grad
     err_model = (staged - both).abs().max().item() / scale
-    q.put((rank, ok, err, float((staged - local).abs().max().item() / scale), err_model))
+    # gradient accumulation under the staged reduction (torch semantics: a second backward() without zero_grad() ADDS): two backward passes
+    # on the rank's batch, reduced stage by stage, must leave 2 x the reduced gradient
+    model._grad_sync = sync
+    model._arena.zero_grad()
+    crit(model(b["img"], None, b["x0bar"]), b["obj"]).backward()
+    sync.finish()
+    crit(model(b["img"], None, b["x0bar"]), b["obj"]).backward()      # no zero_grad(): accumulates
+    sync.finish()
+    err_acc = (model._arena.grad - 2 * staged).abs().max().item() / scale
+    model._grad_sync = None
+    q.put((rank, ok, err, float((staged - local).abs().max().item() / scale), max(err_model, err_acc)))
     dist.destroy_process_group()
 
 
