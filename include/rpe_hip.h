@@ -481,6 +481,13 @@ long rpe_resnet50_profile_kernels(rpe_resnet50_t* e, char* buf, long buflen);
 /* short name of the implicit-GEMM kernel instance the last conv / Linear call on this thread launched,
  * e.g. "nt_kernel<bf16,2,128,4,0,3,1>" = <dtype, waves_m, BN, chunks per K-row, mode, ring depth, role> */
 const char* rpe_last_kernel_name(void);
+/* Walk direction of the calling thread's NEXT launches of the direction-aware kernels (the implicit-GEMM kernels and the BatchNorm apply
+ * passes): every XCD owns one contiguous eighth of a launch's row tiles / spans and walks it upwards (mode 0, the default), downwards
+ * (1), or alternately launch by launch starting upwards (2) -- a consumer that walks against its producer's direction reads what the
+ * producer wrote last, i.e. what the 256-MiB Infinity Cache still holds of a larger tensor, first (tools/micro/mall_order.hip).
+ * Results do not depend on it (partial sums are indexed by tile).  The engine sets mode 2 around its training step and restores the
+ * caller's mode; RPE_NO_WALK_ALT=1 keeps it at 0.  No reference counterpart (scheduling only). */
+void rpe_set_walk_direction(int mode);
 /* The same backward in stages, so a data-parallel caller can all-reduce finished gradients while the rest is computed:
  * begin (fc + avgpool) -> blocks(count, join=1) ... until all 16 blocks are done -> end (stem).  After blocks(.., join=1)
  * every gradient of the blocks processed so far is complete in stream order on `stream`. */

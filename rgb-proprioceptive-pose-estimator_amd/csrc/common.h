@@ -138,6 +138,28 @@ __device__ inline double wave_sum_d(double v) {
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- walk direction ("boustrophedon") -----------------------------------------------------------------------------
+// Workgroups are dispatched in blockIdx order and the big kernels hand every XCD one contiguous eighth of the row tiles / spans
+// (blocks b, b + 8, .. share an XCD), so a kernel writes the END of every eighth last.  A consumer that walks its eighths DOWNWARDS
+// reads the bytes the producer wrote last first -- the part of a tensor larger than the 256-MiB Infinity Cache that is still
+// resident there (tools/micro/mall_order.hip: a chain of 411-MB read + write passes 5.7 -> 6.7 TB/s when directions alternate; one
+// that walks upwards like its producer meets nothing but evicted lines).  rev = 0: upwards.  The host side keeps the walk MODE of the
+// calling thread (rpe_set_walk_direction: 0 upwards, 1 downwards, 2 alternate): every launcher of a direction-aware kernel (nt_kernel,
+// tn_kernel, the BatchNorm apply passes) takes the direction of its launch with walk_take(), which in mode 2 flips it for the next one.
+__device__ __forceinline__ int xcd_remap_dir(int bid, int nwg, int rev) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    int i = bid >> 3;
+    if (rev) i = q + (x < r ? 1 : 0) - 1 - i;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+extern thread_local int g_walk_mode, g_walk_next;
+inline int walk_take() {
+    if (g_walk_mode != 2) return g_walk_mode;
+    const int r = g_walk_next;
+    g_walk_next ^= 1;
+    return r;
+}
+
 // name of the kernel (symbol, short form) the last C-ABI call of this thread launched: what rpe_last_kernel_name() returns and
 // the engine's per-symbol profile keys on (defined in igemm.hip)
 extern thread_local char g_last_kernel[96];

@@ -176,6 +176,11 @@ struct rpe_resnet50 {
     int side_concurrent = -1;    // -1 not probed (RPE_NO_SIDE_PROBE / capture), 0 no candidate overlapped, 1 yes
     std::vector<hipStream_t> side_rejects;
     bool capturing = false;              // the caller's stream is being captured into a hipGraph (capture_guard)
+    // Walk direction of the big kernels on the caller's stream (common.h, xcd_remap_dir): alternating launch by launch in the training
+    // step, so that every kernel meets the bytes its producer wrote last -- what is left of a > 256-MB tensor in the Infinity Cache --
+    // first.  walk_next carries the direction across the staged backward's C calls.  RPE_NO_WALK_ALT=1: every kernel walks upwards.
+    bool walk_alt = getenv("RPE_NO_WALK_ALT") == nullptr;
+    int walk_next = 0;
     std::vector<hipEvent_t> sync_pool;
     size_t sync_next = 0;
     double flops[RPE_PROF_NUM] = {0};   // algorithmic FLOPs per pass, per category
@@ -222,6 +227,20 @@ static void prof_hook_split(void* ctx, hipStream_t s) { prof_close((rpe_resnet50
         if (err__) return err__;                                                     \
         if ((e)->profiling) prof_close((e), (hipStream_t)(stream), false);           \
     } while (0)
+
+// walk mode of this thread's launches for the lifetime of the object (WalkScope(e, true): the engine's alternating direction, resumed
+// where the last scope left it; WalkScope(e, false): upwards -- the second stream's launches), the previous mode restored afterwards
+struct WalkScope {
+    rpe_resnet50* e; bool alt; int mode0, next0;
+    WalkScope(rpe_resnet50* e_, bool alt_) : e(e_), alt(alt_ && e_->walk_alt), mode0(rpe::g_walk_mode), next0(rpe::g_walk_next) {
+        rpe::g_walk_mode = alt ? 2 : 0;
+        if (alt) rpe::g_walk_next = e->walk_next;
+    }
+    ~WalkScope() {
+        if (alt) e->walk_next = rpe::g_walk_next;
+        rpe::g_walk_mode = mode0; rpe::g_walk_next = next0;
+    }
+};
 
 static int add_conv(rpe_resnet50* e, const std::string& name, const std::string& bn, int in_h, int in_w, int in_c, int out_c, int k,
                     int stride, int pad) {
@@ -793,6 +812,8 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
     if ((!img_nchw && !frames) || !features || ld_features < e->latent) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_forward: bad img/features");
     TRY(capture_guard(e, stream, "resnet50_forward"));   // first: a refusal (profiling under capture, no second stream yet) must come before any launch is recorded
     e->train_mode = training;
+    if (training) e->walk_next = 0;
+    WalkScope walk(e, training != 0);
     if (training && e->pack_state != 1) TRY(rpe_resnet50_pack_weights(e, stream));
     if (!training && e->pack_state != 2) TRY(fold_for_eval(e, stream));
     if (frames && rs) PROF(e, RPE_PROF_OTHER, stream, rpe_stage_frames_u8_resized(e->dtype, frames, e->x4, e->B, Hs, Ws, rs->Hr, rs->Wr, rs->top, rs->left, e->H, e->W,
@@ -850,7 +871,7 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
             if (!x_ready || !ds_done) return event_error(e);
             HIPTRY(hipEventRecord(x_ready, (hipStream_t)stream));
             HIPTRY(hipStreamWaitEvent(e->side, x_ready, 0));
-            TRY(conv_bn(e, cd, x, nullptr, 0, e->side, true, nullptr, nullptr, fuse_ds));
+            { WalkScope up(e, false); TRY(conv_bn(e, cd, x, nullptr, 0, e->side, true, nullptr, nullptr, fuse_ds)); }
             HIPTRY(hipEventRecord(ds_done, e->side));
             idn = cd.a;
         }
@@ -977,6 +998,7 @@ template <typename F> static int to_side(rpe_resnet50* e, void* stream, F work) 
     if (!ready) return event_error(e);
     HIPTRY(hipEventRecord(ready, (hipStream_t)stream));
     HIPTRY(hipStreamWaitEvent(e->side, ready, 0));
+    WalkScope up(e, false);
     return work(e->side);
 }
 static int wgrad(rpe_resnet50* e, ConvL& c, const void* x, const void* dy, void* stream) {
@@ -1071,6 +1093,7 @@ extern "C" int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_fea
     hipStream_t s = (hipStream_t)stream;
     TRY(capture_guard(e, stream, "resnet50_backward"));
     TRY(ensure_side(e, s));
+    WalkScope walk(e, true);
     e->sync_next = 0;
     if (e->gspan_lo) HIPTRY(hipMemsetAsync(e->gspan_lo, 0, e->gspan_bytes, s));
     // fc
@@ -1102,6 +1125,7 @@ extern "C" int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_fea
 extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int join, void* stream) {
     if (!e || !e->bound || e->bwd_next < -1) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward_blocks: call rpe_resnet50_backward_begin first");
     int bi = e->bwd_next;
+    WalkScope walk(e, true);
     // Gradient buffers.  Every layer owns the buffer its dz / dy lives in (ConvL::dy) and every block the buffer of its
     // output gradient (Block::dz): 8.5 GB more workspace at 256 images than rotating a handful of scratch buffers, but a weight
     // gradient on the side stream then never reads a buffer the main stream writes again, so the main stream waits for the
@@ -1233,6 +1257,7 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
 extern "C" int rpe_resnet50_backward_end(rpe_resnet50_t* e, int use_d_early, void* stream) {
     if (!e || !e->bound || e->bwd_next != -1) return rpe_set_error(RPE_ERR_STATE, "resnet50_backward_end: blocks not finished");
     hipStream_t s = (hipStream_t)stream;
+    WalkScope walk(e, true);
     void *g0 = e->d_pool, *g1 = e->convs[0].dy;
     // stem: g0 = gradient wrt maxpool output
     ConvL& st = e->convs[0];

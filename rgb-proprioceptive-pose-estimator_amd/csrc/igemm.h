@@ -101,6 +101,7 @@ template <typename T> struct NTArgs {
     const T* bn_a;       // BN(+residual)+ReLU output, [M][ldc] (mode 1)
     const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
     int tiles_m, tiles_n;
+    int rev;             // walk every XCD's share of the tiles downwards (common.h, xcd_remap_dir): filled by the launcher (walk_take)
     int role;            // 0 conv forward (training), 1 conv data gradient, 2 Linear, 3 conv forward (inference: bias/addend/ReLU),
                          // 5 1x1 conv forward (training) with BatchNorm + residual + ReLU + mask in the epilogue:
                          // selects the epilogue variant compiled into the kernel and tags its symbol in profiles
@@ -178,8 +179,15 @@ template <typename T> struct TNArgs {
     int ldp, ldq, ldd;
     Gather g;
     int tiles_i, tiles_j, splits;
+    int rev;             // walk every XCD's share of the (split, tile) pairs downwards (common.h): filled by the launcher (walk_take)
     int rows_per_split;  // multiple of the m-step
     long q_elems;        // elements of the tensor behind Q (conv modes: set by the caller; dense: M * ldq, filled by the launcher)
 };
+
+// row-streaming 1x1 conv + BatchNorm + identity + ReLU + mask (stream1x1.hip): the y3-free bottleneck's conv3 in layers 1-2
+bool conv1x1_stream_fwd_ok(int dtype, long M, int N, int K, const void* y_out);
+template <typename T>
+int conv1x1_stream_fwd(const T* x, const T* w, const T* res, T* out, unsigned char* mask, const float* scale, const float* shift, const float* res_scale,
+                       const float* res_shift, long M, int N, int K, hipStream_t s);
 
 }  // namespace rpe

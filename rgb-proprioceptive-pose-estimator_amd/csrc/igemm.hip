@@ -10,6 +10,7 @@ namespace rpe {
 
 thread_local char g_last_kernel[96] = "";
 thread_local ProfHook g_prof_hook = {nullptr, nullptr};
+thread_local int g_walk_mode = 0, g_walk_next = 0;
 
 template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s);
 
@@ -63,3 +64,4 @@ template int launch_nt<f16>(NTArgs<f16>&, int, hipStream_t);
 }  // namespace rpe
 
 extern "C" const char* rpe_last_kernel_name(void) { return rpe::g_last_kernel; }
+extern "C" void rpe_set_walk_direction(int mode) { rpe::g_walk_mode = (mode == 1 || mode == 2) ? mode : 0; rpe::g_walk_next = 0; }

@@ -74,6 +74,20 @@ struct TagNext { static constexpr bool value = false; };
 // a few per cent error in one 8-channel slab of a weight gradient, a few times per hundred launches (tools/repro_check.py).
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
+// One LDS-DMA instruction (64 lanes x 16 B -> 1 KB of LDS at the uniform address `lds_addr`) issued from inline assembly.  tn_kernel uses
+// this form, not __builtin_amdgcn_raw_ptr_buffer_load_lds: the compiler's waitcnt pass tracks the builtin as a write to LDS and, unable to
+// see that ds_read_b64_tr_b16 (an intrinsic: no alias information) reads ANOTHER ring slot, put `s_waitcnt vmcnt(0)` in front of the first
+// transposing read of every K step -- i.e. right behind the request for the next tile: rounds 1-3's ring kept no tile in flight while a
+// wave multiplied, whatever its depth (found in round 4 in the ISA; nt_kernel's plain ds_read_b128 never drew that wait).  The asm form is
+// invisible to that pass; the counted waits (wait_vmcnt) and the barriers of the ring are the synchronisation, as designed.
+// M0 carries the LDS address (one wait state between its write and the DMA: s_nop).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void dma16_asm(const __amdgpu_buffer_rsrc_t rs, unsigned lds_addr, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
 // -----------------------------------------------------------------------------------------------
 // NT kernel.  Tile BM x BN = (64*WAVES_M) x BN, 2*WAVES_M waves of 64 x (BN/2), K-step = KCH 16-byte chunks per row.
 //   <2, 128|64, 4, ., 3>: 128-row tile, 64-B K rows, 3-slot ring  (K < 1024, stem)
@@ -137,7 +151,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
         if (tm_ >= p.tiles_m) break;
         lb_ = tm_ * p.tiles_n + tn_;
     } else {
-        lb_ = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+        lb_ = xcd_remap_dir(blockIdx.x, p.tiles_m * p.tiles_n, p.rev);
         tn_ = lb_ % p.tiles_n; tm_ = lb_ / p.tiles_n;
     }
     const int lb = lb_, tile_n = tn_, tile_m = tm_;
@@ -549,7 +563,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
         // tile 0 must have landed: allow the (pf - 1) newer tiles to stay in flight
         {
             const int newer = (nk < pf ? nk : pf) - 1;
-            if (newer >= 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
+            if (newer >= 3) wait_vmcnt<3 * NI>(); else if (newer == 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
         int st = 0;
@@ -560,7 +574,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
             // tile kt+1 must be complete; tiles kt+2 .. may still be in flight
             int newer = nk - 2 - kt;               // tiles issued after kt+1
             if (newer > pf - 1) newer = pf - 1;
-            if (newer >= 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
+            if (newer >= 3) wait_vmcnt<3 * NI>(); else if (newer == 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             if (++st == NSTAGE) st = 0;
         };
@@ -838,14 +852,14 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
     constexpr int PT = BMK * CPI, QT = BMK * CPJ;      // tile sizes in 16-byte units
     constexpr int STAGE = PT + QT;
     constexpr int NSTAGE = DMA ? NSLOT : 2;            // DMA: ring of NSLOT slots, NSLOT-1 tiles in flight while one is multiplied
-    static_assert(NSLOT >= 2 && NSLOT <= 3, "ring depth 2..3");
+    static_assert(NSLOT >= 2 && NSLOT <= 4, "ring depth 2..4");
     static_assert(BMK % RPI == 0 && BMK % RPJ == 0, "tile rows must split evenly over the passes");
     __shared__ u32x4 lds[NSTAGE * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_i = wave >> 1, wave_j = wave & 1;
     const int nt = p.tiles_i * p.tiles_j;
-    const int lb = xcd_remap(blockIdx.x, nt * p.splits);
+    const int lb = xcd_remap_dir(blockIdx.x, nt * p.splits, p.rev);
     const int split = lb / nt, t2 = lb - split * nt;
     const int tile_j = t2 % p.tiles_j, tile_i = t2 / p.tiles_j;
     const int i0 = tile_i * BI, j0 = tile_j * BJ;
@@ -952,10 +966,10 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
     }
     const unsigned p_step = (unsigned)(BMK * p_ld * ES), q_step = (unsigned)(BMK * p.ldq * ES);
     auto dma_tile = [&](int st) {
-        lds_char* base = (lds_char*)lds + st * (STAGE * 16);
+        const unsigned lds_u = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)((lds_char*)lds + st * (STAGE * 16)));
 #pragma unroll
         for (int i = 0; i < NPI; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_p, (lds_void*)(base + (i * 4 + wave_u) * 1024), 16, (int)p_voff[i], 0, 0, 0);
+            dma16_asm(rs_p, lds_u + (unsigned)((i * 4 + wave_u) * 1024), p_voff[i]);
             if (p_voff[i] < OOB) p_voff[i] += p_step;   // (the compare keeps the out-of-range marker where it is)
         }
 #pragma unroll
@@ -977,7 +991,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
                 q_oh[i] -= ch ? (unsigned)g.Ho : 0u;
                 q_b[i] += adv_b + (ch ? 1u : 0u);
             }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_void*)(base + PT * 16 + (i * 4 + wave_u) * 1024), 16, (int)vo, 0, 0, 0);
+            dma16_asm(rs_q, lds_u + (unsigned)(PT * 16 + (i * 4 + wave_u) * 1024), vo);
         }
     };
     u32x4 rp[NPI], rq[NPJ];
@@ -1097,7 +1111,7 @@ __global__ __launch_bounds__(256) void tn_kernel(const TNArgs<T> p) {
         // has passed, with its ds_reads retired by the lgkmcnt(0) of wait_vmcnt (WAR, see there).
         constexpr int NI = NPI + NPJ, PF = NSTAGE - 1;
         auto wait_newer = [&](int newer) {
-            if (newer >= 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
+            if (newer >= 3) wait_vmcnt<3 * NI>(); else if (newer == 2) wait_vmcnt<2 * NI>(); else if (newer == 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();
         };
 #pragma unroll
         for (int t = 0; t < PF; ++t)
@@ -1305,6 +1319,7 @@ template <typename T, int WAVES_M, int BN, int KCH, int MODE, int NST = 3> stati
 template <typename T, int MODE> int launch_nt_mode(NTArgs<T>& a, hipStream_t s) {
     constexpr int CE = Elem<T>::kChunk;
     const bool wide = a.N > 64;
+    a.rev = walk_take();
     // BN partial sums are always indexed by 128-row tiles (rpe_conv_stats_tiles), whatever the M tile
     if constexpr (MODE == MODE_STEM) {
         return launch_nt_cfg<T, 2, 64, 4, MODE_STEM>(a, s);
@@ -1391,7 +1406,12 @@ template <typename T, int BI, int BJ, int MODE> static void plan_tn_cfg(TNArgs<T
 // 0.23 -> 0.16 ms for the 64 <-> 256 1x1 with half the workgroups).  3- and 4-slot rings of 32-row steps lost 4..35 % everywhere.
 static inline void tn_ring(long M, int& ksub, int& nslot) {
     ksub = 2;
-    nslot = M >= 400000 ? 3 : 2;
+    nslot = M >= 40000 ? 3 : 2;
+    static const char* ov = getenv("RPE_TN_RING");   // experiment: "ksub,nslot[,Mmin]" for every launch with M >= Mmin (default 0)
+    if (ov) {
+        int k = 0, n = 0; long mm = 0;
+        if (sscanf(ov, "%d,%d,%ld", &k, &n, &mm) >= 2 && (k == 1 || k == 2) && (n == 2 || n == 3 || (n == 4 && k == 1)) && M >= mm) { ksub = k; nslot = n; }
+    }
 }
 
 template <typename T, int BI, int BJ, int MODE, int KS, int NS> static int launch_tn_ring(TNArgs<T>& a, hipStream_t s, long nwg) {
@@ -1421,7 +1441,7 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
     const int BMK = (dma ? 4 * ksub : 4) * Elem<T>::kChunk;
     // (the register-staged stem kernel is bound by the latency of its load -> LDS -> barrier steps, not by bytes: 2x / 4x the
     // workgroups measured level, as did reading dy once instead of four times)
-    plan_tn_cfg<T, BI, BJ, MODE>(a, BMK, (dma && nslot == 3) ? 2 : 1);
+    plan_tn_cfg<T, BI, BJ, MODE>(a, BMK, (dma && nslot == 3 && ksub == 2) ? 2 : 1);
     const long nwg = (long)a.tiles_i * a.tiles_j * a.splits;
     const long slab_bytes = nwg * (long)(BI * BJ) * 4;
     if (slab_query) { *slab_query = slab_bytes; return 0; }
@@ -1460,6 +1480,11 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
         RPE_CHECK_LAUNCH();
         return 0;
     } else {
+        if (ksub == 1) {
+            if (nslot == 4) return launch_tn_ring<T, BI, BJ, MODE, 1, 4>(a, s, nwg);
+            if (nslot == 3) return launch_tn_ring<T, BI, BJ, MODE, 1, 3>(a, s, nwg);
+            return launch_tn_ring<T, BI, BJ, MODE, 1, 2>(a, s, nwg);
+        }
         if (nslot == 3) return launch_tn_ring<T, BI, BJ, MODE, 2, 3>(a, s, nwg);
         return launch_tn_ring<T, BI, BJ, MODE, 2, 2>(a, s, nwg);
     }
@@ -1468,6 +1493,7 @@ template <typename T, int BI, int BJ, int MODE> static int launch_tn_cfg(TNArgs<
 
 template <typename T> int launch_tn(TNArgs<T>& a, int mode, hipStream_t s, long* slab_query) {
     constexpr int CE = Elem<T>::kChunk;
+    a.rev = slab_query ? 0 : walk_take();
     if (a.M <= 0 || a.I <= 0 || a.J <= 0) return rpe_set_error(RPE_ERR_SHAPE, "igemm_tn: empty problem");
     if (!slab_query) {
         if ((a.ldp % CE) || (((uintptr_t)a.P) & 15) || (((uintptr_t)a.Q) & 15))

@@ -192,33 +192,58 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
 // [rows >= Ci + 1][Ci] with x^T x in rows [0, Ci) and colsum(x) in row `ones_row` (rpe_gram); W is the compute-dtype copy the conv
 // multiplies with.  One block per output channel; the quadratic form is centred (S - s1 s1^T / M) and summed in double, the
 // threads' partial sums meet in a fixed order.
-template <typename T>
-__global__ __launch_bounds__(256) void bn_gram_stats_kernel(const T* __restrict__ w, int Ci, const float* __restrict__ gram, int ones_row, const BnFwdFin fin) {
-    __shared__ float ws[1024], s1s[1024];
-    __shared__ double red[2][4];
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void bn_gram_stats_kernel(const T* __restrict__ w, int Ci, const float* __restrict__ gram, int ones_row, int vec, const BnFwdFin fin) {
+    __shared__ __attribute__((aligned(16))) float ws[1024];
+    __shared__ __attribute__((aligned(16))) float s1s[1024];
+    __shared__ double red[2][NT / 64];
     const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* s1 = gram + (long)ones_row * Ci;
-    for (int i = threadIdx.x; i < Ci; i += 256) { ws[i] = Elem<T>::to_f(w[(long)c * Ci + i]); s1s[i] = s1[i]; }
+    for (int i = threadIdx.x; i < Ci; i += NT) { ws[i] = Elem<T>::to_f(w[(long)c * Ci + i]); s1s[i] = s1[i]; }
     __syncthreads();
     const double inv_count = 1.0 / fin.count;
     double m = 0.0;
-    for (int i = threadIdx.x; i < Ci; i += 256) m += (double)ws[i] * (double)s1s[i];
-    // element idx = i * Ci + j of S: consecutive threads read consecutive floats, 8 loads in flight per thread (the block sits on the
-    // forward's critical path once per y3-free block: the one-row-per-wave walk of round 2 took 23 us for 128 x 128)
+    for (int i = threadIdx.x; i < Ci; i += NT) m += (double)ws[i] * (double)s1s[i];
+    // The block sits on the forward's critical path once per y3-free block and is pure load latency (S comes from another XCD's L2 or
+    // from memory): the one-row-per-wave walk of round 2 took 23 us for 128 x 128, 256 threads with 8 scalar loads in flight 9 us
+    // (64 x 64) / 24 us (128 x 128: eight dependent rounds).  Now 1024 threads with four 16-byte loads each: 128 x 128 is ONE round.
     const int n = Ci * Ci;
     const int ci_shift = (Ci & (Ci - 1)) == 0 ? __builtin_ctz(Ci) : -1;
     double q0 = 0.0, q1 = 0.0;
-    for (int base = threadIdx.x; base < n; base += 256 * 8) {
-        float sv[8];
+    if (vec) {   // Ci % 4 == 0, gram 16-byte aligned: element idx = i * Ci + j, four consecutive j per load
+        const int n4 = n >> 2;
+        for (int base = threadIdx.x; base < n4; base += NT * 4) {
+            f32x4 sv[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int idx = base + u * 256; sv[u] = idx < n ? gram[idx] : 0.f; }
+            for (int u = 0; u < 4; ++u) { const int f = base + u * NT; sv[u] = f < n4 ? *(const f32x4*)(gram + (long)f * 4) : f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * 256;
-            if (idx < n) {
-                const int i = ci_shift >= 0 ? idx >> ci_shift : idx / Ci, j = idx - i * Ci;
-                const double t = (double)ws[i] * (double)ws[j] * ((double)sv[u] - (double)s1s[i] * (double)s1s[j] * inv_count);
-                if (u & 1) q1 += t; else q0 += t;
+            for (int u = 0; u < 4; ++u) {
+                const int f = base + u * NT;
+                if (f < n4) {
+                    const int idx = f * 4;
+                    const int i = ci_shift >= 0 ? idx >> ci_shift : idx / Ci, j = idx - i * Ci;
+                    const double si = (double)s1s[i] * inv_count;
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t += (double)ws[j + k] * ((double)sv[u][k] - si * (double)s1s[j + k]);
+                    t *= (double)ws[i];
+                    if (u & 1) q1 += t; else q0 += t;
+                }
+            }
+        }
+    } else {
+        for (int base = threadIdx.x; base < n; base += NT * 8) {
+            float sv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int idx = base + u * NT; sv[u] = idx < n ? gram[idx] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * NT;
+                if (idx < n) {
+                    const int i = ci_shift >= 0 ? idx >> ci_shift : idx / Ci, j = idx - i * Ci;
+                    const double t = (double)ws[i] * (double)ws[j] * ((double)sv[u] - (double)s1s[i] * (double)s1s[j] * inv_count);
+                    if (u & 1) q1 += t; else q0 += t;
+                }
             }
         }
     }
@@ -228,7 +253,8 @@ __global__ __launch_bounds__(256) void bn_gram_stats_kernel(const T* __restrict_
     if (lane == 0) { red[0][wave] = m; red[1][wave] = q; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double sm = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), sq = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        double sm = 0.0, sq = 0.0;
+        for (int i = 0; i < NT / 64; ++i) { sm += red[0][i]; sq += red[1][i]; }   // wave order
         // fin expects (sum y, sum y^2): sum y^2 = centred form + (sum y)^2 / M
         fin(c, sm, sq + sm * sm * inv_count);
     }
@@ -266,12 +292,14 @@ template <typename T, int UNR, bool NT, bool RESBN = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ out,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
                                                       long nchunks, int C, int relu, unsigned char* __restrict__ mask,
-                                                      const float* __restrict__ res_scale, const float* __restrict__ res_shift) {
+                                                      const float* __restrict__ res_scale, const float* __restrict__ res_shift, int rev) {
     constexpr int CE = Elem<T>::kChunk;
     const int cpr = C / CE;
     const int sub = cpr > 256 ? cpr / 256 : 1;
     const long ustride = 256L * sub, span = ustride * UNR;
-    for (long base = (long)blockIdx.x * span; base < nchunks; base += (long)gridDim.x * span)
+    // every XCD walks one contiguous eighth of the spans, upwards or (rev) downwards: the order of the conv kernels' row tiles (common.h)
+    const int bx = xcd_remap_dir(blockIdx.x, gridDim.x, rev);
+    for (long base = (long)bx * span; base < nchunks; base += (long)gridDim.x * span)
     for (int s = 0; s < sub; ++s) {
     const long i = base + s * 256 + threadIdx.x;
     const int c0 = (int)(i % cpr) * CE;
@@ -395,13 +423,14 @@ template <typename T, int UNR, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_dz_kernel(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                              const float* __restrict__ c1, const float* __restrict__ c2, T* __restrict__ dy,
-                                                             long nchunks, int C) {
+                                                             long nchunks, int C, int rev) {
     constexpr int CE = Elem<T>::kChunk;
     const int cpr = C / CE;
     // contiguous span per block, one pass per thread (see bn_apply_kernel)
     const int sub = cpr > 256 ? cpr / 256 : 1;
     const long ustride = 256L * sub, span = ustride * UNR;
-    for (long base = (long)blockIdx.x * span; base < nchunks; base += (long)gridDim.x * span)
+    const int bx = xcd_remap_dir(blockIdx.x, gridDim.x, rev);
+    for (long base = (long)bx * span; base < nchunks; base += (long)gridDim.x * span)
     for (int s = 0; s < sub; ++s) {
     const long i = base + s * 256 + threadIdx.x;
     const int c0 = (int)(i % cpr) * CE;
@@ -507,14 +536,15 @@ struct StemAuxFwd {
 template <typename T, bool AUX>
 __global__ __launch_bounds__(256) void bn_apply_maxpool_kernel(const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
                                                               T* __restrict__ a, T* __restrict__ out, unsigned char* __restrict__ idx,
-                                                              int B, int H, int W, int C, int Ho, int Wo, const StemAuxFwd aux) {
+                                                              int B, int H, int W, int C, int Ho, int Wo, const StemAuxFwd aux, int rev) {
     constexpr int CE = Elem<T>::kChunk;
     const int cpr = C / CE;
     const long total = (long)B * Ho * Wo * cpr;
     const long span = (long)gridDim.x * blockDim.x;
+    const int bx = xcd_remap_dir(blockIdx.x, gridDim.x, rev);   // (the conv that wrote y dealt its row tiles to the XCDs the same way: common.h)
     // (AUX: every thread of a pooled pixel's group takes part in the shuffles, so the loop bound is rounded up to whole groups -- total is a
     // multiple of cpr, and cpr divides the wave: a group is either all in or all out)
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += span) {
+    for (long i = (long)bx * blockDim.x + threadIdx.x; i < total; i += span) {
         const int cc = (int)(i % cpr);
         long pix = i / cpr;
         const int ow = (int)(pix % Wo); pix /= Wo;
@@ -1038,7 +1068,7 @@ int bn_apply_launch(const void* y, const void* res, void* out, const float* scal
     if (!ew_pow2(cpr)) cfg.unr = 1;
     const long g = ew_grid_rows(n, cpr, cfg);
     if (mask && sizeof(T) != 2) return rpe_set_error(RPE_ERR_DTYPE, "bn_apply_mask: the packed ReLU mask is written for 16-bit element types only");
-#define RPE_BN_APPLY(U, N, R) hipLaunchKernelGGL((bn_apply_kernel<T, U, N, R>), dim3((unsigned)g), dim3(256), 0, s, (const T*)y, (const T*)res, (T*)out, scale, shift, n, C, relu, mask, res_scale, res_shift)
+#define RPE_BN_APPLY(U, N, R) hipLaunchKernelGGL((bn_apply_kernel<T, U, N, R>), dim3((unsigned)g), dim3(256), 0, s, (const T*)y, (const T*)res, (T*)out, scale, shift, n, C, relu, mask, res_scale, res_shift, walk_take())
     if (res_scale) {   // the residual under its own BatchNorm (rpe_bn_apply_res_bn): one configuration
         if (!res || !res_shift) return rpe_set_error(RPE_ERR_SHAPE, "bn_apply: the residual and its shift are required with res_scale");
         if (cfg.unr == 1) { if (cfg.nt) RPE_BN_APPLY(1, true, true); else RPE_BN_APPLY(1, false, true); }
@@ -1060,7 +1090,7 @@ static int bn_apply_dz_launch(const void* dz, const void* y, const float* mean, 
     EwCfg cfg = ew_cfg();
     if (!ew_pow2(cpr)) cfg.unr = 1;   // (see bn_apply_launch)
     const long g = ew_grid_rows(n, cpr, cfg);
-#define RPE_BN_DZ(U, N) hipLaunchKernelGGL((bn_bwd_apply_dz_kernel<T, U, N>), dim3((unsigned)g), dim3(256), 0, s, (const T*)dz, (const T*)y, mean, invstd, gamma, c1, c2, (T*)dy, n, C)
+#define RPE_BN_DZ(U, N) hipLaunchKernelGGL((bn_bwd_apply_dz_kernel<T, U, N>), dim3((unsigned)g), dim3(256), 0, s, (const T*)dz, (const T*)y, mean, invstd, gamma, c1, c2, (T*)dy, n, C, walk_take())
     if (cfg.nt) { if (cfg.unr == 1) RPE_BN_DZ(1, true); else if (cfg.unr == 2) RPE_BN_DZ(2, true); else RPE_BN_DZ(4, true); }
     else { if (cfg.unr == 1) RPE_BN_DZ(1, false); else if (cfg.unr == 2) RPE_BN_DZ(2, false); else RPE_BN_DZ(4, false); }
 #undef RPE_BN_DZ
@@ -1172,9 +1202,10 @@ int rpe_bn_stats_from_gram(int dtype, const void* w, int Co, int Ci, const float
     if (!w || !gram || Co <= 0 || Ci <= 0 || Ci > 1024 || count <= 0 || ones_row < Ci) return rpe_set_error(RPE_ERR_SHAPE, "bn_stats_from_gram: bad arguments (in_c <= 1024)");
     const BnFwdFin fin{(double)count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, scale, shift, save_mean, save_invstd};
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == RPE_F32) hipLaunchKernelGGL((bn_gram_stats_kernel<float>), dim3(Co), dim3(256), 0, s, (const float*)w, Ci, gram, ones_row, fin);
-    else if (dtype == RPE_BF16) hipLaunchKernelGGL((bn_gram_stats_kernel<bf16>), dim3(Co), dim3(256), 0, s, (const bf16*)w, Ci, gram, ones_row, fin);
-    else if (dtype == RPE_F16) hipLaunchKernelGGL((bn_gram_stats_kernel<f16>), dim3(Co), dim3(256), 0, s, (const f16*)w, Ci, gram, ones_row, fin);
+    const int vec = (Ci & 3) == 0 && ((uintptr_t)gram & 15) == 0;
+    if (dtype == RPE_F32) hipLaunchKernelGGL((bn_gram_stats_kernel<float, 1024>), dim3(Co), dim3(1024), 0, s, (const float*)w, Ci, gram, ones_row, vec, fin);
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((bn_gram_stats_kernel<bf16, 1024>), dim3(Co), dim3(1024), 0, s, (const bf16*)w, Ci, gram, ones_row, vec, fin);
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((bn_gram_stats_kernel<f16, 1024>), dim3(Co), dim3(1024), 0, s, (const f16*)w, Ci, gram, ones_row, vec, fin);
     else return rpe_set_error(RPE_ERR_DTYPE, "bn_stats_from_gram: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;
@@ -1303,9 +1334,9 @@ int rpe_bn_apply_maxpool3x3s2(int dtype, const void* y, const float* scale, cons
     const long n = (long)B * Ho * Wo * C;
     hipStream_t s = (hipStream_t)stream;
     const StemAuxFwd none{};
-    if (dtype == RPE_F32) hipLaunchKernelGGL((bn_apply_maxpool_kernel<float, false>), dim3(ew_grid(n / 4)), dim3(256), 0, s, (const float*)y, scale, shift, (float*)a, (float*)out, idx, B, H, W, C, Ho, Wo, none);
-    else if (dtype == RPE_BF16) hipLaunchKernelGGL((bn_apply_maxpool_kernel<bf16, false>), dim3(ew_grid(n / 8)), dim3(256), 0, s, (const bf16*)y, scale, shift, (bf16*)a, (bf16*)out, idx, B, H, W, C, Ho, Wo, none);
-    else if (dtype == RPE_F16) hipLaunchKernelGGL((bn_apply_maxpool_kernel<f16, false>), dim3(ew_grid(n / 8)), dim3(256), 0, s, (const f16*)y, scale, shift, (f16*)a, (f16*)out, idx, B, H, W, C, Ho, Wo, none);
+    if (dtype == RPE_F32) hipLaunchKernelGGL((bn_apply_maxpool_kernel<float, false>), dim3(ew_grid(n / 4)), dim3(256), 0, s, (const float*)y, scale, shift, (float*)a, (float*)out, idx, B, H, W, C, Ho, Wo, none, walk_take());
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((bn_apply_maxpool_kernel<bf16, false>), dim3(ew_grid(n / 8)), dim3(256), 0, s, (const bf16*)y, scale, shift, (bf16*)a, (bf16*)out, idx, B, H, W, C, Ho, Wo, none, walk_take());
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((bn_apply_maxpool_kernel<f16, false>), dim3(ew_grid(n / 8)), dim3(256), 0, s, (const f16*)y, scale, shift, (f16*)a, (f16*)out, idx, B, H, W, C, Ho, Wo, none, walk_take());
     else return rpe_set_error(RPE_ERR_DTYPE, "bn_apply_maxpool: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;
@@ -1322,9 +1353,9 @@ int rpe_bn_apply_maxpool3x3s2_aux(int dtype, const void* y, const float* scale, 
     hipStream_t s = (hipStream_t)stream;
     const StemAuxFwd aux{aux_w, aux_bias, depth_feat, aux_out, ld_aux_out, aux_raw, aux_idx};
     // whole blocks of whole groups: the grid covers every chunk exactly once (no grid-stride tail splits a group)
-    if (dtype == RPE_F32) hipLaunchKernelGGL((bn_apply_maxpool_kernel<float, true>), dim3(ew_grid(n / 4)), dim3(256), 0, s, (const float*)y, scale, shift, (float*)a, (float*)out, idx, B, H, W, C, Ho, Wo, aux);
-    else if (dtype == RPE_BF16) hipLaunchKernelGGL((bn_apply_maxpool_kernel<bf16, true>), dim3(ew_grid(n / 8)), dim3(256), 0, s, (const bf16*)y, scale, shift, (bf16*)a, (bf16*)out, idx, B, H, W, C, Ho, Wo, aux);
-    else if (dtype == RPE_F16) hipLaunchKernelGGL((bn_apply_maxpool_kernel<f16, true>), dim3(ew_grid(n / 8)), dim3(256), 0, s, (const f16*)y, scale, shift, (f16*)a, (f16*)out, idx, B, H, W, C, Ho, Wo, aux);
+    if (dtype == RPE_F32) hipLaunchKernelGGL((bn_apply_maxpool_kernel<float, true>), dim3(ew_grid(n / 4)), dim3(256), 0, s, (const float*)y, scale, shift, (float*)a, (float*)out, idx, B, H, W, C, Ho, Wo, aux, walk_take());
+    else if (dtype == RPE_BF16) hipLaunchKernelGGL((bn_apply_maxpool_kernel<bf16, true>), dim3(ew_grid(n / 8)), dim3(256), 0, s, (const bf16*)y, scale, shift, (bf16*)a, (bf16*)out, idx, B, H, W, C, Ho, Wo, aux, walk_take());
+    else if (dtype == RPE_F16) hipLaunchKernelGGL((bn_apply_maxpool_kernel<f16, true>), dim3(ew_grid(n / 8)), dim3(256), 0, s, (const f16*)y, scale, shift, (f16*)a, (f16*)out, idx, B, H, W, C, Ho, Wo, aux, walk_take());
     else return rpe_set_error(RPE_ERR_DTYPE, "bn_apply_maxpool_aux: unsupported dtype");
     RPE_CHECK_LAUNCH();
     return 0;

@@ -151,6 +151,12 @@ def last_kernel_name():
     return lib.rpe_last_kernel_name().decode()
 
 
+def set_walk_direction(mode):
+    """Walk direction of this thread's next launches of the direction-aware kernels (rpe_set_walk_direction): 0 every XCD walks its
+    share of the row tiles upwards (default), 1 downwards, 2 alternating launch by launch.  Scheduling only: results do not depend on it."""
+    lib.rpe_set_walk_direction(int(mode))
+
+
 def scratch(nbytes, device):
     """Per-device workspace for the deterministic weight-gradient calls (per-workgroup fp32 tiles, summed in a fixed order).
     One buffer that only ever grows: consecutive calls on one stream are ordered, so they can share it -- and its address stays

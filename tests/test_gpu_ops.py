@@ -812,7 +812,7 @@ def test_bn_apply_with_shortcut_bn_on_the_fly(dtype, rows, c):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("cfg", [(8, 28, 64, 256), (4, 14, 128, 512), (6, 14, 256, 1024), (2, 6, 64, 256)])
+@pytest.mark.parametrize("cfg", [(8, 28, 64, 256), (4, 14, 128, 512), (6, 14, 256, 1024), (2, 6, 64, 256), (3, 30, 64, 256), (5, 14, 128, 512), (33, 28, 64, 512)])
 @pytest.mark.parametrize("shortcut", ["identity", "projection", "none"])
 def test_conv1x1_forward_with_bn_from_gram(dtype, cfg, shortcut):
     """conv3 -> bn3 -> (+identity) -> ReLU without writing or re-reading the conv output: BatchNorm statistics from the Gram matrix of
@@ -853,8 +853,18 @@ def test_conv1x1_forward_with_bn_from_gram(dtype, cfg, shortcut):
     assert rel_err(y, y64.float().reshape(b, h, h, co)) < tol(dtype)
     bits = ((mask.cpu()[:, None] >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(rows, co).bool()
     assert torch.equal(bits, out.cpu().float().reshape(rows, co) > 0)
+    # without y the 64 / 128 -> 256 k launches of >= 512 rows take the row-streaming kernel (csrc/stream1x1.hip; ragged spans in the (3, 30, ..)
+    # and (5, 14, ..) cases): bitwise the tiled form, in both walk directions
     out2, mask2, none = ops.conv1x1_fwd_bn(xd, wd, scale, shift, None if res is None else res.to(dtype).to(DEV).reshape(b, h, h, co), dev(rs), dev(rb))
     assert none is None and torch.equal(out2, out) and torch.equal(mask2, mask)
+    if rows >= 512 and ci in (64, 128) and co % 256 == 0:
+        assert ops.last_kernel_name().startswith("conv1x1_stream_fwd_kernel")
+    ops.set_walk_direction(1)
+    try:
+        out3, mask3, _ = ops.conv1x1_fwd_bn(xd, wd, scale, shift, None if res is None else res.to(dtype).to(DEV).reshape(b, h, h, co), dev(rs), dev(rb))
+    finally:
+        ops.set_walk_direction(0)
+    assert torch.equal(out3, out) and torch.equal(mask3, mask)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -1,5 +1,6 @@
 """Diagnostic: timeline of ONE train step from a rocprofv3 --kernel-trace csv: per-queue busy time, overlap, gaps, and the
-main-stream critical path by kernel symbol.  usage: python tools/timeline.py <kernel_trace.csv> [step_index]"""
+main-stream critical path by kernel symbol.  usage: python tools/timeline.py <kernel_trace.csv> [step_index] [--list]
+(--list: every launch of the step in start order: start ms, queue M/S, duration us, gap to the previous launch on its queue, grid, symbol)"""
 import csv
 import sys
 import os
@@ -9,8 +10,12 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_reduce import symbol
 
 csv.field_size_limit(1 << 30)
+LIST = "--list" in sys.argv
+if LIST:
+    sys.argv.remove("--list")
 rows = list(csv.DictReader(open(sys.argv[1])))
-ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), symbol(r["Kernel_Name"]), r["Queue_Id"]) for r in rows)
+ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), symbol(r["Kernel_Name"]), r["Queue_Id"],
+             "%sx%s" % (int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) // max(1, int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1)) or 1)), r.get("Grid_Size_Y", "1"))) for r in rows)
 adam = [i for i, k in enumerate(ks) if k[2] == "adam_kernel"]
 step = int(sys.argv[2]) if len(sys.argv) > 2 else -5   # a timed step: negative = counted from the end (bench.py ends with 3 event-bracketed steps; pre-conditioning and warm-up steps come first)
 if step < 0:
@@ -50,10 +55,11 @@ if len(qs) > 1:
     main, side = byq[qs[0]], byq[qs[1]]
     ub = union([(k[0], k[1]) for k in main]) + union([(k[0], k[1]) for k in side]) - union([(k[0], k[1]) for k in main + side])
     print("  main/side overlapped time %.3f ms" % (ub / 1e6))
-    # phase split: forward = before the first side-queue kernel
-    s0 = min(k[0] for k in side)
+    # phase split: the forward ends with the loss kernel (the second queue also carries the projection shortcuts of the forward)
+    loss = [k for k in main if k[2] == "pose_loss_kernel"]
+    s0 = loss[0][1] if loss else min(k[0] for k in side)
     s1 = max(k[1] for k in side)
-    print("  forward (start -> first side kernel) %.3f ms; backward span %.3f ms; tail after last side kernel %.3f ms" %
+    print("  forward (start -> loss kernel) %.3f ms; backward up to the last side kernel %.3f ms; tail after it %.3f ms" %
           ((s0 - t0) / 1e6, (s1 - s0) / 1e6, (t1 - s1) / 1e6))
     # main-queue kernels during the backward span, by symbol
     agg = defaultdict(lambda: [0, 0.0])
@@ -63,10 +69,10 @@ if len(qs) > 1:
         a[0] += 1
         a[1] += (k[1] - k[0]) / 1e6
     for k in side:
-        a = agg[("side", k[2])]
+        a = agg[("side-fwd" if k[1] <= s0 else "side", k[2])]
         a[0] += 1
         a[1] += (k[1] - k[0]) / 1e6
-    for ph in ("fwd", "bwd", "side"):
+    for ph in ("fwd", "side-fwd", "bwd", "side"):
         tot = sum(v[1] for kk, v in agg.items() if kk[0] == ph)
         print("  -- %s: %.3f ms of kernel time" % (ph, tot))
         for kk, v in sorted(agg.items(), key=lambda x: -x[1][1]):
@@ -78,3 +84,10 @@ if len(qs) > 1:
     pos = [g for g in gaps if g > 0]
     print("  main-queue gaps: %d, total %.3f ms, median %.2f us, >20us: %d" %
           (len(pos), sum(pos) / 1e3, sorted(pos)[len(pos) // 2] if pos else 0, sum(1 for g in pos if g > 20)))
+if LIST:
+    last = {}
+    mq = qs[0]
+    for k in seg:
+        g = (k[0] - last[k[3]]) / 1e3 if k[3] in last else 0.0
+        last[k[3]] = k[1]
+        print("%8.3f %s %8.1f us  gap %6.1f  %-10s %s" % ((k[0] - t0) / 1e6, "M" if k[3] == mq else "S", (k[1] - k[0]) / 1e3, g, k[4], k[2]))
