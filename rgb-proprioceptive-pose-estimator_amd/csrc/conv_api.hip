@@ -513,7 +513,7 @@ template <typename T>
 static int conv1x1_fwd_bn_t(const rpe_conv_desc* d, const void* x, const void* w, void* out, void* y_out, const float* scale, const float* shift,
                             const void* residual, const float* res_scale, const float* res_shift, unsigned char* mask, hipStream_t s) {
     const long M_ = (long)d->batch * d->in_h * d->in_w;
-    if (conv1x1_stream_fwd_ok(Elem<T>::kDtype, M_, d->out_c, d->in_c, y_out))   // layers 1-2: the row-streaming form (stream1x1.hip), bitwise the tiled one
+    if (residual && mask && conv1x1_stream_fwd_ok(Elem<T>::kDtype, M_, d->out_c, d->in_c, y_out))   // layers 1-2: the row-streaming form (stream1x1.hip), bitwise the tiled one
         return conv1x1_stream_fwd<T>((const T*)x, (const T*)w, (const T*)residual, (T*)out, mask, scale, shift, res_scale, res_shift, M_, d->out_c, d->in_c, s);
     NTArgs<T> a;
     memset(&a, 0, sizeof(a));

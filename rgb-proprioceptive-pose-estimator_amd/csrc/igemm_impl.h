@@ -598,24 +598,46 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
     float* stg = (float*)lds + wave * (16 * LDW);  // 16 staged rows (one 16-row fragment) per wave at a time
     float cs[8], cq[8], cmean[8], cinv[8], csc[8], csh[8], cbias[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        cs[j] = 0.f; cq[j] = 0.f; cmean[j] = 0.f; cinv[j] = 0.f; csc[j] = 0.f; csh[j] = 0.f; cbias[j] = 0.f;
-        if (n + j < p.N) {
-            if (e_bias) cbias[j] = e_bias[n + j];
-            if (bn_mode && bn_mode != 5) { cinv[j] = p.bn_invstd[n + j]; cmean[j] = -p.bn_mean[n + j] * cinv[j]; }   // xhat = y*inv + (-mean*inv): one fma
-            if (bn_mode == 2) { csc[j] = p.bn_scale[n + j]; csh[j] = p.bn_shift[n + j]; }
+    for (int j = 0; j < 8; ++j) { cs[j] = 0.f; cq[j] = 0.f; cmean[j] = 0.f; cinv[j] = 0.f; csc[j] = 0.f; csh[j] = 0.f; cbias[j] = 0.f; }
+    // Per-column coefficients.  Conv roles (whole 8-channel chunks: ncol_ok covers all eight) read them under ONE uniform test per
+    // array, so that all loads are requested before the first is used: with the test per element (rounds 1-3) every element was a
+    // basic block of its own and the compiler put `s_waitcnt vmcnt(0)` behind each -- eight dependent round trips (~5 us) between the
+    // K loop and the epilogue of every tile, found in the ISA in round 4.
+    if (VEC_ONLY ? ncol_ok : true) {
+        float tm[8];
+        if (e_bias) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (VEC_ONLY || n + j < p.N) cbias[j] = e_bias[n + j];
+        }
+        if (bn_mode && bn_mode != 5) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { tm[j] = 0.f; if (VEC_ONLY || n + j < p.N) { cinv[j] = p.bn_invstd[n + j]; tm[j] = p.bn_mean[n + j]; } }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cmean[j] = -tm[j] * cinv[j];   // xhat = y*inv + (-mean*inv): one fma
+        }
+        if (bn_mode == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (VEC_ONLY || n + j < p.N) { csc[j] = p.bn_scale[n + j]; csh[j] = p.bn_shift[n + j]; }
         }
     }
     float fsc[8], fsh[8], frs[8];   // role 5: BN scale / shift of this layer (the shift carries the residual's shift) and the residual's scale
     if constexpr (FWD_BN) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            fsc[j] = 0.f; fsh[j] = 0.f; frs[j] = 1.f;
-            if (n + j < p.N) {
-                fsc[j] = p.fwd_scale[n + j];
-                fsh[j] = p.fwd_shift[n + j] + (p.res_shift ? p.res_shift[n + j] : 0.f);
-                if (p.res_scale) frs[j] = p.res_scale[n + j];
+        for (int j = 0; j < 8; ++j) { fsc[j] = 0.f; fsh[j] = 0.f; frs[j] = 1.f; }
+        if (ncol_ok) {   // (role 5 moves whole chunks)
+            float t0[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { fsc[j] = p.fwd_scale[n + j]; fsh[j] = p.fwd_shift[n + j]; t0[j] = 0.f; }
+            if (p.res_shift) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t0[j] = p.res_shift[n + j];
             }
+            if (p.res_scale) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) frs[j] = p.res_scale[n + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fsh[j] += t0[j];
         }
     }
     auto load8 = [&](const T* base, long off, bool vec, float* out) {
@@ -665,7 +687,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
                     if (p.y_out) *(u32x4*)(p.y_out + m * p.ldc + n) = f_to_chunk<T>(v);   // (16-bit element types only: CE == 8)
                     float ad[8];
                     if (e_addend) {
-                        if (PIPE && vec_add) chunk_to_f<T>(qd[sl], ad);
+                        if constexpr (PIPE) chunk_to_f<T>(qd[sl], ad);   // (PIPE roles move whole chunks: inside this guard vec_add holds)
                         else load8(e_addend, m * p.ld_add + n, vec_add, ad);
                     }
                     unsigned bits = 0;
@@ -680,7 +702,10 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
                 } else
                 if (e_addend) {
                     float ad[8];
-                    if (PIPE && vec_add) chunk_to_f<T>(qd[sl], ad);
+                    // (PIPE roles move whole chunks: inside the m / ncol_ok guard vec_add and vec_c hold, so the prefetched registers are THE
+                    // operands.  With the run-time fallback `else load8(..)` compiled beside them the wait in front of the first use had to cover a
+                    // load that might just have been issued: vmcnt(0) in every step, which drained the whole prefetch -- round 4, from the ISA.)
+                    if constexpr (PIPE) chunk_to_f<T>(qd[sl], ad);
                     else load8(e_addend, m * p.ld_add + n, vec_add, ad);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += ad[j];
@@ -689,7 +714,7 @@ __global__ __launch_bounds__(128 * WAVES_M, 2) void nt_kernel(const NTArgs<T> p)
                     // v = dA (gradient wrt the BN output after ReLU).  dz = dA * [a_out > 0]; partial sums of dz and dz*xhat.
                     float yy[8], aa[8];
                     unsigned mbits = 0;
-                    if (PIPE && vec_c) {
+                    if constexpr (PIPE) {
                         if (bn_mode != 5) chunk_to_f<T>(qy[sl], yy);
                         if (bn_mode == 1) chunk_to_f<T>(qa[sl], aa);
                         if (bn_mode == 4 || bn_mode == 5) mbits = qa[sl].x;
