@@ -110,7 +110,9 @@ int rpe_conv2d_dgrad_bn(const rpe_conv_desc* d, int dtype, const void* dy, const
  * weight-gradient-style launch, fixed-order slab sum).  rpe_bn_stats_from_gram: what rpe_bn_finalize produces (scale, shift, saved
  * mean / invstd, running statistics), from the Gram matrix and the compute-dtype weight.  rpe_conv1x1_fwd_bn: the conv with
  * out = relu(acc * scale + shift + residual [* res_scale + res_shift]) and the packed ReLU mask in its epilogue -- the raw output
- * is written only when y_out is given. */
+ * is written only when y_out is given.  Without y_out, with a residual and a mask, in_c 64 / 128, out_c a multiple of 256 and >= 512 rows
+ * (the y3-free blocks of layers 1-2) the launch is the row-streaming kernel of csrc/stream1x1.hip (weights resident in registers, a per-wave
+ * LDS-DMA ring), bitwise the tiled form; RPE_NO_STREAM1X1=1 keeps the tiled form. */
 /* rpe_bn_apply_gram: out = relu(y * scale + shift) (bn2's apply pass) AND the Gram buffer of `out` -- same layout and values as rpe_gram(out)
  * -- in one pass over y (C = 64 or 128, 16-bit element types; workspace = per-workgroup fp32 partials, summed in a fixed order). */
 long rpe_bn_apply_gram_workspace_bytes(int dtype, long rows, int C);

@@ -1424,11 +1424,12 @@ template <typename T, int BI, int BJ, int MODE> static void plan_tn_cfg(TNArgs<T
     a.splits = (int)((a.M + rps - 1) / rps);
 }
 
-// Ring configuration of the DMA path.  Measured per shape at 256 images (tools/sweep_tn.sh, isolated launches): the 2-slot
-// ring with 64-row steps at 2 workgroups per CU wins wherever the operands are re-read through L2 (the per-CU LDS fill rate,
-// not HBM latency, bounds those launches: 128x128x64 steps fetch 32 KB per 2.1 MFLOP), a 3-slot ring (96 KB, one workgroup per
-// CU, two tiles in flight) wins on the long, HBM-streaming reductions of layer1 (M = 802816 rows: 0.33 -> 0.18 ms for the 3x3,
-// 0.23 -> 0.16 ms for the 64 <-> 256 1x1 with half the workgroups).  3- and 4-slot rings of 32-row steps lost 4..35 % everywhere.
+// Ring configuration of the DMA path.  Rounds 2-3 measured the 2-slot ring fastest wherever operands are re-read through L2 and blamed the
+// LDS fill rate; round 4 found the cause in the ISA -- the compiler drained every request in front of the first transposing read
+// (dma16_asm above), so no ring depth had kept a tile in flight.  With the DMA in assembly (bench.py on one box, profiles/r04_ab_tn_asm_dma.txt):
+// three 64-row slots (96 KB at 128 x 128: one workgroup per CU, two tiles in flight) win wherever the reduction is long -- M >= 40 000 rows,
+// layers 1-3 at 256 images: 18.52 -> 18.31 ms/step -- and two slots (two workgroups per CU) where it is short (layer 4, the heads); 32-row
+// steps in 3 or 4 slots lose 0.2-0.3 ms.  RPE_TN_RING="ksub,nslot[,Mmin]" overrides (experiments).
 static inline void tn_ring(long M, int& ksub, int& nslot) {
     ksub = 2;
     nslot = M >= 40000 ? 3 : 2;

@@ -1,18 +1,19 @@
-// Row-streaming form of the y3-free bottleneck's two widest GEMMs (layers 1-2, 16-bit element types): a 1x1 conv whose reduction is
-// only 64 / 128 (256 with the K-concatenated operand) deep but whose output is 4x as wide, with everything that follows it fused.
+// Row-streaming form of the y3-free bottleneck's conv3 forward (layers 1-2, 16-bit element types): a 1x1 conv whose reduction is only 64 /
+// 128 deep but whose output is 4x as wide, with everything that follows it fused (rpe_conv1x1_fwd_bn):
 //
-//   forward  (rpe_conv1x1_fwd_bn):    out = relu((x W^T) * scale + shift + identity [* res_scale + res_shift]), packed ReLU mask
+//     out = relu((x W^T) * scale + shift + identity [* res_scale + res_shift]),  packed ReLU mask
 //
 // On the tiled kernel (nt_kernel role 5, 128 x 128 tiles) such a launch is a 2..4-step K loop in front of an epilogue that moves 96 KB
 // per workgroup: every workgroup pays descriptor set-up, a cold operand ring and the LDS round trip of its accumulators for ~1 us of
-// matrix work, and the launch streams at 3.7-4.5 TB/s where the BatchNorm passes reach 6.  Here the WEIGHTS are the resident operand:
-// a wave owns 64 output channels and keeps their W rows as MFMA fragments in registers for its whole life (32 / 64 VGPRs), a workgroup
-// (4 waves = 256 channels) walks a contiguous span of rows 16 at a time, and the activation rows arrive as 16-byte loads that ARE the
-// second MFMA operand (lane = (row, 8 k)): no LDS, no barrier, nothing per tile.  The fragment -> channel map is permuted so that
-// accumulator register e of fragment c in lane (row = l & 15, g = l >> 4) is channel 16 g + 4 c + e of the wave's 64: a lane ends up
-// with 16 CONSECUTIVE channels of one row -- two 16-byte chunks of the identity in, two of the output out, two mask bytes.
-// The next step's operands are requested before the current one is multiplied.  K steps are accumulated in ascending order by the
-// same instruction as nt_kernel (operands in the same roles), so the results are bitwise those of the tiled form.
+// matrix work (213 / 130 us per launch in layers 1 / 2).  Here the WEIGHTS are the resident operand: a wave owns 64 output channels and
+// keeps their W rows as MFMA fragments in registers for its whole life (32 / 64 VGPRs); a workgroup (4 waves = 256 channels) walks ONE
+// contiguous span of rows 16 at a time; the x rows and the wave's 128-byte slice of the identity rows arrive by LDS-DMA in a ring that
+// belongs to the WAVE (no workgroup barrier anywhere) and are read back as the second MFMA operand / the epilogue's addend.  The
+// fragment -> channel map is permuted so that a lane ends up with two 16-byte chunks of ONE row (channels 8 g .. 8 g + 7 and 32 + 8 g ..):
+// two chunks of identity in, two of output out, and the four lanes of a row merge their mask bytes into one 8-byte store.
+// K steps are accumulated in ascending order by the same instruction with the operands in the same roles as nt_kernel, so the result is
+// bitwise the tiled form's (tests/test_gpu_ops.py::test_conv1x1_forward_with_bn_from_gram, both walk directions).  190 / 120 us per launch.
+// What still bounds a step are the wave's own stores: see the vmcnt note at the kernel.
 // replaces: conv3 -> bn3 -> (+ identity) -> ReLU of a torchvision Bottleneck in training mode (util/model_utils.py:136; called at
 // models/naive.py:316), statistics from the Gram matrix (DESIGN.md, y3-free blocks).
 #include <stdlib.h>

@@ -36,6 +36,9 @@ ENGINE_VARIANTS = [
     # y3-free with dz3^T a2 as the side product of the next block's fused conv1 data gradient (measured slower, off by default);
     # layer3 handled the same way as layers 1-2 where the shapes allow (Gram statistics for planes 256: the unfused Gram launch)
     {"RPE_T_FUSE": "1", "RPE_Y3FREE_MAX": "256"},
+    # the y3-free conv3 forward as the tiled launch instead of the row-streaming kernel; every kernel walking its row tiles upwards;
+    # the weight-gradient ring at two slots of 32 rows everywhere
+    {"RPE_NO_STREAM1X1": "1", "RPE_NO_WALK_ALT": "1", "RPE_TN_RING": "1,2"},
 ]
 
 

@@ -20,6 +20,9 @@ if has pmc; then
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc -o fetch -- python3 $root/bench.py $B > /dev/null 2> $out/fetch.err || echo "fetch pass failed" >> $out/progress.txt
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc -o write -- python3 $root/bench.py $B > /dev/null 2> $out/write.err || echo "write pass failed" >> $out/progress.txt
   (cd $root && python tools/pmc_reduce.py $out/pmc/fetch_counter_collection.csv $out/pmc/write_counter_collection.csv > $out/hbm_traffic_pmc.json) && echo "pmc done" >> $out/progress.txt
+  # the bench phase below looks the dominant kernel's traffic up in profiles/hbm_traffic_pmc.json and withholds it unless that file was measured on
+  # the library it loaded (build id): hand it this box's fresh measurement (the caller copies the same file into profiles/ afterwards)
+  [ -s $out/hbm_traffic_pmc.json ] && cp $out/hbm_traffic_pmc.json $root/profiles/hbm_traffic_pmc.json
   rm -rf $out/pmc
 fi
 if has mfma; then
