@@ -207,6 +207,37 @@ def test_conv_wgrad(dtype, cfg):
     assert rel_err(dwa.permute(0, 3, 1, 2), ref) < tol(dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("cfg", [(8, 28, 64, 64, 3, 1, 1), (6, 14, 256, 128, 1, 1, 0), (5, 30, 64, 128, 3, 2, 1)])
+def test_walk_direction_does_not_change_results(dtype, cfg):
+    """rpe_set_walk_direction is scheduling only: every XCD walks its share of a launch's row tiles / spans upwards (0), downwards (1) or
+    alternately (2), and the conv forward (+ its BN partial sums), data gradient, weight gradient and the BatchNorm apply pass give the
+    same bits either way (partial sums are indexed by tile, not by arrival)."""
+    b, h, ci, co, k, s, p = cfg
+    x, w = _conv_inputs(cfg, dtype)
+    xd, wd = nhwc(x).to(dtype).to(DEV), nhwc(w).to(dtype).to(DEV)
+    ho = (h + 2 * p - k) // s + 1
+    g = torch.Generator().manual_seed(9)
+    dyd = nhwc(q(torch.randn(b, co, ho, ho, generator=g), dtype)).to(dtype).to(DEV)
+    w_crsk = w.permute(1, 2, 3, 0).contiguous().to(dtype).to(DEV)
+    sc, sh = (torch.rand(co, generator=g) + 0.5).to(DEV), (torch.randn(co, generator=g) * 0.3).to(DEV)
+
+    def run():
+        y, st = ops.conv2d_fwd(xd, wd, s, p, want_stats=True)
+        return (y, st, ops.conv2d_dgrad(dyd, w_crsk, (b, h, h, ci), s, p), ops.conv2d_wgrad(xd, dyd, k, s, p), ops.bn_apply(y, sc, sh),
+                ops.bn_apply(y, sc, sh), ops.conv2d_fwd(xd, wd, s, p, want_stats=True)[0])   # (mode 2: consecutive launches differ in direction)
+
+    ref = run()
+    try:
+        for mode in (1, 2):
+            ops.set_walk_direction(mode)
+            got = run()
+            for a, r in zip(got, ref):
+                assert torch.equal(a, r), "walk direction %d changed a result" % mode
+    finally:
+        ops.set_walk_direction(0)
+
+
 def test_conv_wgrad_many_splits_is_deterministic():
     """A long reduction (many M splits per tile, the shape class of the layer1 1x1 weight gradients at bs256): slab mode must
     reproduce itself bitwise and agree with the atomic mode to fp32 summation-order noise."""
