@@ -553,13 +553,17 @@ __global__ __launch_bounds__(256) void bn_apply_maxpool_kernel(const T* __restri
         float sc[CE], sh[CE], aw[CE], ad[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < CE; ++e) { sc[e] = scale[cc * CE + e]; sh[e] = shift[cc * CE + e]; aw[e] = AUX ? aux.w[cc * CE + e] : 0.f; }
+        // all nine taps are requested before the first is used: a tap outside the image reads the clamped pixel instead (its value is
+        // ignored).  With the load under `if (inside)` (rounds 3-4) every tap was a basic block with its own wait -- nine dependent round
+        // trips per thread, 2.7 TB/s (from the ISA, round 4)
         u32x4 raw[9];
         bool ok[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const int ih = oh * 2 - 1 + k / 3, iw = ow * 2 - 1 + k % 3;
             ok[k] = ih >= 0 && ih < H && iw >= 0 && iw < W;
-            if (ok[k]) raw[k] = *(const u32x4*)(y + (((long)b * H + ih) * W + iw) * C + cc * CE);
+            const int ihc = ih < 0 ? 0 : (ih >= H ? H - 1 : ih), iwc = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
+            raw[k] = *(const u32x4*)(y + (((long)b * H + ihc) * W + iwc) * C + cc * CE);
         }
         float best[CE];
         unsigned char bi[CE];
@@ -686,20 +690,32 @@ __device__ __forceinline__ void stem_dz_block(const T* __restrict__ dpool, const
     const bool right = ow + 1 < Wo, below = oh + 1 < Ho;
     float d[4][CE];
     unsigned long long taps[4];
-    auto window = [&](int k, long o, bool ok) {
-        if (ok) {
-            chunk_to_f<T>(*(const u32x4*)(dpool + o), d[k]);
-            taps[k] = CE == 8 ? *(const unsigned long long*)(pidx + o) : (unsigned long long)*(const unsigned*)(pidx + o);
-        } else {
+    // the four windows and the aux head's three scalars are requested together, a window past the edge reads the own window instead (and
+    // is then zeroed): with the loads under `if (inside)` / `if (aux)` each was a basic block with a wait of its own (round 4, from the ISA)
+    const long wo[4] = {o00, right ? o00 + 64 : o00, below ? o00 + (long)Wo * 64 : o00, (right && below) ? o00 + (long)Wo * 64 + 64 : o00};
+    const bool wok[4] = {true, right, below, right && below};
+    u32x4 wraw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        wraw[k] = *(const u32x4*)(dpool + wo[k]);
+        taps[k] = CE == 8 ? *(const unsigned long long*)(pidx + wo[k]) : (unsigned long long)*(const unsigned*)(pidx + wo[k]);
+    }
+    const long apos = (long)oh * Wo + ow, aflat = (long)b * Ho * Wo + apos;   // (the aux head pools the same 2 x 2 blocks: Ho = H / 2)
+    // (no aux head / no depth feature: the reads go to the pooled gradient and its winner bytes, always there, and are ignored)
+    const unsigned char* awp = ax.dout ? ax.idx + aflat : pidx;
+    const float* agp = ax.dout ? ax.dout + (long)b * ax.ld + apos : (const float*)dpool;
+    const float* adp = (ax.dout && ax.depth_feat) ? ax.depth_feat + aflat : (const float*)dpool;
+    const int awin = (int)*awp;
+    const float ag = *agp, adf = *adp;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        chunk_to_f<T>(wraw[k], d[k]);
+        if (!wok[k]) {
 #pragma unroll
             for (int e = 0; e < CE; ++e) d[k][e] = 0.f;
             taps[k] = ~0ull;   // (no tap is 255)
         }
-    };
-    window(0, o00, true);
-    window(1, o00 + 64, right);
-    window(2, o00 + (long)Wo * 64, below);
-    window(3, o00 + (long)Wo * 64 + 64, right && below);
+    }
 #pragma unroll
     for (int e = 0; e < CE; ++e) {
         const unsigned t0 = (unsigned)(taps[0] >> (8 * e)) & 0xffu, t1 = (unsigned)(taps[1] >> (8 * e)) & 0xffu;
@@ -710,10 +726,9 @@ __device__ __forceinline__ void stem_dz_block(const T* __restrict__ dpool, const
         dz[3][e] = (t0 == 8u ? d[0][e] : 0.f) + (t1 == 6u ? d[1][e] : 0.f) + (t2 == 2u ? d[2][e] : 0.f) + (t3 == 0u ? d[3][e] : 0.f);
     }
     if (ax.dout) {
-        const long pos = (long)oh * Wo + ow, flat = (long)b * Ho * Wo + pos;   // (the aux head pools the same 2 x 2 blocks: Ho = H / 2)
-        const int win = ax.idx[flat];
-        float g = ax.dout[(long)b * ax.ld + pos];
-        if (ax.depth_feat) g *= ax.depth_feat[flat];
+        const int win = awin;
+        float g = ag;
+        if (ax.depth_feat) g *= adf;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
