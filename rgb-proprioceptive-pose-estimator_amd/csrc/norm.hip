@@ -21,19 +21,27 @@ struct BnFwdFin {
     float momentum, eps;
     float *scale, *shift, *save_mean, *save_invstd;
     __device__ void operator()(int c, double s, double q) const {
+        // every input is read BEFORE the first output is stored (gamma, beta, the running statistics; without running statistics the two
+        // reads go to gamma and are ignored): with load, store, load, store ... (rounds 1-3) each load waited for the store in front of it
+        // as well -- loads and stores share one counter on gfx950 and the compiler can only answer vmcnt(0) -- i.e. four dependent round
+        // trips at the end of every one of the step's ~50 forward finalize launches (round 4, from the ISA)
+        const float g = gamma[c], bt = beta[c];
+        const float* rmp = running_mean ? running_mean : gamma;
+        const float* rvp = running_var ? running_var : gamma;
+        const float rm = rmp[c], rv = rvp[c];
         const double mean = s / count;
         double var = q / count - mean * mean;
         if (var < 0.0) var = 0.0;
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[c] * invstd;
+        const float sc = g * invstd;
         scale[c] = sc;
-        shift[c] = beta[c] - (float)mean * sc;
+        shift[c] = bt - (float)mean * sc;
         save_mean[c] = (float)mean;
         save_invstd[c] = invstd;
         if (running_mean) {
             const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+            running_mean[c] = (1.f - momentum) * rm + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * rv + momentum * (float)unb;
         }
         if (num_batches && c == 0) *num_batches += 1;
     }
@@ -80,7 +88,8 @@ template <typename T> struct BnBwdFinT {
         return r;
     }
     __device__ void operator()(int c, double s, double d) const {
-        const double q = (double)invstd[c] * (d - (double)mean[c] * s);
+        const float is_ = invstd[c], mu_ = mean[c];   // (inputs before the first store: see BnFwdFin)
+        const double q = (double)is_ * (d - (double)mu_ * s);
         if (dbeta) dbeta[c] = (float)s;
         if (dgamma) dgamma[c] = (float)q;
         c1[c] = (float)(s / count);
@@ -155,14 +164,14 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
             // NS <= 64 (reduce_slices): at most 8 slices per thread, all requested before the first is added
             double vs[8], vq[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = rl + 8 * u;
-                vs[u] = 0.0; vq[u] = 0.0;
-                if (i < NS) {
-                    vs[u] = __hip_atomic_load(&dpart[((long)i * 2 + 0) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    vq[u] = __hip_atomic_load(&dpart[((long)i * 2 + 1) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            for (int u = 0; u < 8; ++u) {   // (branch-free requests: a slice index past NS re-reads slice 0 and is zeroed below)
+                const int i = rl + 8 * u, ic = i < NS ? i : 0;
+                vs[u] = __hip_atomic_load(&dpart[((long)ic * 2 + 0) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vq[u] = __hip_atomic_load(&dpart[((long)ic * 2 + 1) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (rl + 8 * u >= NS) { vs[u] = 0.0; vq[u] = 0.0; }
 #pragma unroll
             for (int u = 0; u < 8; ++u) { s += vs[u]; q += vq[u]; }
         }
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(NT) void bn_gram_stats_kernel(const T* __restrict__
         for (int base = threadIdx.x; base < n4; base += NT * 4) {
             f32x4 sv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int f = base + u * NT; sv[u] = f < n4 ? *(const f32x4*)(gram + (long)f * 4) : f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int u = 0; u < 4; ++u) { const int f = base + u * NT; sv[u] = *(const f32x4*)(gram + (long)(f < n4 ? f : 0) * 4); }   // (branch-free: all four requested at once; a chunk past the end is not used below)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int f = base + u * NT;
