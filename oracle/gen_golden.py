@@ -219,13 +219,17 @@ def run_c1():
 R101 = (dict(latent_dim=64, hidden=[32], use_depth=False, no_proprioception=False, depth=101), (2,), 41, 401)
 
 
-def run_r101():
-    cfg, lead, wseed, dseed = R101
+# ... and the BasicBlock member it reaches: ResNet-18 (its option set {18, 32, 50, 101, 152} spells 34 as 32, which torchvision does not have)
+R18 = (dict(latent_dim=64, hidden=[32], use_depth=False, no_proprioception=False, depth=18), (2,), 45, 451)
+
+
+def run_r101(case=None, tag="r101"):
+    cfg, lead, wseed, dseed = case or R101
     torch.manual_seed(0)
-    model = NaiveObjectStateEstimator("cube", list(cfg["hidden"]), 101, cfg["latent_dim"], False, (9,), False, False, False)
+    model = NaiveObjectStateEstimator("cube", list(cfg["hidden"]), cfg["depth"], cfg["latent_dim"], False, (9,), False, False, False)
     sd = po.make_state("no", cfg, wseed)
     ref_keys = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
-    assert ref_keys == [(k, tuple(s)) for k, s in po.model_keys("no", cfg)], "state_dict key table mismatch (ResNet-101)"
+    assert ref_keys == [(k, tuple(s)) for k, s in po.model_keys("no", cfg)], "state_dict key table mismatch (ResNet-%d)" % cfg["depth"]
     load_values(model, "no", sd)
     rec = {"keys": np.array([k for k, _ in ref_keys])}
     model.eval()
@@ -244,8 +248,8 @@ def run_r101():
             gn.append(name)
             gd.append(digest(p.grad))
     rec["grad_keys_s1"], rec["grad_digest_s1"] = np.array(gn), np.stack(gd)
-    np.savez_compressed(os.path.join(OUT, "model_no_r101.npz"), **rec)
-    print("no_r101 loss", rec["loss_s1"])
+    np.savez_compressed(os.path.join(OUT, "model_no_%s.npz" % tag), **rec)
+    print("no_%s loss" % tag, rec["loss_s1"])
 
 
 # BASELINE.json configs[2]: the two-arm TD model on sequences of FOUR frames (lead dims (S, N) = (4, 2); the toy cases above run
@@ -523,7 +527,7 @@ def run_loss():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["loss"] + list(CASES) + ["c1", "r101", "td_s4", "hooks", "nohook", "td_cfg", "tdo_cfg", "tdo_v2_cfg", "nanloss", "frozen"]
+    which = sys.argv[1:] or ["loss"] + list(CASES) + ["c1", "r101", "r18", "td_s4", "hooks", "nohook", "td_cfg", "tdo_cfg", "tdo_v2_cfg", "nanloss", "frozen"]
     for w in which:
         if w == "loss":
             run_loss()
@@ -531,6 +535,8 @@ if __name__ == "__main__":
             run_c1()
         elif w == "r101":
             run_r101()
+        elif w == "r18":
+            run_r101(R18, "r18")
         elif w == "td_s4":
             run_td_s4()
         elif w == "hooks":

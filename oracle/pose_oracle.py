@@ -38,7 +38,8 @@ import torch.nn.functional as F
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 STAGES = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))  # planes, blocks, stride  (ResNet-50)
-BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+BLOCKS = {18: (2, 2, 2, 2), 34: (3, 4, 6, 3), 50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+BASIC = (18, 34)   # torchvision BasicBlock members (two 3x3 convs, expansion 1); util/model_utils.py:130-136 reaches 18 only ("32" is no torchvision model)
 
 
 def stages(depth=50):
@@ -51,7 +52,7 @@ MODEL_KINDS = ("n", "no", "td", "tdo", "tdo_v2")
 # key tables (state_dict layout of the reference classes)
 # ----------------------------------------------------------------------------
 def resnet_keys(latent_dim, depth=50):
-    """Ordered (key, shape) list of a torchvision bottleneck ResNet (50 / 101 / 152) with fc -> latent_dim."""
+    """Ordered (key, shape) list of a torchvision ResNet (BasicBlock 18 / 34, bottleneck 50 / 101 / 152) with fc -> latent_dim."""
     out = []
 
     def conv(name, cout, cin, k):
@@ -67,6 +68,21 @@ def resnet_keys(latent_dim, depth=50):
     conv("conv1", 64, 3, 7)
     bn("bn1", 64)
     inpl = 64
+    if depth in BASIC:
+        for li, (planes, nblk, stride) in enumerate(stages(depth), start=1):
+            for b in range(nblk):
+                p = "layer%d.%d" % (li, b)
+                conv(p + ".conv1", planes, inpl, 3)
+                bn(p + ".bn1", planes)
+                conv(p + ".conv2", planes, planes, 3)
+                bn(p + ".bn2", planes)
+                if b == 0 and (stride != 1 or inpl != planes):   # (layer1.0 keeps the identity shortcut)
+                    conv(p + ".downsample.0", planes, inpl, 1)
+                    bn(p + ".downsample.1", planes)
+                inpl = planes
+        out.append(("fc.weight", (latent_dim, 512)))
+        out.append(("fc.bias", (latent_dim,)))
+        return out
     for li, (planes, nblk, stride) in enumerate(stages(depth), start=1):
         for b in range(nblk):
             p = "layer%d.%d" % (li, b)
@@ -321,6 +337,15 @@ def resnet50_forward(sd, pre, x, train, depth=50):
         for b in range(nblk):
             p = "%slayer%d.%d" % (pre, li, b)
             s = stride if b == 0 else 1
+            if depth in BASIC:   # torchvision BasicBlock: conv3x3(s) - bn - relu - conv3x3 - bn, + identity / projection, relu
+                o = _q(F.relu(_bn(sd, p + ".bn1", _q(F.conv2d(y, _qw(sd[p + ".conv1.weight"]), None, s, 1)), train)))
+                o = _bn(sd, p + ".bn2", _q(F.conv2d(o, _qw(sd[p + ".conv2.weight"]), None, 1, 1)), train)
+                if (p + ".downsample.0.weight") in sd:
+                    idn = _q(_bn(sd, p + ".downsample.1", _q(F.conv2d(y, _qw(sd[p + ".downsample.0.weight"]), None, s)), train))
+                else:
+                    idn = y
+                y = _q(F.relu(o + idn))
+                continue
             o = _q(F.relu(_bn(sd, p + ".bn1", _q(F.conv2d(y, _qw(sd[p + ".conv1.weight"]))), train)))
             o = _q(F.relu(_bn(sd, p + ".bn2", _q(F.conv2d(o, _qw(sd[p + ".conv2.weight"]), None, s, 1)), train)))
             o = _bn(sd, p + ".bn3", _q(F.conv2d(o, _qw(sd[p + ".conv3.weight"]))), train)

@@ -8,8 +8,8 @@ Neither is installed in this image and neither is part of the reference tree
 in this container we register the two modules below in ``sys.modules`` before
 importing it.  They restate the PUBLISHED algorithms:
 
-* ``torchvision.models.resnet50``: ResNet-50 v1.5 (He et al. 2015, stride on
-  the 3x3 conv), attribute names conv1/bn1/relu/maxpool/layer1-4/avgpool/fc,
+* ``torchvision.models.resnet50`` (and 101 / 152; 18 / 34 with BasicBlock):
+  ResNet v1.5 (He et al. 2015, stride on the 3x3 conv), attribute names conv1/bn1/relu/maxpool/layer1-4/avgpool/fc,
   kaiming_normal_(fan_out, relu) conv init, BN weight 1 / bias 0.
 * ``robosuite.utils.transform_utils`` (~v1.0, mid 2020): xyzw quaternions,
   ``quat_distance(q1, q0) = q1 * q0^-1`` and ``quat2axisangle`` returning the
@@ -57,9 +57,33 @@ class _Bottleneck(nn.Module):
         return self.relu(out)
 
 
-class _ResNet(nn.Module):
-    def __init__(self, blocks, num_classes=1000):
+class _BasicBlock(nn.Module):
+    """torchvision BasicBlock (ResNet-18 / 34): two 3x3 convs, stride on the first, expansion 1."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out += identity
+        return self.relu(out)
+
+
+class _ResNet(nn.Module):
+    def __init__(self, blocks, num_classes=1000, block=_Bottleneck):
+        super().__init__()
+        self.block = block
         self.inplanes = 64
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
@@ -70,7 +94,7 @@ class _ResNet(nn.Module):
         self.layer3 = self._stage(256, blocks[2], 2)
         self.layer4 = self._stage(512, blocks[3], 2)
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
-        self.fc = nn.Linear(512 * 4, num_classes)
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
@@ -79,16 +103,16 @@ class _ResNet(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def _stage(self, planes, n, stride):
-        down = None
-        if stride != 1 or self.inplanes != planes * 4:
+        down, block = None, self.block
+        if stride != 1 or self.inplanes != planes * block.expansion:
             down = nn.Sequential(
-                nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False),
-                nn.BatchNorm2d(planes * 4),
+                nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride=stride, bias=False),
+                nn.BatchNorm2d(planes * block.expansion),
             )
-        layers = [_Bottleneck(self.inplanes, planes, stride, down)]
-        self.inplanes = planes * 4
+        layers = [block(self.inplanes, planes, stride, down)]
+        self.inplanes = planes * block.expansion
         for _ in range(1, n):
-            layers.append(_Bottleneck(self.inplanes, planes))
+            layers.append(block(self.inplanes, planes))
         return nn.Sequential(*layers)
 
     def forward(self, x):
@@ -101,6 +125,14 @@ def _resnet50(pretrained=False, **kw):
     # pretrained=True would be a network fetch: never attempted (no egress);
     # the caller gets the seeded random init instead.
     return _ResNet([3, 4, 6, 3])
+
+
+def _resnet18(pretrained=False, **kw):
+    return _ResNet([2, 2, 2, 2], block=_BasicBlock)
+
+
+def _resnet34(pretrained=False, **kw):
+    return _ResNet([3, 4, 6, 3], block=_BasicBlock)
 
 
 def _resnet101(pretrained=False, **kw):
@@ -167,6 +199,7 @@ def install():
         tvm = types.ModuleType("torchvision.models")
         tvt = types.ModuleType("torchvision.transforms")
         tvm.resnet50, tvm.resnet101, tvm.resnet152 = _resnet50, _resnet101, _resnet152
+        tvm.resnet18, tvm.resnet34 = _resnet18, _resnet34   # (no resnet32: util/model_utils.py:130's "32" raises AttributeError there too)
         for name in ("Compose", "ToPILImage", "Resize", "CenterCrop", "ToTensor", "Normalize"):
             setattr(tvt, name, _Inert)
         tv.models, tv.transforms = tvm, tvt

@@ -13,6 +13,8 @@ C1 = (dict(latent_dim=512, hidden=[1024, 256, 64], use_depth=False, no_proprioce
 SAMPLE_STRIDE, SAMPLE_MAX = 997, 4096
 # NaiveObjectStateEstimator on ResNet-101 (import_resnet's deeper bottleneck option) -- must match oracle/gen_golden.py R101
 R101 = (dict(latent_dim=64, hidden=[32], use_depth=False, no_proprioception=False, depth=101), (2,), 41, 401)
+# ... and on ResNet-18, the BasicBlock member import_resnet reaches -- must match oracle/gen_golden.py R18
+R18 = (dict(latent_dim=64, hidden=[32], use_depth=False, no_proprioception=False, depth=18), (2,), 45, 451)
 # BASELINE.json configs[2]: the two-arm TD model on sequences of four frames -- must match oracle/gen_golden.py TD_S4
 TD_S4 = (dict(latent_dim=64, hidden=32, use_depth=False), (4, 2), 51, 501)
 # feature_layer_nums other than (9,): every hook the reference can run at 224x224 (given out of order), depth heads on; and None
