@@ -169,11 +169,11 @@ def main():
         raise SystemExit("--model %s runs (S, N) = (4, batch/4) sequences: --batch must be a multiple of 4" % args.model)
     lead = (4, args.batch // 4) if seq else (args.batch,)
     builders = {
-        "no": lambda: M.NaiveObjectStateEstimator("cube", [1024, 256, 64], 50, 512, False, (9,), dh, False, False, compute_dtype=dtype),
-        "n": lambda: M.NaiveEndEffectorStateEstimator([1024, 256, 64], [1024, 256, 64], 50, 512, False, compute_dtype=dtype),
-        "td": lambda: M.TemporallyDependentStateEstimator(512, 512, 50, 512, 4, 0.1, False, (9,), dh, False, compute_dtype=dtype),
-        "tdo": lambda: M.TemporallyDependentObjectStateEstimator("hammer", 512, 50, 512, 4, 0.1, False, (9,), dh, False, False, compute_dtype=dtype),
-        "tdo_v2": lambda: M.TemporallyDependentObjectStateEstimatorV2("robot1_eef", 512, 64, 50, 512, 4, 0.1, False, (9,), dh, False, compute_dtype=dtype),
+        "no": lambda: M.NaiveObjectStateEstimator("cube", [1024, 256, 64], args.resnet, 512, False, (9,), dh, False, False, compute_dtype=dtype),
+        "n": lambda: M.NaiveEndEffectorStateEstimator([1024, 256, 64], [1024, 256, 64], args.resnet, 512, False, compute_dtype=dtype),
+        "td": lambda: M.TemporallyDependentStateEstimator(512, 512, args.resnet, 512, 4, 0.1, False, (9,), dh, False, compute_dtype=dtype),
+        "tdo": lambda: M.TemporallyDependentObjectStateEstimator("hammer", 512, args.resnet, 512, 4, 0.1, False, (9,), dh, False, False, compute_dtype=dtype),
+        "tdo_v2": lambda: M.TemporallyDependentObjectStateEstimatorV2("robot1_eef", 512, 64, args.resnet, 512, 4, 0.1, False, (9,), dh, False, compute_dtype=dtype),
     }
     workloads = {
         "no": "NaiveObjectStateEstimator train step (BASELINE.json configs[1]): ResNet-50 trunk + bn1 aux head + proprio MLP [1024,256,64] + PoseDistanceLoss(combined, alpha 0.5) + Adam",
@@ -375,7 +375,8 @@ def main():
             # device-side NaN test of the loss value (two small elementwise launches per step, inside the timed region since round 3).
             "precondition_s": round(precondition_s, 2), "precondition_steps": precondition_steps,
             "host_issue_ms_per_step": round(host_issue_ms, 2), "host_loop_ms_per_step": round(host_loop_ms, 2),
-            "config": {"workload": workloads[args.model] + (" [use_depth=True]" if dh else ""), "model": args.model,
+            "config": {"workload": (workloads[args.model] if args.resnet == 50 else workloads[args.model].replace("ResNet-50", "ResNet-%d" % args.resnet).replace("BASELINE.json ", "as BASELINE.json ")) +
+                                   (" [use_depth=True]" if dh else ""), "model": args.model,
                        "images_per_gpu": args.batch, "global_batch": args.batch * world, "resolution": 224, "latent_dim": 512,
                        "parallelism": "dp%d" % world + (" (RCCL world 1: staged joins + bucketed all-reduce on one GPU)" if args.force_dist else ""),
                        "launch": "hipGraph replay" if use_graph else "eager", "final_loss": final_loss, "nan_loss_steps": nan_loss_steps,
@@ -386,7 +387,10 @@ def main():
         ips = imgs / dt / world
         out["step_roofline"] = {"tflops_per_gpu": round(ips * 24.52e9 / 1e12, 2), "frac_mfma": round(ips * 24.52e9 / 1e12 / PEAK_TFLOPS[args.dtype], 4),
                                 "ideal_fused_gbs_per_gpu": round(ips * 152.9e6 / 1e9, 1), "frac_hbm": round(ips * 152.9e6 / 1e9 / PEAK_HBM_GBS, 4)}
-        if world == 1 and not args.no_cpu_baseline and args.model == "no" and not dh and not args.force_dist:
+        if args.resnet != 50:   # a side record: the per-image constants above and the metric are the ResNet-50 workload's
+            out.pop("step_roofline")
+            out["metric"] += " [side record: ResNet-%d trunk, not the BASELINE workload]" % args.resnet
+        if world == 1 and not args.no_cpu_baseline and args.model == "no" and not dh and not args.force_dist and args.resnet == 50:
             out["cpu_baseline"], ref_first = cpu_baseline()
             del model, opt
             torch.cuda.empty_cache()

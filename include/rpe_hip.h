@@ -414,8 +414,12 @@ typedef struct rpe_resnet50 rpe_resnet50_t;
 #define RPE_RESNET50_NUM_BUFFERS 106
 
 int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, int width, int dtype, int latent_dim);
-/* the same engine for the deeper bottleneck ResNets the reference's import_resnet offers (util/model_utils.py:130-136):
- * depth 50 ([3,4,6,3] blocks), 101 ([3,4,23,3]) or 152 ([3,8,36,3]); the BasicBlock networks (18, 34) have no plan */
+/* the same engine for every ResNet the reference's import_resnet offers (util/model_utils.py:130-136): the bottleneck networks
+ * depth 50 ([3,4,6,3] blocks), 101 ([3,4,23,3]) or 152 ([3,8,36,3]), and the BasicBlock networks 18 ([2,2,2,2] blocks of two 3x3
+ * convs, identity shortcut in layer1.0, fc input 512) or 34 ([3,4,6,3]).  Parameter / buffer tables in torchvision's order for that
+ * depth (rpe_resnet50_param_name); the rpe_resnet50_* entry points below take the handle of any depth.  The BasicBlock plan is
+ * the general launch sequence (conv + statistics, finalize, apply; fused data gradient + BatchNorm reduction; dz, y -> dy; weight
+ * gradients on the second stream) -- the bottleneck-only forms (folded conv3 backward, y3-free blocks) do not apply to it. */
 int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int height, int width, int dtype, int latent_dim);
 void rpe_resnet50_destroy(rpe_resnet50_t* e);
 /* bytes of device workspace the engine needs (activations, gradients, packed weights, scratch) */

@@ -303,13 +303,14 @@ def run_td_s4():
 # output, bn1, layer1..3 (given out of order: aux_nets follow the order the hooks FIRE in) -- with the depth heads on; and None (no
 # early features).  Key table, pristine eval output, step-1 outputs / loss / gradient digests + the head gradients whole.
 HOOKS = (dict(latent_dim=64, hidden=[32], use_depth=True, no_proprioception=False, hooks=(3, 0, 9, 2, 1)), (2,), 61, 601)
+HOOKS18 = (dict(latent_dim=64, hidden=[32], use_depth=True, no_proprioception=False, hooks=(3, 0, 9, 2, 1), depth=18), (2,), 63, 603)   # the same on resnet18
 NOHOOK = (dict(latent_dim=64, hidden=[32], use_depth=False, no_proprioception=False, hooks=None), (2,), 62, 602)
 
 
 def run_hooks(tag, case):
     cfg, lead, wseed, dseed = case
     torch.manual_seed(0)
-    model = NaiveObjectStateEstimator("cube", list(cfg["hidden"]), 50, cfg["latent_dim"], False, cfg["hooks"], cfg["use_depth"], False, False)
+    model = NaiveObjectStateEstimator("cube", list(cfg["hidden"]), cfg.get("depth", 50), cfg["latent_dim"], False, cfg["hooks"], cfg["use_depth"], False, False)
     sd = po.make_state("no", cfg, wseed)
     ref_keys = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
     assert ref_keys == [(k, tuple(s)) for k, s in po.model_keys("no", cfg)], "state_dict key table mismatch (%s)" % tag
@@ -527,7 +528,7 @@ def run_loss():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["loss"] + list(CASES) + ["c1", "r101", "r18", "td_s4", "hooks", "nohook", "td_cfg", "tdo_cfg", "tdo_v2_cfg", "nanloss", "frozen"]
+    which = sys.argv[1:] or ["loss"] + list(CASES) + ["c1", "r101", "r18", "td_s4", "hooks", "hooks18", "nohook", "td_cfg", "tdo_cfg", "tdo_v2_cfg", "nanloss", "frozen"]
     for w in which:
         if w == "loss":
             run_loss()
@@ -541,6 +542,8 @@ if __name__ == "__main__":
             run_td_s4()
         elif w == "hooks":
             run_hooks("hooks", HOOKS)
+        elif w == "hooks18":
+            run_hooks("hooks18", HOOKS18)
         elif w == "nohook":
             run_hooks("nohook", NOHOOK)
         elif w == "frozen":

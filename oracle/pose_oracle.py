@@ -127,6 +127,12 @@ def hooks_of(cfg):
     return [x for x in HOOK_ORDER if x in h]
 
 
+def hook_channels(layer, cfg):
+    """channels of a hooked map: the layer outputs of a BasicBlock trunk have planes, not 4 x planes, channels"""
+    c = HOOK_SHAPE[layer][0]
+    return c // 4 if (layer in (1, 2, 3) and cfg.get("depth", 50) in BASIC) else c
+
+
 def hook_pools(layer):
     """number of AvgPool2d(2) steps of the depth head (models/naive.py:235-236)"""
     c, hw = HOOK_SHAPE[layer]
@@ -157,12 +163,12 @@ def model_keys(kind, cfg):
     keys += [(fpre + k, s) for k, s in resnet_keys(L, cfg.get("depth", 50))]
     if kind in ("no", "tdo", "tdo_v2"):   # nn.ModuleList(aux_nets) is registered before nn.ModuleList(depth_nets)
         for i, h in enumerate(hooks):
-            keys += [("aux_nets.%d.module.0.weight" % i, (1, HOOK_SHAPE[h][0], 1, 1)), ("aux_nets.%d.module.0.bias" % i, (1,))]
+            keys += [("aux_nets.%d.module.0.weight" % i, (1, hook_channels(h, cfg), 1, 1)), ("aux_nets.%d.module.0.bias" % i, (1,))]
         for i, h in enumerate(hooks):
             keys += [("depth_nets.%d.module.%d.weight" % (i, hook_pools(h)), (1,)), ("depth_nets.%d.module.%d.bias" % (i, hook_pools(h)), (1,))]
     if kind == "td":
         for i, h in enumerate(hooks):
-            keys += [("~aux_nets.%d.0.weight" % i, (1, HOOK_SHAPE[h][0], 1, 1)), ("~aux_nets.%d.0.bias" % i, (1,))]
+            keys += [("~aux_nets.%d.0.weight" % i, (1, hook_channels(h, cfg), 1, 1)), ("~aux_nets.%d.0.bias" % i, (1,))]
         for i, h in enumerate(hooks):
             keys += [("~depth_nets.%d.%d.weight" % (i, hook_pools(h)), (1,)), ("~depth_nets.%d.%d.bias" % (i, hook_pools(h)), (1,))]
     if kind == "n":

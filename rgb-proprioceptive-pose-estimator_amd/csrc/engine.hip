@@ -36,7 +36,10 @@ struct ConvL {
 };
 
 struct Block {
-    int c1, c2, c3, cd;  // conv indices (cd = -1: identity shortcut)
+    int c1, c2, c3, cd;  // conv indices (cd = -1: identity shortcut; c3 = -1: a BasicBlock -- two 3x3 convs, ResNet-18 / 34)
+    int out = -1;        // the conv whose BatchNorm output (+ shortcut, ReLU) is the block's output: c3, or c2 of a BasicBlock
+    int layer = 0;       // 1..4
+    bool first = false;  // first block of its layer (the input of a stage-entry block of layers 2..4 is a hookable layer output)
     void* dz = nullptr;  // backward: ReLU-masked gradient at the block output (kept as the shortcut gradient)
     // y3-free block (rpe_resnet50::y3free): fp32 [ones_row + 1][planes] Gram matrix + column sums of conv3's input, written by the forward
     // (BN3 statistics without y3) and read again by the backward's weight-gradient combine; dzt_a: fp32 [4 planes][planes] = dz3^T a2
@@ -57,6 +60,8 @@ struct Named {
 
 struct rpe_resnet50 {
     int B, H, W, dtype, latent;
+    int feat = 2048;     // channels of the last block = inputs of fc (512 for the BasicBlock networks)
+    bool basic = false;  // ResNet-18 / 34: BasicBlock (3x3, 3x3) instead of Bottleneck (1x1, 3x3, 1x1) blocks
     size_t esz;
     std::vector<ConvL> convs;
     std::vector<Block> blocks;
@@ -272,38 +277,58 @@ extern "C" int rpe_resnet50_create(rpe_resnet50_t** out, int batch, int height, 
     return rpe_resnet_create(out, 50, batch, height, width, dtype, latent_dim);
 }
 
-// depth: 50, 101 or 152 -- the bottleneck members of the family util/model_utils.py:130-136 offers (18 / 34 are BasicBlock networks)
+// depth: 50, 101 or 152 -- the bottleneck members of the family util/model_utils.py:130-136 offers -- or 18 / 34, its BasicBlock members
+// (the reference's option set reaches 18; the same plan covers 34).  The BasicBlock plan is built from the same launches as the
+// bottleneck plan's general path (conv + statistics, finalize, apply; fused data gradient + BatchNorm reduction, dz, y -> dy, weight
+// gradient on the second stream); the bottleneck-only dataflow changes (folded conv3 backward, y3-free blocks) do not apply to it.
 extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int height, int width, int dtype, int latent_dim) {
     if (!out) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_create: null out");
-    if (depth != 50 && depth != 101 && depth != 152) return rpe_set_error(RPE_ERR_SHAPE, "resnet_create: depth must be 50, 101 or 152 (bottleneck ResNets)");
+    if (depth != 18 && depth != 34 && depth != 50 && depth != 101 && depth != 152)
+        return rpe_set_error(RPE_ERR_SHAPE, "resnet_create: depth must be 18, 34 (BasicBlock) or 50, 101, 152 (bottleneck)");
     if (batch <= 0 || latent_dim <= 0) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_create: bad batch/latent");
     if (height < 32 || width < 32 || (height % 32) || (width % 32)) return rpe_set_error(RPE_ERR_SHAPE, "resnet50_create: H, W must be multiples of 32");
     if (dtype != RPE_F32 && dtype != RPE_BF16 && dtype != RPE_F16) return rpe_set_error(RPE_ERR_DTYPE, "resnet50_create: dtype must be RPE_F32, RPE_BF16 or RPE_F16");
     rpe_resnet50* e = new rpe_resnet50();
     e->B = batch; e->H = height; e->W = width; e->dtype = dtype; e->latent = latent_dim;
     e->esz = dtype == RPE_F32 ? 4 : 2;
+    e->basic = depth == 18 || depth == 34;
+    e->feat = e->basic ? 512 : 2048;
     add_conv(e, "conv1", "bn1", height, width, 3, 64, 7, 2, 3);
     int h = e->convs[0].Ho / 2, w = e->convs[0].Wo / 2;  // after maxpool 3x3/2 pad 1 (even sizes)
     int inpl = 64;
     const int planes[4] = {64, 128, 256, 512}, strides[4] = {1, 2, 2, 2};
-    const int nblk[4] = {3, depth == 152 ? 8 : 4, depth == 50 ? 6 : (depth == 101 ? 23 : 36), 3};
+    const int nblk18[4] = {2, 2, 2, 2};
+    const int nblk50[4] = {3, depth == 152 ? 8 : 4, (depth == 50 || depth == 34) ? 6 : (depth == 101 ? 23 : 36), 3};
+    const int* nblk = depth == 18 ? nblk18 : nblk50;
     for (int li = 0; li < 4; ++li) {
         for (int b = 0; b < nblk[li]; ++b) {
             const std::string p = "layer" + std::to_string(li + 1) + "." + std::to_string(b);
             const int s = b == 0 ? strides[li] : 1;
             Block blk;
+            blk.layer = li + 1; blk.first = b == 0;
+            if (e->basic) {
+                blk.c1 = add_conv(e, p + ".conv1", p + ".bn1", h, w, inpl, planes[li], 3, s, 1);
+                const int h2 = e->convs[blk.c1].Ho, w2 = e->convs[blk.c1].Wo;
+                blk.c2 = add_conv(e, p + ".conv2", p + ".bn2", h2, w2, planes[li], planes[li], 3, 1, 1);
+                blk.c3 = -1; blk.cd = -1; blk.out = blk.c2;
+                if (b == 0 && (s != 1 || inpl != planes[li])) blk.cd = add_conv(e, p + ".downsample.0", p + ".downsample.1", h, w, inpl, planes[li], 1, s, 0);
+                e->blocks.push_back(blk);
+                inpl = planes[li];
+                h = h2; w = w2;
+                continue;
+            }
             blk.c1 = add_conv(e, p + ".conv1", p + ".bn1", h, w, inpl, planes[li], 1, 1, 0);
             blk.c2 = add_conv(e, p + ".conv2", p + ".bn2", h, w, planes[li], planes[li], 3, s, 1);
             const int h2 = e->convs[blk.c2].Ho, w2 = e->convs[blk.c2].Wo;
             blk.c3 = add_conv(e, p + ".conv3", p + ".bn3", h2, w2, planes[li], planes[li] * 4, 1, 1, 0);
-            blk.cd = -1;
+            blk.cd = -1; blk.out = blk.c3;
             if (b == 0) blk.cd = add_conv(e, p + ".downsample.0", p + ".downsample.1", h, w, inpl, planes[li] * 4, 1, s, 0);
             e->blocks.push_back(blk);
             inpl = planes[li] * 4;
             h = h2; w = w2;
         }
     }
-    e->pnames.push_back("fc.weight"); e->pnumel.push_back((long)latent_dim * 2048);
+    e->pnames.push_back("fc.weight"); e->pnumel.push_back((long)latent_dim * e->feat);
     e->pnames.push_back("fc.bias"); e->pnumel.push_back(latent_dim);
     e->latent_pad = (latent_dim + 3) / 4 * 4;
 
@@ -338,13 +363,13 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
     const long pool_n = (long)batch * (st.Ho / 2) * (st.Wo / 2) * 64;
     want(e, &e->pool, pool_n * es);
     want(e, (void**)&e->pool_idx, pool_n);
-    want(e, (void**)&e->pooled, (long)batch * 2048 * 4);
-    want(e, (void**)&e->d_pooled, (long)batch * 2048 * 4);
-    want(e, (void**)&e->fc_wt, 2048L * e->latent_pad * 4);
+    want(e, (void**)&e->pooled, (long)batch * e->feat * 4);
+    want(e, (void**)&e->d_pooled, (long)batch * e->feat * 4);
+    want(e, (void**)&e->fc_wt, (long)e->feat * e->latent_pad * 4);
     want(e, &e->early_grad, st.rows * 64 * es);
     for (int i = 0; i < 2; ++i) want(e, &e->G[i], max_act * es);
     for (auto& b : e->blocks) {
-        const ConvL& c3 = e->convs[b.c3];
+        const ConvL& c3 = e->convs[b.out];
         want(e, &b.dz, c3.rows * c3.d.out_c * es);
         if (dtype != RPE_F32) want(e, (void**)&b.relu_mask, c3.rows * c3.d.out_c / 8);
     }
@@ -357,7 +382,7 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
     want(e, (void**)&e->dpart, RPE_BN_DPART_DOUBLES(2048) * 8);
     want(e, (void**)&e->dpart2, RPE_BN_DPART_DOUBLES(2048) * 8);
     want(e, (void**)&e->stem_dw, 64L * 256 * 4);
-    e->fold = getenv("RPE_NO_BN_FOLD") == nullptr;
+    e->fold = !e->basic && getenv("RPE_NO_BN_FOLD") == nullptr;   // (the folds below are forms of the bottleneck's 1x1 convs)
     if (e->fold) {
         long wk = 0;
         for (auto& b : e->blocks) {
@@ -425,13 +450,13 @@ extern "C" int rpe_resnet_create(rpe_resnet50_t** out, int depth, int batch, int
         }
         if (e->wg_slab_bytes > 0) want(e, &e->wg_slab, e->wg_slab_bytes);
         e->main_slab_bytes = rpe_stem_conv_wgrad_workspace_bytes(dtype, batch, height, width);
-        const long fcb = rpe_linear_wgrad_workspace_bytes(RPE_F32, batch, latent_dim, 2048);
+        const long fcb = rpe_linear_wgrad_workspace_bytes(RPE_F32, batch, latent_dim, e->feat);
         if (fcb > e->main_slab_bytes) e->main_slab_bytes = fcb;
         if (y3_slab > e->main_slab_bytes) e->main_slab_bytes = y3_slab;
         if (e->main_slab_bytes > 0) want(e, &e->main_slab, e->main_slab_bytes);
     }
     {
-        const long f = rpe_linear_fwd_workspace_bytes(RPE_F32, batch, latent_dim, 2048), d = rpe_linear_fwd_workspace_bytes(RPE_F32, batch, 2048, e->latent_pad);
+        const long f = rpe_linear_fwd_workspace_bytes(RPE_F32, batch, latent_dim, e->feat), d = rpe_linear_fwd_workspace_bytes(RPE_F32, batch, e->feat, e->latent_pad);
         e->fc_ws_bytes = f > d ? f : d;
         if (e->fc_ws_bytes > 0 && getenv("RPE_NO_LINEAR_SPLITK") == nullptr) want(e, &e->fc_ws, e->fc_ws_bytes);
     }
@@ -624,7 +649,7 @@ extern "C" int rpe_resnet50_pack_weights(rpe_resnet50_t* e, void* stream) {
     PROF(e, RPE_PROF_OTHER, stream, rpe_pack_conv_weights_multi(e->dtype, e->pack_tab, (int)e->convs.size() - 1, e->pack_total, stream));
     e->pack_state = 1;
     const int np = (int)e->pnames.size();
-    TRY(rpe_transpose_f32(e->params[np - 2], e->fc_wt, e->latent, 2048, 2048, e->latent_pad, stream));
+    TRY(rpe_transpose_f32(e->params[np - 2], e->fc_wt, e->latent, e->feat, e->feat, e->latent_pad, stream));
     return 0;
 }
 
@@ -856,7 +881,7 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
     static const bool ds_fuse_ok = getenv("RPE_NO_DS_FUSE") == nullptr;
     const bool fuse_ds = ds_fuse_ok && training;
     for (auto& b : e->blocks) {
-        ConvL &c1 = e->convs[b.c1], &c2 = e->convs[b.c2], &c3 = e->convs[b.c3];
+        ConvL &c1 = e->convs[b.c1], &c2 = e->convs[b.c2], &c3 = e->convs[b.out];
         const void* idn = x;
         hipEvent_t ds_done = nullptr;
         // (training only.  An INFERENCE frame stays on one stream: with the fork / join to the second stream a batch-1 frame took 3-4 ms
@@ -876,6 +901,17 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
             idn = cd.a;
         }
         TRY(conv_bn(e, c1, x, nullptr, 1, stream));
+        if (e->basic) {
+            // BasicBlock: out = relu(bn2(conv2(relu(bn1(conv1 x)))) + shortcut); the projection shortcut as in the bottleneck plan (second
+            // stream, its BatchNorm applied inside bn2's apply pass when training)
+            static const bool use_mask_b = getenv("RPE_NO_RELU_MASK") == nullptr;
+            if (b.cd >= 0 && !ds_done) { ConvL& cd = e->convs[b.cd]; TRY(conv_bn(e, cd, x, nullptr, 0, stream, false, nullptr, nullptr, fuse_ds)); idn = cd.a; }
+            if (ds_done) HIPTRY(hipStreamWaitEvent((hipStream_t)stream, ds_done, 0));
+            if (b.cd >= 0 && fuse_ds) TRY(conv_bn(e, c2, c1.a, e->convs[b.cd].y, 1, stream, false, use_mask_b ? b.relu_mask : nullptr, &e->convs[b.cd]));
+            else TRY(conv_bn(e, c2, c1.a, idn, 1, stream, false, use_mask_b ? b.relu_mask : nullptr));
+            x = c2.a;
+            continue;
+        }
         const bool y3f_fwd = training && b.gram && b.relu_mask;
         const bool fused_gram = y3f_fwd && e->apply_gram && (c2.d.out_c == 64 || c2.d.out_c == 128);
         TRY(conv_bn(e, c2, c1.a, nullptr, 1, stream, false, nullptr, nullptr, false, fused_gram ? b.gram : nullptr));
@@ -904,10 +940,10 @@ static int forward_impl(rpe_resnet50_t* e, const float* img_nchw, const unsigned
         TRY(conv_bn(e, c3, c2.a, idn, 1, stream, false, use_mask ? b.relu_mask : nullptr));   // (relu_mask is null for fp32 engines)
         x = c3.a;
     }
-    ConvL& last = e->convs[e->blocks.back().c3];
-    TRY(rpe_avgpool_fwd(e->dtype, last.a, e->pooled, e->B, last.Ho * last.Wo, 2048, stream));
+    ConvL& last = e->convs[e->blocks.back().out];
+    TRY(rpe_avgpool_fwd(e->dtype, last.a, e->pooled, e->B, last.Ho * last.Wo, e->feat, stream));
     const int np = (int)e->pnames.size();
-    TRY(rpe_linear_fwd_ws(RPE_F32, e->pooled, 2048, e->params[np - 2], 2048, e->params[np - 1], features, (int)ld_features, e->B, e->latent, 2048, 0,
+    TRY(rpe_linear_fwd_ws(RPE_F32, e->pooled, e->feat, e->params[np - 2], e->feat, e->params[np - 1], features, (int)ld_features, e->B, e->latent, e->feat, 0,
                           nullptr, 0, e->fc_ws, e->fc_ws ? e->fc_ws_bytes : 0, stream));
     e->fwd_done = training != 0;
     return 0;
@@ -1099,20 +1135,20 @@ extern "C" int rpe_resnet50_backward_begin(rpe_resnet50_t* e, const float* d_fea
     // fc
     float* dWfc = e->grads[np - 2];
     if (e->main_slab) {
-        TRY(rpe_linear_wgrad_det(RPE_F32, d_features, (int)ld_d_features, e->pooled, 2048, dWfc, 2048, e->B, e->latent, 2048, 0, e->main_slab, e->main_slab_bytes, stream));
+        TRY(rpe_linear_wgrad_det(RPE_F32, d_features, (int)ld_d_features, e->pooled, e->feat, dWfc, e->feat, e->B, e->latent, e->feat, 0, e->main_slab, e->main_slab_bytes, stream));
     } else {
-        if (!e->gspan_lo) HIPTRY(hipMemsetAsync(dWfc, 0, (size_t)e->latent * 2048 * 4, s));
-        TRY(rpe_linear_wgrad(RPE_F32, d_features, (int)ld_d_features, e->pooled, 2048, dWfc, 2048, e->B, e->latent, 2048, stream));
+        if (!e->gspan_lo) HIPTRY(hipMemsetAsync(dWfc, 0, (size_t)e->latent * e->feat * 4, s));
+        TRY(rpe_linear_wgrad(RPE_F32, d_features, (int)ld_d_features, e->pooled, e->feat, dWfc, e->feat, e->B, e->latent, e->feat, stream));
     }
     TRY(rpe_colsum(d_features, e->B, e->latent, (int)ld_d_features, e->grads[np - 1], 0, stream));
     // d_pooled[B][2048] = d_features[B][latent] * Wfc[latent][2048]  ==  NT with weight fc_wt [2048][latent_pad].
     // K runs to latent_pad: the extra columns of d_features (whatever the caller keeps there) meet zero weights.
     if ((ld_d_features & 3) || ld_d_features < e->latent_pad)
         return rpe_set_error(RPE_ERR_ALIGN, "resnet50_backward: ld_d_features must be a multiple of 4 and >= pad4(latent_dim)");
-    TRY(rpe_linear_fwd_ws(RPE_F32, d_features, (int)ld_d_features, e->fc_wt, e->latent_pad, nullptr, e->d_pooled, 2048, e->B, 2048, e->latent_pad, 0,
+    TRY(rpe_linear_fwd_ws(RPE_F32, d_features, (int)ld_d_features, e->fc_wt, e->latent_pad, nullptr, e->d_pooled, e->feat, e->B, e->feat, e->latent_pad, 0,
                           nullptr, 0, e->fc_ws, e->fc_ws ? e->fc_ws_bytes : 0, stream));
-    ConvL& last = e->convs[e->blocks.back().c3];
-    TRY(rpe_avgpool_bwd(e->dtype, e->d_pooled, e->blocks.back().dz, e->B, last.Ho * last.Wo, 2048, stream));
+    ConvL& last = e->convs[e->blocks.back().out];
+    TRY(rpe_avgpool_bwd(e->dtype, e->d_pooled, e->blocks.back().dz, e->B, last.Ho * last.Wo, e->feat, stream));
     e->bwd_next = (int)e->blocks.size() - 1;
     return 0;
 }
@@ -1134,16 +1170,42 @@ extern "C" int rpe_resnet50_backward_blocks(rpe_resnet50_t* e, int count, int jo
     // it one launch later (1x1 beside 3x3) measured slower (+0.3 ms/step).
     for (; bi >= 0 && count > 0; --bi, --count) {
         Block& b = e->blocks[bi];
-        ConvL &c1 = e->convs[b.c1], &c2 = e->convs[b.c2], &c3 = e->convs[b.c3];
-        const void* x_in = bi == 0 ? (const void*)e->pool : (const void*)e->convs[e->blocks[bi - 1].c3].a;
+        ConvL &c1 = e->convs[b.c1], &c2 = e->convs[b.c2], &c3 = e->convs[b.out];
+        const void* x_in = bi == 0 ? (const void*)e->pool : (const void*)e->convs[e->blocks[bi - 1].out].a;
         void* gA = b.dz;                                             // dz3 (for the last block: the raw dA)
         void* gD = bi == 0 ? e->d_pool : e->blocks[bi - 1].dz;       // where the gradient of the block input goes
         // a hooked layer output (the input of a stage-entry block) carries one more gradient term: it joins the shortcut gradient
         const void* hook_in = nullptr;
-        if (b.cd >= 0 && bi > 0) {
-            int layer = 0;
-            for (int j = 0; j <= bi; ++j) layer += e->blocks[j].cd >= 0;
-            if (layer >= 2 && layer <= 4) hook_in = e->hook_grad[layer - 1];
+        if (b.first && b.layer >= 2) hook_in = e->hook_grad[b.layer - 1];   // (stage-entry blocks of layers 2..4 have a projection shortcut in every member)
+        if (e->basic) {
+            // BasicBlock, entering with gA = dz2 (ReLU-masked gradient at the block output; for the last block: the raw dA) and -- except for
+            // the last block -- bn2's partial sums left by the next block's fused conv1 data gradient
+            if (bi == (int)e->blocks.size() - 1) TRY(bn_back(e, c2, gA, 1, c2.dy, gA, stream));   // dy2, dz2 (in place)
+            else TRY(bn_from_dz(e, c2, gA, c2.dy, stream));                                        // dy2 (gA keeps dz2 = the shortcut gradient)
+            TRY(wgrad(e, c2, c1.a, c2.dy, stream));
+            TRY(dgrad_fused(e, c2, c2.dy, c1.dy, nullptr, &c1, 2, stream));                        // dz1 (+ bn1's partial sums)
+            TRY(bn_from_dz(e, c1, c1.dy, c1.dy, stream));
+            TRY(wgrad(e, c1, x_in, c1.dy, stream));
+            const void* shortcut = gA;
+            if (b.cd >= 0) {
+                ConvL& cd = e->convs[b.cd];
+                shortcut = e->G[0];
+                TRY(bn_back(e, cd, gA, 0, cd.dy, nullptr, stream));                                // no ReLU on the projection shortcut
+                TRY(wgrad(e, cd, x_in, cd.dy, stream));
+                e->pending_flops = conv_flops(cd);
+                e->pending_bytes = conv_out_bytes(e, cd) + conv_in_bytes(e, cd) * (hook_in ? 2.0 : 1.0);
+                PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&cd.d, e->dtype, cd.dy, cd.wd, e->G[0], hook_in, stream));
+            }
+            static const bool use_mask_b = getenv("RPE_NO_RELU_MASK") == nullptr;
+            if (bi > 0) {
+                const Block& pb = e->blocks[bi - 1];
+                TRY(dgrad_fused(e, c1, c1.dy, gD, shortcut, &e->convs[pb.out], 1, stream, use_mask_b ? pb.relu_mask : nullptr));   // dz2 of the previous block
+            } else {
+                e->pending_flops = conv_flops(c1);
+                e->pending_bytes = conv_out_bytes(e, c1) + conv_in_bytes(e, c1) * 2.0;
+                PROF(e, RPE_PROF_CONV_DGRAD, stream, rpe_conv2d_dgrad(&c1.d, e->dtype, c1.dy, c1.wd, gD, shortcut, stream));
+            }
+            continue;
         }
         static const bool ds_fold_ok = getenv("RPE_NO_DS_FOLD") == nullptr;
         const bool y3f = b.gram && b.relu_mask && !e->y3_keep;   // this block's y3 was never written
@@ -1340,10 +1402,10 @@ extern "C" int rpe_resnet50_backward_frozen(rpe_resnet50_t* e, const float* d_fe
     hipStream_t s = (hipStream_t)stream;
     float* dWfc = e->grads[np - 2];
     if (e->main_slab) {
-        TRY(rpe_linear_wgrad_det(RPE_F32, d_features, (int)ld_d_features, e->pooled, 2048, dWfc, 2048, e->B, e->latent, 2048, 0, e->main_slab, e->main_slab_bytes, stream));
+        TRY(rpe_linear_wgrad_det(RPE_F32, d_features, (int)ld_d_features, e->pooled, e->feat, dWfc, e->feat, e->B, e->latent, e->feat, 0, e->main_slab, e->main_slab_bytes, stream));
     } else {
-        HIPTRY(hipMemsetAsync(dWfc, 0, (size_t)e->latent * 2048 * 4, s));
-        TRY(rpe_linear_wgrad(RPE_F32, d_features, (int)ld_d_features, e->pooled, 2048, dWfc, 2048, e->B, e->latent, 2048, stream));
+        HIPTRY(hipMemsetAsync(dWfc, 0, (size_t)e->latent * e->feat * 4, s));
+        TRY(rpe_linear_wgrad(RPE_F32, d_features, (int)ld_d_features, e->pooled, e->feat, dWfc, e->feat, e->B, e->latent, e->feat, stream));
     }
     TRY(rpe_colsum(d_features, e->B, e->latent, (int)ld_d_features, e->grads[np - 1], 0, stream));
     e->aux_dout = nullptr;                                    // (an aux head's gradient towards bn1 has nowhere to go)

@@ -13,7 +13,9 @@ from . import ops
 from ._lib import ResizePlan, lib
 from .util.data_utils import crop_origin, pil_bilinear_tables, resized_hw
 
-_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}   # bottleneck ResNets (util/model_utils.py:130-136 also lists 18 / 34: BasicBlock, no plan)
+# util/model_utils.py:130-136: the bottleneck members 50 / 101 / 152 and the BasicBlock member 18 (its "32" is no torchvision model; 34 runs on the same plan)
+_BLOCKS = {18: (2, 2, 2, 2), 34: (3, 4, 6, 3), 50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+_BASIC = (18, 34)
 _PLANES_STRIDES = ((64, 1), (128, 2), (256, 2), (512, 2))
 
 
@@ -37,8 +39,23 @@ class _BottleneckParams(nn.Module):
         raise RuntimeError("parameter container only: the trunk runs as one native plan (ResNet50Trunk.run)")
 
 
+class _BasicBlockParams(nn.Module):
+    """torchvision BasicBlock (ResNet-18 / 34): conv3x3(stride) - bn - relu - conv3x3 - bn, + identity / projection, relu"""
+    def __init__(self, inplanes, planes, stride, project):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        if project:
+            self.downsample = _Shortcut(nn.Conv2d(inplanes, planes, 1, stride=stride, bias=False), nn.BatchNorm2d(planes))
+
+    def forward(self, *a, **k):
+        raise RuntimeError("parameter container only: the trunk runs as one native plan (ResNet50Trunk.run)")
+
+
 class ResNet50Trunk(nn.Module):
-    """ResNet-50 v1.5 parameters + native forward/backward plan.
+    """ResNet v1.5 parameters (depth 50 by default; 101 / 152, BasicBlock 18 / 34) + native forward/backward plan.
 
     compute_dtype: torch.bfloat16 (default; fp32 accumulate, fp32 master weights) or torch.float32
     (exact-fp32 MFMA path used for the 1e-4 parity bar).
@@ -47,18 +64,23 @@ class ResNet50Trunk(nn.Module):
     def __init__(self, num_outputs=1000, compute_dtype=torch.bfloat16, depth=50):
         super().__init__()
         if depth not in _BLOCKS:
-            raise NotImplementedError("only the bottleneck ResNets (50, 101, 152) have a native MI355X launch plan (requested resnet%d)" % depth)
+            raise NotImplementedError("no native MI355X launch plan for resnet%d (18, 34, 50, 101, 152 have one)" % depth)
         self.depth = depth
+        self.expansion = 1 if depth in _BASIC else 4
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         inpl = 64
         for li, ((planes, stride), n) in enumerate(zip(_PLANES_STRIDES, _BLOCKS[depth]), start=1):
             blocks = []
             for b in range(n):
-                blocks.append(_BottleneckParams(inpl, planes, stride if b == 0 else 1, b == 0))
-                inpl = planes * 4
+                s = stride if b == 0 else 1
+                if depth in _BASIC:
+                    blocks.append(_BasicBlockParams(inpl, planes, s, b == 0 and (s != 1 or inpl != planes)))
+                else:
+                    blocks.append(_BottleneckParams(inpl, planes, s, b == 0))
+                inpl = planes * self.expansion
             setattr(self, "layer%d" % li, nn.Sequential(*blocks))
-        self.fc = nn.Linear(2048, num_outputs)
+        self.fc = nn.Linear(512 * self.expansion, num_outputs)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
@@ -81,7 +103,9 @@ class ResNet50Trunk(nn.Module):
         pairs = [(self.conv1, self.bn1)]
         for li in range(1, 5):
             for blk in getattr(self, "layer%d" % li):
-                pairs += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2), (blk.conv3, blk.bn3)]
+                pairs += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)]
+                if hasattr(blk, "conv3"):
+                    pairs.append((blk.conv3, blk.bn3))
                 if hasattr(blk, "downsample"):
                     pairs.append((blk.downsample[0], blk.downsample[1]))
         params = []
@@ -270,7 +294,7 @@ class _Plan:
             return self.early_feature()
         if layer == 0:
             return self.tensor("conv1.y").view(self.batch, self.h // 2, self.w // 2, 64)
-        t = self.tensor("layer%d.%d.conv3.a" % (layer, _BLOCKS[self.trunk.depth][layer - 1] - 1))
+        t = self.tensor("layer%d.%d.%s.a" % (layer, _BLOCKS[self.trunk.depth][layer - 1] - 1, "conv2" if self.trunk.depth in _BASIC else "conv3"))
         s = 2 << layer   # layer1: 1/4 of the image, layer2: 1/8, layer3: 1/16
         return t.view(self.batch, self.h // s, self.w // s, t.shape[1])
 

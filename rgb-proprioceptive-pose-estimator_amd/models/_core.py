@@ -121,6 +121,8 @@ class PoseModelBase(nn.Module):
         trunk, _ = import_resnet(num_resnet_layers, latent_dim, feature_extract, use_pretrained=use_pretrained,
                                  compute_dtype=self.compute_dtype)
         self.feature_net = trunk  # registered first, as in the reference, so state_dict order matches
+        if trunk.expansion != 4:   # BasicBlock trunk (resnet18): the layer outputs have planes, not 4 x planes, channels
+            self.HOOK_SHAPES = {k: ((c // 4 * trunk.expansion) if k in (1, 2, 3) else c, h, w) for k, (c, h, w) in self.HOOK_SHAPES.items()}
         self._hooks = []
         if feature_layer_nums is not None:
             layers = list(feature_layer_nums)

@@ -22,17 +22,19 @@ def set_parameter_requires_grad(model, feature_extracting):
 
 
 def import_resnet(num_layers, output_dim, feature_extract=True, use_pretrained=True, compute_dtype=torch.bfloat16):
-    """ResNet feature extractor with its fc replaced by Linear(2048, output_dim).
+    """ResNet feature extractor with its fc replaced by Linear(fc.in_features, output_dim) (2048; 512 for resnet18).
 
     Same contract as util/model_utils.py:116-147: validates `num_layers` against the reference's
     option set (which spells 34 as 32), freezes the body iff `feature_extract and use_pretrained`,
-    the new fc is always trainable, returns (model, 224).  Depths 50, 101 and 152 (the bottleneck members) have a
-    native launch plan; every caller of the reference passes 50 (scripts/train_model.py:63).
+    the new fc is always trainable, returns (model, 224).  Every member the reference can build has a native launch
+    plan: the bottleneck networks 50 / 101 / 152 and the BasicBlock network 18 (fc input 512); "32" passes the reference's
+    assert and then fails in `getattr(models, "resnet32")` -- the same AttributeError is raised here.  Every caller of the
+    reference passes 50 (scripts/train_model.py:63).
     """
     options = {18, 32, 50, 101, 152}
     assert num_layers in options, "Invalid layer size specified. Options are: {}".format(options)
-    if num_layers not in (50, 101, 152):   # 18 / "32" (the reference's spelling of 34) are BasicBlock networks
-        raise NotImplementedError("only the bottleneck ResNets (50, 101, 152) have a native MI355X launch plan (requested resnet%d)" % num_layers)
+    if num_layers == 32:   # util/model_utils.py:136: getattr(models, "resnet32") -- torchvision has no such model
+        raise AttributeError("module 'torchvision.models' has no attribute 'resnet32'")
     model = ResNet50Trunk(1000, compute_dtype=compute_dtype, depth=num_layers)
     if use_pretrained:
         path = os.environ.get(PRETRAINED_ENV)

@@ -20,6 +20,7 @@ TD_S4 = (dict(latent_dim=64, hidden=32, use_depth=False), (4, 2), 51, 501)
 # feature_layer_nums other than (9,): every hook the reference can run at 224x224 (given out of order), depth heads on; and None
 # -- must match oracle/gen_golden.py HOOKS / NOHOOK
 HOOKS = (dict(latent_dim=64, hidden=[32], use_depth=True, no_proprioception=False, hooks=(3, 0, 9, 2, 1)), (2,), 61, 601)
+HOOKS18 = (dict(latent_dim=64, hidden=[32], use_depth=True, no_proprioception=False, hooks=(3, 0, 9, 2, 1), depth=18), (2,), 63, 603)   # ... on resnet18
 NOHOOK = (dict(latent_dim=64, hidden=[32], use_depth=False, no_proprioception=False, hooks=None), (2,), 62, 602)
 # BASELINE.json configs[2..4] at the head sizes the reference's scripts train (latent 512, hidden 512, proprio hidden 64), lead dims
 # (S, N) = (4, 8) -- must match oracle/gen_golden.py SEQ_CFG

@@ -203,20 +203,26 @@ def test_model_bf16_tracks_fp32_reference(kind, golden_dir):
             assert torch.isfinite(p.grad).all(), name
 
 
-def test_resnet101_trunk_matches_reference(golden_dir):
-    """import_resnet's deeper bottleneck option on the same native engine ([3,4,23,3] blocks): state_dict keys, pristine eval
-    output and train step 1 against the reference's vectors (fp32 path, 1e-4 bar), gradients against the oracle."""
-    from _helpers_cases import R101
-    gold = np.load(os.path.join(golden_dir, "model_no_r101.npz"))
-    cfg, lead, wseed, dseed = R101
+@pytest.mark.parametrize("tag,dtype", [("r101", torch.float32), ("r18", torch.float32), ("r18", torch.bfloat16), ("r18", torch.float16)])
+def test_resnet101_trunk_matches_reference(golden_dir, tag, dtype):
+    """import_resnet's other members on the same native engine -- the deeper bottleneck option ([3,4,23,3] blocks) and the BasicBlock
+    network resnet18 ([2,2,2,2] blocks of two 3x3 convs, fc input 512; util/model_utils.py:130-136): state_dict keys, pristine eval
+    output and train step 1 against the reference's vectors (fp32 path, 1e-4 bar; 16-bit: the output bars of the other model tests),
+    gradients against the oracle."""
+    import _helpers_cases as hc
+    gold = np.load(os.path.join(golden_dir, "model_no_%s.npz" % tag))
+    cfg, lead, wseed, dseed = getattr(hc, tag.upper())
+    f32 = dtype == torch.float32
+    bar = 1e-4 if f32 else (5e-2 if dtype == torch.bfloat16 else 1.5e-2)
     sd = po.make_state("no", cfg, wseed)
-    model = build("no", cfg, torch.float32)
+    model = build("no", cfg, dtype)
     assert list(model.state_dict().keys()) == list(gold["keys"])
+    assert model.trunk.fc.in_features == (512 if tag == "r18" else 2048)
     load_values(model, "no", sd)
     model.cuda().eval()
     b9 = to_dev(po.synth_batch(lead, dseed + 9))
     with torch.no_grad():
-        assert rel(model(b9["img"], None, b9["x0bar"]), gold["pre_eval_out0"]) < 2e-4
+        assert rel(model(b9["img"], None, b9["x0bar"]), gold["pre_eval_out0"]) < (2e-4 if f32 else bar)
     model.train()
     crit = M.PoseDistanceLoss(distance_metric="combined", scale_factor=1.0, alpha=0.5, mode="pose")
     b1c = po.synth_batch(lead, dseed + 1)
@@ -224,20 +230,28 @@ def test_resnet101_trunk_matches_reference(golden_dir):
     out = model(b1["img"], None, b1["x0bar"])
     loss = crit(out, b1["obj"])
     loss.backward()
-    assert rel(out, gold["out0_s1"]) < 1e-4
-    np.testing.assert_allclose(loss.item(), gold["loss_s1"], rtol=1e-4)
-    ref = po.train_step("no", cfg, {k: v.clone() for k, v in sd.items()}, b1c, LOSS_CFG, {}, lr=1e-3, val_metrics=False)
+    assert rel(out, gold["out0_s1"]) < bar
+    np.testing.assert_allclose(loss.item(), gold["loss_s1"], rtol=bar)
     named = dict(model.named_parameters())
+    for name, p in named.items():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    if not f32:
+        return
+    ref = po.train_step("no", cfg, {k: v.clone() for k, v in sd.items()}, b1c, LOSS_CFG, {}, lr=1e-3, val_metrics=False)
     cos = []
     for name, g in ref["grads"].items():
         if float(g.abs().max()) == 0.0:
             continue
         a, b = named[name].grad.detach().cpu().double().flatten(), g.double().flatten()
         cos.append((torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-300)).item())
-    # 101 layers of train-mode BN at batch 2 amplify fp32 rounding further than ResNet-50 does (see the module docstring)
-    assert np.median(cos) > 0.95 and min(cos) > 0.5, (np.median(cos), min(cos))
-    with pytest.raises(NotImplementedError):
-        M.NaiveObjectStateEstimator("cube", [32], 18, 64, False, (9,), False, False, False)
+    # 101 layers of train-mode BN at batch 2 amplify fp32 rounding further than ResNet-50 does (see the module docstring); the 18-layer
+    # network is held to a tighter bar
+    if tag == "r18":
+        assert np.median(cos) > 0.999 and min(cos) > 0.95, (np.median(cos), min(cos))
+        for name, refd in zip(gold["grad_keys_s1"], gold["grad_digest_s1"]):   # every gradient's norm as in the reference
+            np.testing.assert_allclose(named[str(name)].grad.double().norm().item(), refd[1], rtol=5e-2, atol=1e-7, err_msg=str(name))
+    else:
+        assert np.median(cos) > 0.95 and min(cos) > 0.5, (np.median(cos), min(cos))
 
 
 def test_resnet152_trunk_runs_and_matches_the_oracle():
@@ -316,16 +330,17 @@ def test_td_four_frame_sequences_match_reference(dtype, bar, golden_dir):
 
 
 @pytest.mark.parametrize("tag,dtype,bar", [("hooks", torch.float32, 1e-4), ("hooks", torch.bfloat16, 5e-2), ("hooks", torch.float16, 1.5e-2),
-                                           ("nohook", torch.float32, 1e-4), ("nohook", torch.bfloat16, 5e-2)])
+                                           ("nohook", torch.float32, 1e-4), ("nohook", torch.bfloat16, 5e-2),
+                                           ("hooks18", torch.float32, 1e-4), ("hooks18", torch.bfloat16, 5e-2), ("hooks18", torch.float16, 1.5e-2)])
 def test_other_hook_layers_match_reference(tag, dtype, bar, golden_dir):
     """feature_layer_nums other than the scripts' (9,) (models/naive.py:196-240): hooks on conv1, bn1 and layer1..3 -- given out of
     order, depth heads on -- and None, against the reference's vectors: state_dict keys (aux_nets in hook FIRING order), pristine
     eval output, step-1 output / loss; fp32: every gradient's norm and the head gradients element-wise."""
     import _helpers_cases as hc
-    cfg, lead, wseed, dseed = hc.HOOKS if tag == "hooks" else hc.NOHOOK
+    cfg, lead, wseed, dseed = {"hooks": hc.HOOKS, "hooks18": hc.HOOKS18, "nohook": hc.NOHOOK}[tag]   # (hooks18: the same hooks on the BasicBlock trunk)
     gold = np.load(os.path.join(golden_dir, "model_no_%s.npz" % tag))
     sd = po.make_state("no", cfg, wseed)
-    model = M.NaiveObjectStateEstimator("cube", list(cfg["hidden"]), 50, cfg["latent_dim"], False, cfg["hooks"], cfg["use_depth"], False, False,
+    model = M.NaiveObjectStateEstimator("cube", list(cfg["hidden"]), cfg.get("depth", 50), cfg["latent_dim"], False, cfg["hooks"], cfg["use_depth"], False, False,
                                         compute_dtype=dtype)
     assert list(model.state_dict().keys()) == list(gold["keys"])
     load_values(model, "no", sd)

@@ -76,6 +76,15 @@ def test_import_resnet_contract():
     with pytest.warns(UserWarning):
         m, _ = import_resnet(50, 12, feature_extract=True, use_pretrained=True)
     assert [n for n, p in m.named_parameters() if p.requires_grad] == ["fc.weight", "fc.bias"]
+    # "32" passes the reference's assert and then fails in getattr(models, "resnet32") (util/model_utils.py:136); 18 is the BasicBlock
+    # network: fc -> Linear(512, output_dim), identity shortcut in layer1.0, projection shortcuts in layer2..4.0, torchvision's key table
+    with pytest.raises(AttributeError):
+        import_resnet(32, 10, False, False)
+    net, size = import_resnet(18, 8, True, False)
+    assert size == 224 and net.fc.in_features == 512 and net.fc.out_features == 8
+    assert not hasattr(net.layer1[0], "downsample") and hasattr(net.layer2[0], "downsample") and not hasattr(net.layer1[0], "conv3")
+    from oracle import pose_oracle as po
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(s)) for k, s in po.resnet_keys(8, 18)]
 
 
 def test_pretrained_checkpoint_ingestion_and_freezing(tmp_path, monkeypatch):
