@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--model", default="no", choices=["no", "n", "td", "tdo", "tdo_v2"],
                     help="model family: no = NaiveObjectStateEstimator (BASELINE configs[1], the default and the metric's workload); td / tdo / tdo_v2 = the "
                          "sequence models of configs[2..4] at (S, N) = (4, batch/4), latent 512, hidden 512 (proprio hidden 64)")
+    ap.add_argument("--resnet", type=int, default=50, choices=[18, 50, 101, 152], help="num_resnet_layers of the trunk (the metric's workload is 50; the others are "
+                    "side records of import_resnet's remaining members, util/model_utils.py:130-136)")
     ap.add_argument("--depth-head", action="store_true", help="use_depth=True (configs[3]: TDO + auxiliary depth head)")
     ap.add_argument("--force-dist", action="store_true", help="N = 1 only: initialise RCCL with one rank and run the data-parallel path "
                     "(parameter broadcast, staged stream joins, bucketed SUM all-reduce) so that its cost on one GPU is measured")

@@ -1102,3 +1102,61 @@ def test_bn_reduce_handoff_under_load():
         else:
             assert torch.equal(res, first), "repetition %d differs" % it
     torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------ torch.ops.rpe.* (dispatcher registration, torch_ops.py)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 14, 14, 64, 64, 3, 1, 1), (2, 16, 16, 64, 128, 3, 2, 1), (2, 28, 28, 64, 256, 1, 1, 0)])
+def test_torch_ops_conv2d_autograd(dtype, cfg):
+    """`torch.ops.rpe.conv2d` (one differentiable dispatcher op built from the forward / data-gradient / weight-gradient launches) against
+    F.conv2d and torch autograd on the CPU in fp32; the plain ops are bitwise the ctypes wrappers they register."""
+    import rgb_proprioceptive_pose_estimator_amd.torch_ops  # noqa: F401  (registers torch.ops.rpe)
+    b, h, w_, ci, co, k, s, p = cfg
+    g = torch.Generator().manual_seed(b * 100 + co + k)
+    x = torch.randn(b, ci, h, w_, generator=g)
+    w = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+    xr, wr = q(x, dtype).requires_grad_(), q(w, dtype).requires_grad_()
+    yr = F.conv2d(xr, wr, None, s, p)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(q(dy, dtype))
+    xd = nhwc(x).to(dtype).to(DEV).requires_grad_()
+    wd = nhwc(w).to(dtype).to(DEV).requires_grad_()
+    y = torch.ops.rpe.conv2d(xd, wd, s, p)
+    y.backward(nhwc(dy).to(dtype).to(DEV))
+    assert rel_err(nchw(y), yr) < tol(dtype)
+    assert rel_err(nchw(xd.grad), xr.grad) < tol(dtype) * 2
+    assert rel_err(nchw(wd.grad), wr.grad) < max(tol(dtype) * 2, 1e-4)
+    assert torch.equal(torch.ops.rpe.conv2d_fwd(xd.detach(), wd.detach(), s, p), ops.conv2d_fwd(xd.detach(), wd.detach(), s, p))
+    with pytest.raises(NotImplementedError):   # CUDA (= HIP) dispatch key only: no CPU fallback behind the op
+        torch.ops.rpe.conv2d_fwd(nhwc(x), nhwc(w), s, p)
+
+
+def test_torch_ops_loss_adam_linear_bn():
+    """The remaining dispatcher ops: `pose_distance_loss` (value + gradient through autograd) against the oracle's loss, `adam_step`
+    against the oracle's update, `linear_fwd` and `bn_apply` against torch on the CPU."""
+    import rgb_proprioceptive_pose_estimator_amd.torch_ops  # noqa: F401
+    g = torch.Generator().manual_seed(5)
+    pred, truth = torch.randn(6, 7, generator=g), torch.randn(6, 7, generator=g)
+    truth[:, 3:] = F.normalize(truth[:, 3:], dim=-1)
+    pr = pred.clone().requires_grad_()
+    ref = po.pose_loss(pr, truth, metric="combined", scale=1.0, alpha=0.5, eps=1e-4, mode="pose")
+    ref.backward()
+    pd = pred.to(DEV).requires_grad_()
+    loss, _ = torch.ops.rpe.pose_distance_loss(pd, truth.to(DEV), 3, 1, 1.0, 0.5, 1e-4)
+    (2.0 * loss).backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-5)
+    assert rel_err(pd.grad, 2.0 * pr.grad) < 1e-5
+    # Adam, two steps
+    p, gr = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+    m, v = torch.zeros(1000), torch.zeros(1000)
+    pdv, md, vd = p.to(DEV), m.to(DEV), v.to(DEV)
+    for step in (1, 2):
+        po.adam_update(p, gr, m, v, step, lr=1e-3)
+        torch.ops.rpe.adam_step(pdv, gr.to(DEV), md, vd, 1e-3, 0.9, 0.999, 1e-8, step)
+    assert rel_err(pdv, p) < 1e-6 and rel_err(md, m) < 1e-6 and rel_err(vd, v) < 1e-6
+    # Linear + ReLU, BatchNorm affine map + residual + ReLU
+    x, w, b = torch.randn(40, 64, generator=g), torch.randn(24, 64, generator=g), torch.randn(24, generator=g)
+    assert rel_err(torch.ops.rpe.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), True), F.relu(x @ w.t() + b)) < 2e-5
+    y, r = torch.randn(2, 8, 8, 64, generator=g), torch.randn(2, 8, 8, 64, generator=g)
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    assert rel_err(torch.ops.rpe.bn_apply(y.to(DEV), sc.to(DEV), sh.to(DEV), r.to(DEV), True), F.relu(y * sc + sh + r)) < 2e-5

@@ -123,3 +123,26 @@ def test_pretrained_checkpoint_ingestion_and_freezing(tmp_path, monkeypatch):
     assert trunk.body_frozen()
     trunk2, _ = import_resnet(50, 64, feature_extract=False, use_pretrained=True, compute_dtype=torch.float32)   # fine-tuning: loaded, not frozen
     assert torch.equal(trunk2.state_dict()["layer3.2.conv2.weight"], ckpt["layer3.2.conv2.weight"]) and not trunk2.body_frozen()
+
+
+def test_torch_ops_are_registered_for_the_device_only():
+    """torch_ops.py: every `torch.ops.rpe.*` entry exists in the dispatcher with a schema and a fake (shape) implementation, and has a
+    kernel for the CUDA (= HIP) device type ONLY -- a CPU call fails in the dispatcher instead of reaching a fallback."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+
+    import rgb_proprioceptive_pose_estimator_amd.torch_ops as T
+    for n in T.NAMES:
+        assert getattr(torch.ops.rpe, n).default._schema.name == "rpe::" + n
+    x, w = torch.randn(1, 8, 8, 8), torch.randn(8, 3, 3, 8)
+    for call in (lambda: torch.ops.rpe.conv2d_fwd(x, w, 1, 1), lambda: torch.ops.rpe.conv2d(x, w, 1, 1),
+                 lambda: torch.ops.rpe.pose_loss(torch.randn(2, 7), torch.randn(2, 7), 3, 1, 1.0, 0.5, 1e-4),
+                 lambda: torch.ops.rpe.adam_step(torch.zeros(8), torch.zeros(8), torch.zeros(8), torch.zeros(8), 1e-3, 0.9, 0.999, 1e-8, 1)):
+        with pytest.raises(NotImplementedError):
+            call()
+    with FakeTensorMode():
+        xf, wf = torch.empty(2, 16, 16, 8, device="cuda", dtype=torch.bfloat16), torch.empty(16, 3, 3, 8, device="cuda", dtype=torch.bfloat16)
+        y = torch.ops.rpe.conv2d(xf, wf, 2, 1)
+        assert y.shape == (2, 8, 8, 16) and y.dtype == torch.bfloat16
+        assert torch.ops.rpe.conv2d_wgrad(xf, y, 3, 2, 1).shape == (16, 3, 3, 8)
+        assert torch.ops.rpe.conv2d_dgrad(y, wf.permute(3, 1, 2, 0), [2, 16, 16, 8], 2, 1).shape == (2, 16, 16, 8)
