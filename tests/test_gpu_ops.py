@@ -1115,7 +1115,7 @@ def test_torch_ops_conv2d_autograd(dtype, cfg):
     g = torch.Generator().manual_seed(b * 100 + co + k)
     x = torch.randn(b, ci, h, w_, generator=g)
     w = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
-    xr, wr = q(x, dtype).requires_grad_(), q(w, dtype).requires_grad_()
+    xr, wr = q(x, dtype).clone().requires_grad_(), q(w, dtype).clone().requires_grad_()   # (q() may return its argument itself)
     yr = F.conv2d(xr, wr, None, s, p)
     dy = torch.randn(yr.shape, generator=g)
     yr.backward(q(dy, dtype))
