@@ -494,6 +494,13 @@ const char* rpe_last_kernel_name(void);
  * Results do not depend on it (partial sums are indexed by tile).  The engine sets mode 2 around its training step and restores the
  * caller's mode; RPE_NO_WALK_ALT=1 keeps it at 0.  No reference counterpart (scheduling only). */
 void rpe_set_walk_direction(int mode);
+/* Narrowest feature map (in pixels) whose 3x3 / stride-1 / pad-1 DETERMINISTIC weight gradient (rpe_conv2d_wgrad_det, 16-bit element types,
+ * out_c % 64 == 0, in_c % 32 == 0 [% 64 for 64 output channels], width <= 60) runs in the halo form (csrc/wgrad_halo.hip: all nine taps in
+ * one workgroup, x streamed once through a ring of pixels in LDS; the reduction walks the zero-padded pixel grid, which costs
+ * (H + 2)(W + 2) / (H W) of the useful work -- hence a lower bound on the width).  Default 28 (RPE_WGRAD_HALO_MINW); returns the previous
+ * value.  Process-wide; set it before sizing workspaces (rpe_conv2d_wgrad_workspace_bytes follows the choice).  Scheduling / summation
+ * order only: no reference counterpart. */
+int rpe_conv2d_wgrad_halo_min_width(int width);
 /* The same backward in stages, so a data-parallel caller can all-reduce finished gradients while the rest is computed:
  * begin (fc + avgpool) -> blocks(count, join=1) ... until all 16 blocks are done -> end (stem).  After blocks(.., join=1)
  * every gradient of the blocks processed so far is complete in stream order on `stream`. */

@@ -154,6 +154,7 @@ _SPEC = {
     "rpe_resnet50_profile_kernels": (L, [P, P, L]),
     "rpe_last_kernel_name": (c_char_p, []),
     "rpe_set_walk_direction": (None, [I]),
+    "rpe_conv2d_wgrad_halo_min_width": (I, [I]),
     "rpe_resnet50_set_aux_head": (I, [P, P, P, P, P, L, P, P]),
     "rpe_resnet50_aux_head_bwd": (I, [P, P, L, P, P, P, P, P, P, P, P, L, P]),
     "rpe_aux_head_bwd_det_y": (I, [I, P, L, P, P, P, P, P, P, P, P, P, P, I, I, I, P, L, P]),

@@ -129,6 +129,9 @@ static int conv_dgrad_t(const rpe_conv_desc* d, const void* dy, const void* w_cr
 // slab / slab_bytes: workspace of the deterministic form (null: atomic accumulation); slab_query: only report the bytes needed
 template <typename T>
 static int conv_wgrad_t(const rpe_conv_desc* d, const void* x, const void* dy, float* dw, void* slab, long slab_bytes, long* slab_query, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {   // 3x3 / stride 1 / pad 1 on wide maps, deterministic form: the halo kernel (wgrad_halo.hip)
+        if ((slab || slab_query) && wgrad_halo_ok(d, dtype_of<T>())) return conv_wgrad_halo<T>(d, x, dy, dw, slab, slab_bytes, slab_query, s);
+    }
     const int Ho = out_dim(d->in_h, d->kh, d->stride, d->pad), Wo = out_dim(d->in_w, d->kw, d->stride, d->pad);
     TNArgs<T> a;
     memset(&a, 0, sizeof(a));
@@ -1050,6 +1053,8 @@ int rpe_conv2d_wgrad_det(const rpe_conv_desc* d, int dtype, const void* x, const
     if (workspace_bytes < need) return rpe_set_error(RPE_ERR_WORKSPACE, "conv2d_wgrad_det: workspace smaller than rpe_conv2d_wgrad_workspace_bytes()");
     DISPATCH(dtype, conv_wgrad_t, d, x, dy, dw_krsc, workspace, workspace_bytes, nullptr, (hipStream_t)stream);
 }
+
+int rpe_conv2d_wgrad_halo_min_width(int width) { return wgrad_halo_set_min_w(width); }
 
 long rpe_x4_bytes(int dtype, int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return -1;

@@ -184,6 +184,13 @@ template <typename T> struct TNArgs {
     long q_elems;        // elements of the tensor behind Q (conv modes: set by the caller; dense: M * ldq, filled by the launcher)
 };
 
+// halo form of the 3x3 / stride-1 / pad-1 weight gradient (wgrad_halo.hip): all nine taps of a (co tile, ci chunk) in one workgroup, x streamed
+// once through a ring of pixels in LDS.  wgrad_halo_ok: whether the deterministic (slab) weight gradient of this conv takes that form.
+bool wgrad_halo_ok(const rpe_conv_desc* d, int dtype);
+int wgrad_halo_set_min_w(int w);
+template <typename T>
+int conv_wgrad_halo(const rpe_conv_desc* d, const void* x, const void* dy, float* dw, void* slab, long slab_bytes, long* slab_query, hipStream_t s);
+
 // row-streaming 1x1 conv + BatchNorm + identity + ReLU + mask (stream1x1.hip): the y3-free bottleneck's conv3 in layers 1-2
 bool conv1x1_stream_fwd_ok(int dtype, long M, int N, int K, const void* y_out);
 template <typename T>

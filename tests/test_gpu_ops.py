@@ -1160,3 +1160,37 @@ def test_torch_ops_loss_adam_linear_bn():
     y, r = torch.randn(2, 8, 8, 64, generator=g), torch.randn(2, 8, 8, 64, generator=g)
     sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
     assert rel_err(torch.ops.rpe.bn_apply(y.to(DEV), sc.to(DEV), sh.to(DEV), r.to(DEV), True), F.relu(y * sc + sh + r)) < 2e-5
+
+
+# ------------------------------------------------------------------ halo form of the 3x3 weight gradient (csrc/wgrad_halo.hip)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cfg", [
+    # (B, H, W, Ci, Co): 128-channel form (32-channel chunks) and 64-channel form; several row spans per image, image and tensor borders,
+    # maps narrower than the default width bound (min width lowered for the call), H != W, one image, ring wrap-around (56-wide maps)
+    (2, 28, 28, 128, 128), (3, 56, 56, 64, 64), (2, 14, 14, 256, 256), (5, 7, 7, 512, 512), (2, 28, 28, 64, 128), (2, 28, 28, 128, 64),
+    (1, 20, 36, 96, 128), (9, 12, 9, 64, 64), (1, 56, 56, 128, 256), (4, 60, 60, 64, 64)])
+def test_conv_wgrad_halo_form(dtype, cfg):
+    """The deterministic 3x3 / stride-1 / pad-1 weight gradient in the halo form (all nine taps in one workgroup over the zero-padded pixel
+    grid) against torch's weight gradient on the CPU in fp32; bitwise reproducible; the width bound sends narrow maps back to the gathered
+    form and both forms agree to summation-order noise."""
+    from rgb_proprioceptive_pose_estimator_amd._lib import lib
+    b, h, w_, ci, co = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = q(torch.randn(b, ci, h, w_, generator=g), dtype)
+    wt = torch.zeros(co, ci, 3, 3, requires_grad=True)
+    y = F.conv2d(x, wt, None, 1, 1)
+    dy = q(torch.randn(y.shape, generator=g), dtype)
+    (ref,) = torch.autograd.grad(y, wt, dy)
+    xd, dyd = nhwc(x).to(dtype).to(DEV), nhwc(dy).to(dtype).to(DEV)
+    prev = lib.rpe_conv2d_wgrad_halo_min_width(2)
+    try:
+        dw = ops.conv2d_wgrad(xd, dyd, 3, 1, 1)
+        assert ops.last_kernel_name().startswith("wgrad_halo"), ops.last_kernel_name()
+        assert rel_err(dw.permute(0, 3, 1, 2), ref) < tol(dtype)
+        assert torch.equal(dw, ops.conv2d_wgrad(xd, dyd, 3, 1, 1)), "the halo-form weight gradient is not bitwise reproducible"
+        lib.rpe_conv2d_wgrad_halo_min_width(1000)
+        dwg = ops.conv2d_wgrad(xd, dyd, 3, 1, 1)
+        assert not ops.last_kernel_name().startswith("wgrad_halo")
+        assert rel_err(dw, dwg) < 1e-4
+    finally:
+        lib.rpe_conv2d_wgrad_halo_min_width(prev)
