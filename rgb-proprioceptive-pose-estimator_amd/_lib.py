@@ -169,7 +169,7 @@ _SPEC = {
     "rpe_tensor_add": (I, [I, P, P, L, P]),
 }
 # entry points whose int return value is data, not a status
-_NOT_STATUS = {"rpe_abi_version"}
+_NOT_STATUS = {"rpe_abi_version", "rpe_conv2d_wgrad_halo_min_width"}
 
 EXPORTS = tuple(_SPEC)
 
