@@ -1168,7 +1168,7 @@ def test_torch_ops_loss_adam_linear_bn():
     # (B, H, W, Ci, Co): 128-channel form (32-channel chunks) and 64-channel form; several row spans per image, image and tensor borders,
     # maps narrower than the default width bound (min width lowered for the call), H != W, one image, ring wrap-around (56-wide maps)
     (2, 28, 28, 128, 128), (3, 56, 56, 64, 64), (2, 14, 14, 256, 256), (5, 7, 7, 512, 512), (2, 28, 28, 64, 128), (2, 28, 28, 128, 64),
-    (1, 20, 36, 96, 128), (9, 12, 9, 64, 64), (1, 56, 56, 128, 256), (4, 60, 60, 64, 64)])
+    (1, 20, 36, 192, 128), (9, 12, 9, 64, 64), (1, 56, 56, 128, 256), (4, 60, 60, 64, 64)])
 def test_conv_wgrad_halo_form(dtype, cfg):
     """The deterministic 3x3 / stride-1 / pad-1 weight gradient in the halo form (all nine taps in one workgroup over the zero-padded pixel
     grid) against torch's weight gradient on the CPU in fp32; bitwise reproducible; the width bound sends narrow maps back to the gathered
