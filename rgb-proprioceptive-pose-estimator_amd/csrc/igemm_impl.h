@@ -1407,7 +1407,8 @@ template <typename T, int BI, int BJ, int MODE> static void plan_tn_cfg(TNArgs<T
     a.tiles_i = ceil_div(a.I, BI);
     a.tiles_j = ceil_div(a.J, BJ);
     const long tiles = (long)a.tiles_i * a.tiles_j;
-    constexpr long target_wgs = 512;   // (256..768 measured within +-2 %)
+    // (256..768 measured within +-2 % ALONE; RPE_TN_WGS: experiments with fewer, longer workgroups beside the data-gradient chain)
+    static const long target_wgs = getenv("RPE_TN_WGS") ? atol(getenv("RPE_TN_WGS")) : 512;
     // (scaled so the atomic / slab bytes, not the workgroup count, stay constant across tile sizes)
     const long wgs = target_wgs * (128 * 128) / (BI * BJ) / wg_div;   // (wg_div 2: one 96-KB workgroup per CU)
     // round DOWN when that still fills >= 70 % of the target: the target is what is resident at once (64 KB of LDS per

@@ -311,9 +311,15 @@ int conv_wgrad_halo(const rpe_conv_desc* d, const void* x, const void* dy, float
     a.nt = (d->out_c / BI) * a.tiles_c;
     a.G = d->batch * (d->in_h + 2) * (d->in_w + 2);
     a.E = (63 + 2 * (d->in_w + 3)) / 64;
-    // two workgroups per CU, all resident at once (RPE_WGRAD_HALO_WGS: experiments)
-    static const long target = getenv("RPE_WGRAD_HALO_WGS") ? atol(getenv("RPE_WGRAD_HALO_WGS")) : 512;
-    long splits = target / a.nt;
+    // Workgroups: 96, NOT one or two per CU.  These launches run on the engine's second stream beside the HBM-bound data-gradient chain of
+    // layers 1-2, which has the slack: what counts is how little they disturb that chain, not how soon they finish.  Measured in the step
+    // (profiles/r04_ab_wgrad_halo.txt, ms/step): gathered form 17.80; halo form with 1024 workgroups 17.87, 512: 17.82, 384: 17.77, 256: 17.73,
+    // 192: 17.69, 128: 17.68, 96: 17.63, 80: 17.68, 64: 17.77 -- although ALONE the 512-workgroup launch is the fastest (0.088 vs 0.132 ms at
+    // layer 1, profiles/r04_micro_wgrad_halo.txt).  Fewer workgroups also mean a smaller slab (147 KB each).  RPE_WGRAD_HALO_WGS overrides.
+    static const long target = getenv("RPE_WGRAD_HALO_WGS") ? atol(getenv("RPE_WGRAD_HALO_WGS")) : 96;
+    // (maps narrower than 28 pixels -- layers 3-4, where the second stream is level with the data-gradient chain -- want the launch done soon)
+    static const long target_narrow = getenv("RPE_WGRAD_HALO_WGS_NARROW") ? atol(getenv("RPE_WGRAD_HALO_WGS_NARROW")) : 512;
+    long splits = (d->in_w >= 28 ? target : target_narrow) / a.nt;
     if (splits < 1) splits = 1;
     long rps = (a.G + splits - 1) / splits;
     rps = (rps + 63) / 64 * 64;
