@@ -1408,7 +1408,11 @@ template <typename T, int BI, int BJ, int MODE> static void plan_tn_cfg(TNArgs<T
     a.tiles_j = ceil_div(a.J, BJ);
     const long tiles = (long)a.tiles_i * a.tiles_j;
     // (256..768 measured within +-2 % ALONE; RPE_TN_WGS: experiments with fewer, longer workgroups beside the data-gradient chain)
-    static const long target_wgs = getenv("RPE_TN_WGS") ? atol(getenv("RPE_TN_WGS")) : 512;
+    static const long target_all = getenv("RPE_TN_WGS") ? atol(getenv("RPE_TN_WGS")) : 512;
+    // RPE_TN_WGS_BIGM="wgs,Mmin": another target for the long reductions only (layers 1-2, where the second stream has slack)
+    static long big_wgs = 0, big_m = 0;
+    static const bool big_set = getenv("RPE_TN_WGS_BIGM") && sscanf(getenv("RPE_TN_WGS_BIGM"), "%ld,%ld", &big_wgs, &big_m) == 2 && big_wgs > 0;
+    const long target_wgs = (big_set && a.M >= big_m) ? big_wgs : target_all;
     // (scaled so the atomic / slab bytes, not the workgroup count, stay constant across tile sizes)
     const long wgs = target_wgs * (128 * 128) / (BI * BJ) / wg_div;   // (wg_div 2: one 96-KB workgroup per CU)
     // round DOWN when that still fills >= 70 % of the target: the target is what is resident at once (64 KB of LDS per
