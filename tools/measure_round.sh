@@ -19,11 +19,11 @@ cd /tmp && export TMPDIR=/tmp
 if has pmc; then
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc -o fetch -- python3 $root/bench.py $B > /dev/null 2> $out/fetch.err || echo "fetch pass failed" >> $out/progress.txt
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc -o write -- python3 $root/bench.py $B > /dev/null 2> $out/write.err || echo "write pass failed" >> $out/progress.txt
-  (cd $root && python tools/pmc_reduce.py $out/pmc/fetch_counter_collection.csv $out/pmc/write_counter_collection.csv > $out/hbm_traffic_pmc.json) && echo "pmc done" >> $out/progress.txt
+  (cd $root && python tools/pmc_reduce.py $out/pmc/fetch_counter_collection.csv $out/pmc/write_counter_collection.csv > $out/hbm_traffic_pmc.json) && echo "pmc done" >> $out/progress.txt && pmc_ok=1
   # the bench phase below looks the dominant kernel's traffic up in profiles/hbm_traffic_pmc.json and withholds it unless that file was measured on
   # the library it loaded (build id): hand it this box's fresh measurement (the caller copies the same file into profiles/ afterwards)
   [ -s $out/hbm_traffic_pmc.json ] && cp $out/hbm_traffic_pmc.json $root/profiles/hbm_traffic_pmc.json
-  rm -rf $out/pmc
+  [ -n "$pmc_ok" ] && rm -rf $out/pmc   # (a pass that aborted -- round 4's second session lost its FETCH pass to HSA_STATUS_ERROR_INVALID_PACKET_FORMAT 5 s in -- leaves the other pass's csv behind)
 fi
 if has mfma; then
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/mfma -o m -- python3 $root/bench.py $B > /dev/null 2> $out/mfma.err || echo "mfma pass failed" >> $out/progress.txt
