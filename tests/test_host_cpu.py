@@ -146,3 +146,53 @@ def test_torch_ops_are_registered_for_the_device_only():
         assert y.shape == (2, 8, 8, 16) and y.dtype == torch.bfloat16
         assert torch.ops.rpe.conv2d_wgrad(xf, y, 3, 2, 1).shape == (16, 3, 3, 8)
         assert torch.ops.rpe.conv2d_dgrad(y, wf.permute(3, 1, 2, 0), [2, 16, 16, 8], 2, 1).shape == (2, 16, 16, 8)
+
+
+@pytest.mark.parametrize("cfg", [(2, 5, 7, 3, 4), (1, 8, 8, 2, 2), (3, 4, 60, 2, 3)])
+def test_wgrad_halo_padded_grid_algebra(cfg):
+    """The algorithm of csrc/wgrad_halo.hip restated on the CPU (no HIP call): the 3x3 / stride-1 / pad-1 weight gradient as a reduction over
+    the positions g of the zero-padded pixel grid [B][H+2][W+2] with ONE uniform shift per tap, x read from a ring of 64-position blocks that
+    starts W + 3 positions before the split -- against torch's weight gradient; and the ring conditions the launcher relies on (a step reads
+    blocks t .. t + E only; PF + E + 1 blocks fit the ring of every configuration it launches)."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    b, h, w, ci, co = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(b, ci, h, w, generator=g, dtype=torch.float64)
+    wt = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, wt, None, 1, 1)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    (ref,) = torch.autograd.grad(y, wt, dy)
+    pw, ph = w + 2, h + 2
+    G, hl = b * ph * pw, w + 3
+    E = (63 + 2 * hl) // 64
+    xp = np.zeros((b, ph, pw, ci)); xp[:, 1:-1, 1:-1] = x.permute(0, 2, 3, 1).numpy()
+    dyp = np.zeros((b, ph, pw, co)); dyp[:, 1:-1, 1:-1] = dy.permute(0, 2, 3, 1).numpy()
+    xp, dyp = xp.reshape(G, ci), dyp.reshape(G, co)
+
+    def x_at(p):   # what the buffer descriptor's range check returns outside the tensor: zeros
+        return xp[p] if 0 <= p < G else np.zeros(ci)
+
+    dw = np.zeros((co, 3, 3, ci))
+    rps = 128   # two steps per split
+    for g0 in range(0, G, rps):
+        g1 = min(G, g0 + rps)
+        for step in range((g1 - g0 + 63) // 64):
+            for row in range(64):
+                gg = g0 + 64 * step + row
+                if gg >= g1:
+                    continue
+                for t in range(9):
+                    pr = 64 * step + row + (t // 3) * pw + (t % 3)          # stream position: the stream starts at grid position g0 - (W + 3)
+                    assert step <= pr // 64 <= step + E                      # the blocks a step may touch
+                    p = g0 - hl + pr
+                    assert p == gg + (t // 3 - 1) * pw + (t % 3 - 1)         # = the tap's uniform shift on the padded grid
+                    dw[:, t // 3, t % 3, :] += np.outer(dyp[gg], x_at(p))
+    np.testing.assert_allclose(dw, ref.permute(0, 2, 3, 1).numpy(), rtol=1e-10, atol=1e-10)
+    # ring capacity of the four launch configurations (wgrad_halo.hip, conv_wgrad_halo): (WI, PF, RINGP) by E
+    for wi in (2, 1):
+        for e in (1, 2):
+            pf, ring = (2, 512 if e == 2 else 256) if wi == 2 else ((1, 256) if e == 2 else (2, 256))
+            assert (pf + e + 1) * 64 <= ring
+    assert (63 + 2 * (60 + 3)) // 64 == 2   # the widest map the form takes (60 pixels) still reads two blocks ahead at most
