@@ -38,9 +38,9 @@ ENGINE_VARIANTS = [
     {"RPE_T_FUSE": "1", "RPE_Y3FREE_MAX": "256"},
     # the y3-free conv3 forward as the tiled launch instead of the row-streaming kernel; every kernel walking its row tiles upwards;
     # the weight-gradient ring at two slots of 32 rows everywhere
-    {"RPE_NO_STREAM1X1": "1", "RPE_NO_WALK_ALT": "1", "RPE_TN_RING": "1,2"},
-    # the 3x3 / stride-1 weight gradients all in the gathered form; all in the halo form (maps down to 7 pixels, one or two workgroups per CU)
-    {"RPE_NO_WGRAD_HALO": "1"},
+    # ... and every 3x3 / stride-1 weight gradient in the gathered form (with the switches above: the first session's weight-gradient path)
+    {"RPE_NO_STREAM1X1": "1", "RPE_NO_WALK_ALT": "1", "RPE_TN_RING": "1,2", "RPE_NO_WGRAD_HALO": "1"},
+    # every 3x3 / stride-1 weight gradient in the halo form (maps down to 7 pixels, two workgroups per CU)
     {"RPE_WGRAD_HALO_MINW": "7", "RPE_WGRAD_HALO_WGS": "512"},
 ]
 
