@@ -50,7 +50,7 @@ def test_engine_variant_parity(env):
     child_env = dict(os.environ)
     child_env.update(env)
     cmd = [sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_models.py"), "-q", "-x", "-p", "no:cacheprovider", "-k",
-           "(test_model_fp32_matches_reference_and_oracle and tdo_v2) or test_model_bf16_tracks_fp32_reference"]   # (fp32 golden step + the 16-bit path)
+           "(test_model_fp32_matches_reference_and_oracle and tdo_v2) or (test_model_bf16_tracks_fp32_reference and no)"]   # (fp32 golden step of a sequence model + the 16-bit path of the benchmarked model)
     r = subprocess.run(cmd, env=child_env, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=900)
     tail = (r.stdout or "")[-3000:] + (r.stderr or "")[-1000:]
     assert r.returncode == 0, "variant %r failed:\n%s" % (env, tail)
